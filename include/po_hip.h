@@ -1,0 +1,155 @@
+/*
+ * po_hip.h — C ABI of libpo_hip.so, the MI355X (gfx950) batched QP path-optimisation engine.
+ *
+ * This is the drop-in boundary for the reference's OSQP wrapper.  The reference has no FFI layer:
+ * its lower edge is the OsqpEigen::Solver member used in
+ *     /root/reference/src/solver/solver.cpp:46-77            (OsqpSolver::solve)
+ * and its upper edge is
+ *     /root/reference/include/path_optimizer/solver/solver.hpp:31-36
+ *         OsqpSolver::create(type, ReferencePath&, VehicleState&, horizon) / solve(std::vector<State>*)
+ * called only from /root/reference/src/path_optimizer/path_optimizer.cpp:182-183.
+ * Everything between those two edges (Hessian/constraint/bound assembly, the ADMM iteration, the
+ * Frenet->Cartesian output map) runs behind the entry points below.  Plain pointers and sizes only.
+ *
+ * All floating point data is IEEE double ("f64"), as in the reference.
+ */
+#ifndef PO_HIP_H_
+#define PO_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- formulations: the three subclasses OsqpSolver::create() can return (solver.cpp:30-44) ---- */
+enum {
+    PO_KP  = 0, /* "KP"  SolverKpAsInput            src/solver/solver_kp_as_input.cpp             */
+    PO_KPC = 1, /* "KPC" SolverKpAsInputConstrained src/solver/solver_kp_as_input_constrained.cpp */
+    PO_K   = 2  /* "K"   SolverKAsInput             src/solver/solver_k_as_input.cpp              */
+};
+
+/* ---- API return codes (never abort; the reference's CHECK_* aborts become codes) ---- */
+enum {
+    PO_OK              = 0,
+    PO_ERR_INVALID     = -1, /* bad argument (null pointer, N < 2, unknown formulation, ...) */
+    PO_ERR_HIP         = -2, /* a HIP runtime call failed; po_last_hip_error() has the text  */
+    PO_ERR_UNSUPPORTED = -3, /* problem does not fit the device tile (N too large)           */
+    PO_ERR_NOMEM       = -4
+};
+
+/* ---- per-path solver status; values follow OSQP's so that "solved" == 1 maps to the
+ *      reference's `solver_.solve()` returning true (OsqpEigen returns true only for OSQP_SOLVED) ---- */
+enum {
+    PO_STATUS_SOLVED            = 1,
+    PO_STATUS_MAX_ITER          = -2,
+    PO_STATUS_PRIMAL_INFEASIBLE = -3,
+    PO_STATUS_DUAL_INFEASIBLE   = -4,
+    PO_STATUS_UNSOLVED          = -10
+};
+
+/* Parameter block.  Replaces the gflags globals the reference reads during assembly
+ * (src/config/planning_flags.cpp:8-14,18-43,102-119) plus the OSQP settings
+ * (reference touches only verbosity/warm_start, src/solver/solver.cpp:48-49; the rest are
+ * OSQP defaults, except eps which this project's metric fixes at 1e-4). Immutable after po_create. */
+typedef struct po_params {
+    double d[4];            /* FLAGS_d1..d4: rear-axle -> covering-circle centre offsets          */
+    double w_curv;          /* FLAGS_KP_curvature_weight       (10)                                */
+    double w_curv_rate;     /* FLAGS_KP_curvature_rate_weight  (200)                               */
+    double w_dev;           /* FLAGS_KP_deviation_weight       (0)                                 */
+    double w_slack;         /* FLAGS_KP_slack_weight           (3)  (also used by K, k_as_input.cpp:54) */
+    double k_w_curv;        /* FLAGS_K_curvature_weight        (50)                                */
+    double k_w_curv_rate;   /* FLAGS_K_curvature_rate_weight   (200)                               */
+    double k_w_dev;         /* FLAGS_K_deviation_weight        (0)                                 */
+    double w_k_slack;       /* KPC literal 500    (solver_kp_as_input_constrained.cpp:52)          */
+    double w_kp_slack;      /* KPC literal 25000  (solver_kp_as_input_constrained.cpp:53)          */
+    double margin;          /* FLAGS_expected_safety_margin    (1.3)                               */
+    double max_steer;       /* FLAGS_max_steering_angle        (30 deg)                            */
+    double wheel_base;      /* FLAGS_wheel_base                (2.85)                              */
+    int    constraint_end_heading; /* FLAGS_constraint_end_heading (true)                          */
+    int    scaling;         /* Ruiz passes. 0 on the device path; oracle supports 10 */
+    /* ADMM (OSQP names) */
+    double eps_abs, eps_rel;            /* 1e-4, 1e-4 (project metric; OSQP default is 1e-3)       */
+    double eps_prim_inf, eps_dual_inf;  /* 1e-4, 1e-4                                              */
+    double rho0, sigma, alpha;          /* 0.1, 1e-6, 1.6                                          */
+    double adapt_tol;                   /* adaptive_rho_tolerance 5                                */
+    int    max_iter;                    /* 4000                                                    */
+    int    check_every;                 /* check_termination 25                                    */
+    int    adapt_every;                 /* adaptive-rho interval in iterations (100 = OSQP's
+                                           non-profiling default 4*check_termination); 0 = off     */
+    int    reserved;
+} po_params;
+
+typedef struct po_info {
+    int    status;      /* PO_STATUS_*                                  */
+    int    iters;       /* ADMM iterations run                          */
+    int    n_refactor;  /* numeric refactorisations after the first     */
+    int    reserved;
+    double r_prim;      /* ||Ax - z||_inf   at exit (unscaled)          */
+    double r_dual;      /* ||Px + q + A'y||_inf at exit                 */
+    double rho;         /* final rho                                    */
+    double obj;         /* 0.5 x'Px at exit                             */
+} po_info;
+
+/* One homogeneous batch: B independent paths, each with N points and the same `keep`
+ * (keep_control_steps_, solver_kp_as_input.cpp:17; ignored for PO_K; must be 4 for PO_KPC,
+ * solver_kp_as_input_constrained.cpp:17).  All arrays are row-major, path-major.
+ * Replaces the reads of ReferencePath::{getReferenceStates,getBounds,getMaxKList,getMaxKpList}
+ * (include/path_optimizer/data_struct/reference_path.hpp:34-37) and
+ * VehicleState::{getInitError,getStartState,getEndState}
+ * (include/path_optimizer/data_struct/vehicle_state_frenet.hpp:18-23). */
+typedef struct po_batch_in {
+    int formulation, B, N, keep;
+    const double *ref_x, *ref_y, *ref_z, *ref_k, *ref_s; /* [B][N]  State.{x,y,z,k,s}              */
+    const double *bounds;   /* [B][N][4][2]: circles c0..c3 x {lb (right, <=0), ub (left, >=0)}    */
+    const double *x0;       /* [B][3]: init_offset, init_heading_error, start_state.k               */
+    const double *goal_z;   /* [B]: end_state.z                                                     */
+    const double *max_k;    /* [B][N] KPC only (else NULL)                                          */
+    const double *max_kp;   /* [B][N] KPC only; indexed by CONTROL id like the reference (:179-183) */
+} po_batch_in;
+
+typedef struct po_batch_out {
+    double  *states; /* [B][N][5]: x, y, heading, k, s  (State.v = State.a = 0 in the reference)   */
+    po_info *info;   /* [B]                                                                         */
+    double  *x;      /* optional [B][n]: raw QP solution in the REFERENCE variable order, or NULL   */
+} po_batch_out;
+
+typedef struct po_handle_s *po_handle;
+
+/* Fill `p` with the reference defaults (planning_flags.cpp) and the project's ADMM settings. */
+void po_default_params(po_params *p);
+
+/* QP dimensions exactly as the reference constructors compute them
+ * (solver_kp_as_input.cpp:13-24, solver_kp_as_input_constrained.cpp:13-24, solver_k_as_input.cpp:14-20). */
+int po_problem_dims(int formulation, int N, int keep, int *n, int *m, int *C);
+
+/* keep_control_steps_ from the first <=9 arc-length gaps, with the reference's truncation
+ * (solver.cpp:22-27 + solver_kp_as_input.cpp:17). Returns keep (>=1) or PO_ERR_INVALID. */
+int po_keep_control_steps(int formulation, const double *ref_s, int N);
+
+/* One handle = one HIP device + one stream; calls on a handle are serialised. */
+int po_create(int device, const po_params *params, po_handle *out);
+int po_destroy(po_handle h);
+/* Use an existing hipStream_t (e.g. torch's current stream); NULL = the handle's own stream. */
+int po_set_stream(po_handle h, void *hip_stream);
+
+/* Host-pointer entry: H2D, solve, D2H, synchronous. */
+int po_solve_batch(po_handle h, const po_batch_in *in, const po_batch_out *out);
+/* Device-pointer entry: all pointers in `in`/`out` are device pointers; asynchronous on the stream. */
+int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out *out);
+
+/* Test/diagnostic entry: run only the device assembly and return the QP data in the REFERENCE
+ * row order: l,u [B][m]; dyn [B][N-1][3] = per-transition data-dependent A entries
+ * (KP/KPC: ds, -k^2*ds, ds ; K: -ds*k^2, ds, ds/L/cos^2) ; host pointers. */
+int po_assemble_batch(po_handle h, const po_batch_in *in, double *l, double *u, double *dyn);
+
+/* Kernel time (ms) of the last po_solve_batch* on this handle, measured with hipEvents on the
+ * handle's stream (valid after the stream has been synchronised). */
+int po_last_kernel_ms(po_handle h, float *ms);
+
+const char *po_strerror(int code);
+const char *po_last_hip_error(void);
+const char *po_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PO_HIP_H_ */

@@ -1,0 +1,137 @@
+"""ctypes loader for the CPU oracle (oracle/libpo_oracle.so).  TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from path_optimizer_amd.abi import INFO_DTYPE, PoBatchIn, PoBatchOut, PoInfo, PoParams
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libpo_oracle.so")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "po_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "libpo_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.po_oracle_wrap_angle.restype = C.c_double
+        _LIB.po_oracle_wrap_angle.argtypes = [C.c_double]
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def default_params() -> PoParams:
+    p = PoParams()
+    lib().po_oracle_default_params(C.byref(p))
+    return p
+
+
+def dims(form, N, keep):
+    n, m, c = C.c_int(), C.c_int(), C.c_int()
+    rc = lib().po_oracle_dims(form, N, keep, C.byref(n), C.byref(m), C.byref(c))
+    if rc:
+        raise ValueError(f"po_oracle_dims rc={rc}")
+    return n.value, m.value, c.value
+
+
+def keep_steps(form, ref_s):
+    ref_s = np.ascontiguousarray(ref_s, dtype=np.float64)
+    return lib().po_oracle_keep(form, _p(ref_s), len(ref_s))
+
+
+def assemble(form, params, N, keep, ref_k, ref_s, ref_z_last, bounds, x0, goal_z, max_k=None, max_kp=None):
+    """Returns (P, A, l, u) with P upper-triangular scipy CSC and A scipy CSC, reference ordering."""
+    import scipy.sparse as sp
+
+    n, m, _ = dims(form, N, keep)
+    L = lib()
+    ab, pb = L.po_oracle_nnz_bound_A(form, N, keep), L.po_oracle_nnz_bound_P(form, N, keep)
+    Pp = np.zeros(n + 1, np.int32); Pi = np.zeros(pb, np.int32); Px = np.zeros(pb)
+    Ap = np.zeros(n + 1, np.int32); Ai = np.zeros(ab, np.int32); Ax = np.zeros(ab)
+    l = np.zeros(m); u = np.zeros(m)
+    f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+    ref_k, ref_s, bounds, x0, max_k, max_kp = map(f, (ref_k, ref_s, bounds, x0, max_k, max_kp))
+    zl = C.c_double(float(ref_z_last))
+    rc = L.po_oracle_assemble(form, C.byref(params), N, keep, _p(ref_k), _p(ref_s), C.byref(zl), _p(bounds), _p(x0),
+                              C.c_double(float(goal_z)), _p(max_k), _p(max_kp), _p(Pp), _p(Pi), _p(Px), _p(Ap), _p(Ai), _p(Ax), _p(l), _p(u))
+    if rc:
+        raise ValueError(f"po_oracle_assemble rc={rc}")
+    P = sp.csc_matrix((Px[:Pp[n]], Pi[:Pp[n]], Pp), shape=(n, n))
+    A = sp.csc_matrix((Ax[:Ap[n]], Ai[:Ap[n]], Ap), shape=(m, n))
+    return P, A, l, u
+
+
+def qp_solve(P, A, l, u, params, q=None, perm=None):
+    """OSQP-style ADMM on a scipy (P upper CSC, A CSC). Returns x, y, z, info(dict)."""
+    n, m = P.shape[0], A.shape[0]
+    P = P.tocsc(); A = A.tocsc()
+    P.sort_indices(); A.sort_indices()
+    Pp = P.indptr.astype(np.int32); Pi = P.indices.astype(np.int32); Px = P.data.astype(np.float64)
+    Ap = A.indptr.astype(np.int32); Ai = A.indices.astype(np.int32); Ax = A.data.astype(np.float64)
+    l = np.ascontiguousarray(l, np.float64); u = np.ascontiguousarray(u, np.float64)
+    x = np.zeros(n); y = np.zeros(m); z = np.zeros(m)
+    qq = None if q is None else np.ascontiguousarray(q, np.float64)
+    pm = None if perm is None else np.ascontiguousarray(perm, np.int32)
+    info = PoInfo()
+    rc = lib().po_oracle_qp_solve(n, m, _p(Pp), _p(Pi), _p(Px), _p(qq), _p(Ap), _p(Ai), _p(Ax), _p(l), _p(u),
+                                  C.byref(params), _p(pm), _p(x), _p(y), _p(z), C.byref(info))
+    if rc:
+        raise RuntimeError(f"po_oracle_qp_solve rc={rc}")
+    return x, y, z, {k: getattr(info, k) for k, _ in PoInfo._fields_}
+
+
+def kkt_check(P, A, l, u, x, y, q=None):
+    n, m = P.shape[0], A.shape[0]
+    P = P.tocsc(); A = A.tocsc()
+    Pp = P.indptr.astype(np.int32); Pi = P.indices.astype(np.int32); Px = P.data.astype(np.float64)
+    Ap = A.indptr.astype(np.int32); Ai = A.indices.astype(np.int32); Ax = A.data.astype(np.float64)
+    res = np.zeros(4)
+    l = np.ascontiguousarray(l, np.float64); u = np.ascontiguousarray(u, np.float64)
+    x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64)
+    qq = None if q is None else np.ascontiguousarray(q, np.float64)
+    lib().po_oracle_kkt_check(n, m, _p(Pp), _p(Pi), _p(Px), _p(qq), _p(Ap), _p(Ai), _p(Ax), _p(l), _p(u), _p(x), _p(y), _p(res))
+    return dict(stationarity=res[0], primal_violation=res[1], complementarity=res[2], objective=res[3])
+
+
+def _batch_structs(batch, want_x):
+    n, m, _ = dims(batch.formulation, batch.N, batch.keep)
+    bi = PoBatchIn(batch.formulation, batch.B, batch.N, batch.keep, _p(batch.ref_x), _p(batch.ref_y), _p(batch.ref_z),
+                   _p(batch.ref_k), _p(batch.ref_s), _p(batch.bounds), _p(batch.x0), _p(batch.goal_z), _p(batch.max_k), _p(batch.max_kp))
+    states = np.zeros((batch.B, batch.N, 5)); info = np.zeros(batch.B, dtype=INFO_DTYPE)
+    xs = np.zeros((batch.B, n)) if want_x else None
+    bo = PoBatchOut(_p(states), _p(info), _p(xs))
+    return bi, bo, states, info, xs
+
+
+def solve_batch(batch, params=None, want_x=True):
+    """Sequential CPU solve of a synth.Batch. Returns states [B,N,5], info (structured), x [B,n]."""
+    params = params or default_params()
+    bi, bo, states, info, xs = _batch_structs(batch, want_x)
+    rc = lib().po_oracle_solve_batch(C.byref(params), C.byref(bi), C.byref(bo))
+    if rc:
+        raise RuntimeError(f"po_oracle_solve_batch rc={rc}")
+    return states, info, xs
+
+
+def output_map(form, N, xsol, ref_x, ref_y, ref_z):
+    out = np.zeros((N, 5))
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    xsol, ref_x, ref_y, ref_z = map(f, (xsol, ref_x, ref_y, ref_z))
+    lib().po_oracle_output(form, N, _p(xsol), _p(ref_x), _p(ref_y), _p(ref_z), _p(out))
+    return out

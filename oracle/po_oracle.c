@@ -1,0 +1,1276 @@
+/*
+ * po_oracle.c — CPU restatement of the reference hot path.  TEST INFRASTRUCTURE, NOT PRODUCT
+ * (see po_oracle.h for who may use it and for the parity-pinning statement).
+ *
+ * Part 1  assembly of (P, A, l, u) in the reference's variable/row order
+ *           KP  : /root/reference/src/solver/solver_kp_as_input.cpp:13-24,45-203
+ *           KPC : /root/reference/src/solver/solver_kp_as_input_constrained.cpp:13-24,45-221
+ *           K   : /root/reference/src/solver/solver_k_as_input.cpp:14-20,46-207
+ * Part 2  OSQP-style ADMM (sparse quasi-definite LDL' of the KKT system), restated from the
+ *         published algorithm; call site /root/reference/src/solver/solver.cpp:48-74
+ * Part 3  output map getOptimizedPath()  (solver_kp_as_input.cpp:26-43, solver_k_as_input.cpp:22-44)
+ * Part 4  driver mirroring OsqpSolver::solve (solver.cpp:46-77) + KKT certificate
+ *
+ * Build with -ffp-contract=off: the reference is built without FMA contraction (x86-64 baseline).
+ */
+#include "po_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+#ifndef M_PI_2
+#define M_PI_2 1.57079632679489661923
+#endif
+
+#define OSQP_MIN_SCALING 1e-4
+#define OSQP_MAX_SCALING 1e4
+#define OSQP_RHO_MIN 1e-6
+#define OSQP_RHO_MAX 1e6
+#define OSQP_RHO_EQ_OVER_INEQ 1e3
+#define OSQP_RHO_TOL 1e-4
+
+/* ------------------------------------------------------------------------------------------ */
+/* defaults                                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+void po_oracle_default_params(po_params *p) {
+    /* planning_flags.cpp:18-43 (car geometry), :8-14 (updateConfig) */
+    const double car_length = 4.9, rear_axle_to_center = 1.45;
+    memset(p, 0, sizeof(*p));
+    p->d[0] = -3.0 / 8.0 * car_length + rear_axle_to_center;
+    p->d[1] = -1.0 / 8.0 * car_length + rear_axle_to_center;
+    p->d[2] = 1.0 / 8.0 * car_length + rear_axle_to_center;
+    p->d[3] = 3.0 / 8.0 * car_length + rear_axle_to_center;
+    p->w_curv = 10;       /* :108 */
+    p->w_curv_rate = 200; /* :110 */
+    p->w_dev = 0;         /* :112 */
+    p->w_slack = 3;       /* :114 */
+    p->k_w_curv = 50;     /* :102 */
+    p->k_w_curv_rate = 200;
+    p->k_w_dev = 0;
+    p->w_k_slack = 500;
+    p->w_kp_slack = 25000;
+    p->margin = 1.3; /* :116 */
+    p->max_steer = 30.0 * M_PI / 180.0;
+    p->wheel_base = 2.85;
+    p->constraint_end_heading = 1;
+    p->scaling = 0;
+    p->eps_abs = 1e-4;
+    p->eps_rel = 1e-4;
+    p->eps_prim_inf = 1e-4;
+    p->eps_dual_inf = 1e-4;
+    p->rho0 = 0.1;
+    p->sigma = 1e-6;
+    p->alpha = 1.6;
+    p->adapt_tol = 5.0;
+    p->max_iter = 4000;
+    p->check_every = 25;
+    p->adapt_every = 100;
+}
+
+/* tools.hpp:24-35 — recursive in the reference; same fixed point as this loop */
+double po_oracle_wrap_angle(double a) {
+    for (;;) {
+        if (a > M_PI) a -= 2 * M_PI;
+        else if (a < -M_PI) a += 2 * M_PI;
+        else return a;
+    }
+}
+
+int po_oracle_keep(int form, const double *ref_s, int N) {
+    if (!ref_s || N < 2) return PO_ERR_INVALID;
+    if (form == PO_KPC) return 4; /* solver_kp_as_input_constrained.cpp:17 */
+    if (form == PO_K) return 1;   /* no held control */
+    if (form != PO_KP) return PO_ERR_INVALID;
+    double interval = 0; /* solver.cpp:19,22-27 */
+    for (int i = 1; i < N && i < 10; ++i) {
+        double d = ref_s[i] - ref_s[i - 1];
+        if (d > interval) interval = d;
+    }
+    double q = 1.2 / interval; /* solver_kp_as_input.cpp:17 */
+    int k = (q >= 2147483647.0 || q != q) ? 1 : (int)q;
+    return k > 1 ? k : 1;
+}
+
+int po_oracle_dims(int form, int N, int keep, int *n, int *m, int *C) {
+    if (N < 2) return PO_ERR_INVALID;
+    int c = 0, nn = 0, mm = 0;
+    if (form == PO_KP) {
+        if (keep < 1) return PO_ERR_INVALID;
+        c = (N + keep - 2) / keep;
+        nn = 3 * N + c + 2 * N;
+        mm = 11 * N + c + 2;
+    } else if (form == PO_KPC) {
+        if (keep != 4) return PO_ERR_INVALID;
+        c = (N + keep - 2) / keep;
+        nn = 3 * N + c + 3 * N;
+        mm = 12 * N + 3 * c + 2;
+    } else if (form == PO_K) {
+        c = N - 1;
+        nn = 4 * N - 1;
+        mm = 11 * N - 1;
+    } else {
+        return PO_ERR_INVALID;
+    }
+    if (n) *n = nn;
+    if (m) *m = mm;
+    if (C) *C = c;
+    return PO_OK;
+}
+
+int po_oracle_nnz_bound_A(int form, int N, int keep) {
+    (void)keep;
+    (void)form;
+    return 40 * N + 64; /* >= the dense writes of any formulation except K's NxN identity blocks, handled sparsely */
+}
+int po_oracle_nnz_bound_P(int form, int N, int keep) {
+    (void)keep;
+    (void)form;
+    return 8 * N + 16;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Part 1: assembly.  The reference writes into a dense zero matrix and calls sparseView();     */
+/* we record the same writes as (row, col, value, set|add) and compress, dropping exact zeros.  */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int r, c, seq, add;
+    double v;
+} trip_t;
+typedef struct {
+    trip_t *t;
+    int n, cap;
+} tripbuf;
+
+static int tb_push(tripbuf *b, int r, int c, double v, int add) {
+    if (b->n == b->cap) {
+        int nc = b->cap ? 2 * b->cap : 1024;
+        trip_t *nt = (trip_t *)realloc(b->t, (size_t)nc * sizeof(trip_t));
+        if (!nt) return -1;
+        b->t = nt;
+        b->cap = nc;
+    }
+    trip_t *e = &b->t[b->n];
+    e->r = r;
+    e->c = c;
+    e->v = v;
+    e->add = add;
+    e->seq = b->n;
+    b->n++;
+    return 0;
+}
+#define TSET(b, r, c, v) tb_push((b), (int)(r), (int)(c), (v), 0)
+#define TADD(b, r, c, v) tb_push((b), (int)(r), (int)(c), (v), 1)
+
+static int trip_cmp(const void *a, const void *b) {
+    const trip_t *x = (const trip_t *)a, *y = (const trip_t *)b;
+    if (x->c != y->c) return x->c < y->c ? -1 : 1;
+    if (x->r != y->r) return x->r < y->r ? -1 : 1;
+    return x->seq < y->seq ? -1 : (x->seq > y->seq ? 1 : 0);
+}
+
+/* Compress to CSC; upper_only keeps r<=c (OsqpEigen hands OSQP the upper triangle of P). */
+static int tb_compress(tripbuf *b, int ncols, int upper_only, int *Cp, int *Ci, double *Cx) {
+    qsort(b->t, (size_t)b->n, sizeof(trip_t), trip_cmp);
+    int nz = 0, k = 0;
+    for (int c = 0; c < ncols; ++c) {
+        Cp[c] = nz;
+        while (k < b->n && b->t[k].c == c) {
+            int r = b->t[k].r;
+            double v = 0;
+            while (k < b->n && b->t[k].c == c && b->t[k].r == r) {
+                v = b->t[k].add ? v + b->t[k].v : b->t[k].v;
+                ++k;
+            }
+            if (v != 0 && (!upper_only || r <= c)) {
+                Ci[nz] = r;
+                Cx[nz] = v;
+                ++nz;
+            }
+        }
+    }
+    Cp[ncols] = nz;
+    return nz;
+}
+
+#define BND(i, c, lu) bounds[((i) * 4 + (c)) * 2 + (lu)] /* lu: 0 = lb, 1 = ub */
+
+/* End-heading window shared by the three formulations
+ * (solver_kp_as_input.cpp:193-202, ..._constrained.cpp:211-220, solver_k_as_input.cpp:171-177).
+ * Note the SIGNED test `end_psi < 70 deg` (no fabs) — preserved. */
+static void end_heading_window(const po_params *p, double goal_z, double ref_z_last, double *lo, double *hi) {
+    *lo = -PO_ORACLE_INFTY;
+    *hi = PO_ORACLE_INFTY;
+    if (p->constraint_end_heading) {
+        double end_psi = po_oracle_wrap_angle(goal_z - ref_z_last);
+        if (end_psi < 70 * M_PI / 180) {
+            *lo = end_psi - 5 * M_PI / 180;
+            *hi = end_psi + 5 * M_PI / 180;
+        }
+    }
+}
+
+static int assemble_kp_like(int form, const po_params *p, int N, int keep, const double *ref_k,
+                            const double *ref_s, double ref_z_last, const double *bounds,
+                            const double *x0, double goal_z, const double *max_k,
+                            const double *max_kp, tripbuf *TP, tripbuf *TA, double *l, double *u) {
+    int n, m, C;
+    po_oracle_dims(form, N, keep, &n, &m, &C);
+    const int state_size = 3 * N, control_size = C;
+    const double INF = PO_ORACLE_INFTY;
+    const double kmax = tan(p->max_steer) / p->wheel_base;
+    /* ---- Hessian ---- */
+    if (form == PO_KP) { /* solver_kp_as_input.cpp:45-63 */
+        for (int i = 0; i < N; ++i) {
+            TADD(TP, 3 * i, 3 * i, p->w_dev);
+            TADD(TP, 3 * i + 2, 3 * i + 2, p->w_curv);
+            TADD(TP, state_size + control_size + i, state_size + control_size + i, p->w_slack);
+            TADD(TP, state_size + control_size + N + i, state_size + control_size + N + i, p->w_slack);
+        }
+        for (int i = 0; i < C; ++i) TADD(TP, state_size + i, state_size + i, keep * p->w_curv_rate);
+    } else { /* solver_kp_as_input_constrained.cpp:45-66 */
+        for (int i = 0; i < N; ++i) {
+            TADD(TP, 3 * i, 3 * i, p->w_dev);
+            TADD(TP, 3 * i + 2, 3 * i + 2, p->w_curv);
+            TADD(TP, state_size + control_size + i, state_size + control_size + i, p->w_slack);
+            TADD(TP, state_size + control_size + N + i, state_size + control_size + N + i, p->w_k_slack);
+        }
+        for (int i = 0; i < C; ++i) {
+            TADD(TP, state_size + i, state_size + i, keep * p->w_curv_rate);
+            TADD(TP, state_size + control_size + 2 * N + i, state_size + control_size + 2 * N + i,
+                 p->w_kp_slack * keep);
+        }
+    }
+    /* ---- transition part, identical in KP (:75-98) and KPC (:81-104) ---- */
+    for (int i = 0; i < state_size; ++i) TSET(TA, i, i, -1.0);
+    for (int i = 0; i < m; ++i) l[i] = u[i] = 0.0;
+    l[0] = u[0] = -x0[0]; /* :143-147 */
+    l[1] = u[1] = -x0[1];
+    l[2] = u[2] = -x0[2];
+    for (int i = 0; i < N - 1; ++i) {
+        const double k = ref_k[i];
+        const double ds = ref_s[i + 1] - ref_s[i];
+        const double a10 = -pow(k, 2);
+        /* A = a*ds + I with a = [[0,1,0],[a10,0,1],[0,0,0]] */
+        const double Am[3][3] = {{0 * ds + 1, 1 * ds + 0, 0 * ds + 0},
+                                 {a10 * ds + 0, 0 * ds + 1, 1 * ds + 0},
+                                 {0 * ds + 0, 0 * ds + 0, 0 * ds + 1}};
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) TSET(TA, 3 * (i + 1) + r, 3 * i + c, Am[r][c]);
+        const int ci = i / keep;
+        TSET(TA, 3 * (i + 1) + 0, state_size + ci, 0 * ds);
+        TSET(TA, 3 * (i + 1) + 1, state_size + ci, 0 * ds);
+        TSET(TA, 3 * (i + 1) + 2, state_size + ci, 1 * ds);
+        /* c_list[i] = ds*(c - a*ref_state - b*ref_kp) = ds*(0,-k,0); bounds = -c_list (:148-151) */
+        const double c1 = ds * (0.0 - k);
+        l[3 * (i + 1) + 0] = u[3 * (i + 1) + 0] = 0.0;
+        l[3 * (i + 1) + 1] = u[3 * (i + 1) + 1] = -c1;
+        l[3 * (i + 1) + 2] = u[3 * (i + 1) + 2] = 0.0;
+    }
+    double elo, ehi;
+    end_heading_window(p, goal_z, ref_z_last, &elo, &ehi);
+    if (form == PO_KP) {
+        const int vars = 3 * N;
+        const int coll = vars + 2 * N + C;
+        const int endb = coll + 6 * N;
+        for (int i = 0; i < N; ++i) { /* :100-104 */
+            TSET(TA, vars + i, 3 * i + 2, 1.0);
+            TSET(TA, vars + N + C + i, state_size + control_size + i, 1.0);
+        }
+        for (int i = 0; i < C; ++i) TSET(TA, vars + N + i, state_size + i, 1.0); /* :105-107 */
+        for (int i = 0; i < N; ++i) { /* :109-134 */
+            TSET(TA, coll + 2 * i, 3 * i, 1.0);
+            TSET(TA, coll + 2 * i, 3 * i + 1, p->d[0]);
+            TSET(TA, coll + 2 * i + 1, 3 * i, 1.0);
+            TSET(TA, coll + 2 * i + 1, 3 * i + 1, p->d[2]);
+            TSET(TA, coll + 2 * N + i, 3 * i, 1.0);
+            TSET(TA, coll + 2 * N + i, 3 * i + 1, p->d[3]);
+            TSET(TA, coll + 2 * N + i, state_size + control_size + i, -1.0);
+            TSET(TA, coll + 3 * N + i, 3 * i, 1.0);
+            TSET(TA, coll + 3 * N + i, 3 * i + 1, p->d[3]);
+            TSET(TA, coll + 3 * N + i, state_size + control_size + i, 1.0);
+            TSET(TA, coll + 4 * N + i, 3 * i, 1.0);
+            TSET(TA, coll + 4 * N + i, 3 * i + 1, p->d[1]);
+            TSET(TA, coll + 4 * N + i, state_size + control_size + i, -1.0);
+            TSET(TA, coll + 5 * N + i, 3 * i, 1.0);
+            TSET(TA, coll + 5 * N + i, 3 * i + 1, p->d[1]);
+            TSET(TA, coll + 5 * N + i, state_size + control_size + i, 1.0);
+        }
+        TSET(TA, endb, state_size - 3, 1.0); /* :136-137 */
+        TSET(TA, endb + 1, state_size - 2, 1.0);
+        for (int i = 0; i < N; ++i) { /* :153-159 */
+            l[vars + i] = -kmax;
+            u[vars + i] = kmax;
+            l[vars + N + C + i] = 0;
+            u[vars + N + C + i] = p->margin;
+        }
+        for (int i = 0; i < C; ++i) { /* :160-163 */
+            l[vars + N + i] = -INF;
+            u[vars + N + i] = INF;
+        }
+        for (int i = 0; i < N; ++i) { /* :165-188 */
+            l[coll + 2 * i] = BND(i, 0, 0);
+            u[coll + 2 * i] = BND(i, 0, 1);
+            l[coll + 2 * i + 1] = BND(i, 2, 0);
+            u[coll + 2 * i + 1] = BND(i, 2, 1);
+            u[coll + 2 * N + i] = BND(i, 3, 1) - p->margin;
+            l[coll + 2 * N + i] = -INF;
+            l[coll + 3 * N + i] = BND(i, 3, 0) + p->margin;
+            u[coll + 3 * N + i] = INF;
+            u[coll + 4 * N + i] = BND(i, 1, 1) - p->margin;
+            l[coll + 4 * N + i] = -INF;
+            l[coll + 5 * N + i] = BND(i, 1, 0) + p->margin;
+            u[coll + 5 * N + i] = INF;
+        }
+        l[endb] = -1; /* :191-192 */
+        u[endb] = 1;
+        l[endb + 1] = elo;
+        u[endb + 1] = ehi;
+    } else { /* KPC, solver_kp_as_input_constrained.cpp:68-221 */
+        if (!max_k || !max_kp) return PO_ERR_INVALID;
+        const int kl = 3 * N, ku = kl + N, kpl = ku + N, kpu = kpl + C, sb = kpu + C;
+        const int coll = sb + 2 * N + C, endb = coll + 5 * N;
+        const int s0 = state_size + control_size;
+        for (int i = 0; i < N; ++i) { /* :110-117 */
+            TSET(TA, kl + i, 3 * i + 2, 1.0);
+            TSET(TA, kl + i, s0 + N + i, 1.0);
+            TSET(TA, ku + i, 3 * i + 2, 1.0);
+            TSET(TA, ku + i, s0 + N + i, -1.0);
+            TSET(TA, sb + i, s0 + i, 1.0);
+            TSET(TA, sb + N + i, s0 + N + i, 1.0);
+        }
+        for (int i = 0; i < C; ++i) { /* :119-125 */
+            TSET(TA, kpl + i, state_size + i, 1.0);
+            TSET(TA, kpl + i, s0 + 2 * N + i, 1.0);
+            TSET(TA, kpu + i, state_size + i, 1.0);
+            TSET(TA, kpu + i, s0 + 2 * N + i, -1.0);
+            TSET(TA, sb + 2 * N + i, s0 + 2 * N + i, 1.0);
+        }
+        for (int i = 0; i < N; ++i) { /* :128-143 */
+            TSET(TA, coll + 3 * i, 3 * i, 1.0);
+            TSET(TA, coll + 3 * i, 3 * i + 1, p->d[0]);
+            TSET(TA, coll + 3 * i + 1, 3 * i, 1.0);
+            TSET(TA, coll + 3 * i + 1, 3 * i + 1, p->d[1]);
+            TSET(TA, coll + 3 * i + 2, 3 * i, 1.0);
+            TSET(TA, coll + 3 * i + 2, 3 * i + 1, p->d[3]);
+            TSET(TA, coll + 3 * N + i, 3 * i, 1.0);
+            TSET(TA, coll + 3 * N + i, 3 * i + 1, p->d[2]);
+            TSET(TA, coll + 3 * N + i, s0 + i, -1.0);
+            TSET(TA, coll + 4 * N + i, 3 * i, 1.0);
+            TSET(TA, coll + 4 * N + i, 3 * i + 1, p->d[2]);
+            TSET(TA, coll + 4 * N + i, s0 + i, 1.0);
+        }
+        TSET(TA, endb, state_size - 3, 1.0);
+        TSET(TA, endb + 1, state_size - 2, 1.0);
+        for (int i = 0; i < N; ++i) { /* :165-177 */
+            l[kl + i] = -max_k[i];
+            u[kl + i] = INF;
+            l[ku + i] = -INF;
+            u[ku + i] = max_k[i];
+            l[sb + i] = 0;
+            u[sb + i] = p->margin;
+            l[sb + N + i] = 0;
+            double r = kmax - max_k[i];
+            u[sb + N + i] = r > 0.0 ? r : 0.0;
+        }
+        for (int i = 0; i < C; ++i) { /* :178-187: max_kp_list is per POINT but indexed by control id */
+            l[kpl + i] = -max_kp[i];
+            u[kpl + i] = INF;
+            l[kpu + i] = -INF;
+            u[kpu + i] = max_kp[i];
+            l[sb + 2 * N + i] = 0;
+            u[sb + 2 * N + i] = INF;
+        }
+        for (int i = 0; i < N; ++i) { /* :190-205 */
+            l[coll + 3 * i] = BND(i, 0, 0);
+            u[coll + 3 * i] = BND(i, 0, 1);
+            l[coll + 3 * i + 1] = BND(i, 1, 0);
+            u[coll + 3 * i + 1] = BND(i, 1, 1);
+            l[coll + 3 * i + 2] = BND(i, 3, 0);
+            u[coll + 3 * i + 2] = BND(i, 3, 1);
+            u[coll + 3 * N + i] = BND(i, 2, 1) - p->margin;
+            l[coll + 3 * N + i] = -INF;
+            l[coll + 4 * N + i] = BND(i, 2, 0) + p->margin;
+            u[coll + 4 * N + i] = INF;
+        }
+        l[endb] = -INF; /* :209-210: end e_y is free in KPC */
+        u[endb] = INF;
+        l[endb + 1] = elo;
+        u[endb + 1] = ehi;
+    }
+    return PO_OK;
+}
+
+static int assemble_k(const po_params *p, int N, const double *ref_k, const double *ref_s,
+                      double ref_z_last, const double *bounds, const double *x0, double goal_z,
+                      tripbuf *TP, tripbuf *TA, double *l, double *u) {
+    const int m = 11 * N - 1;
+    const int control_size = N - 1;
+    const double INF = PO_ORACLE_INFTY;
+    const double w_c = p->k_w_curv, w_cr = p->k_w_curv_rate, w_pq = p->k_w_dev, w_e = p->w_slack;
+    /* Hessian, solver_k_as_input.cpp:46-87 */
+    for (int i = 0; i < N; ++i) {
+        TSET(TP, 2 * i, 2 * i, 0.0);
+        TSET(TP, 2 * i + 1, 2 * i + 1, w_pq);
+    }
+    for (int i = 0; i < control_size; ++i) { /* matrix_R :62-76, only the tri-diagonal is ever inserted */
+        if (i == 0 || i == control_size - 1) TSET(TP, 2 * N + i, 2 * N + i, w_c + w_cr);
+        else TSET(TP, 2 * N + i, 2 * N + i, w_cr * 2 + w_c);
+        if (i + 1 < control_size) {
+            TSET(TP, 2 * N + i, 2 * N + i + 1, -w_cr);
+            TSET(TP, 2 * N + i + 1, 2 * N + i, -w_cr);
+        }
+    }
+    for (int i = 0; i < N; ++i) TSET(TP, 3 * N - 1 + i, 3 * N - 1 + i, 1.0 * w_e);
+    /* constraints, :105-150 */
+    for (int i = 0; i < 2 * N; ++i) TSET(TA, i, i, -1.0);
+    for (int i = 0; i < m; ++i) l[i] = u[i] = 0.0;
+    const double L = p->wheel_base;
+    for (int i = 0; i < N - 1; ++i) { /* setDynamicMatrix :89-103 */
+        const double k = ref_k[i];
+        const double rs = ref_s[i + 1] - ref_s[i];
+        const double delta = atan(k * L);
+        TSET(TA, 2 * (i + 1) + 0, 2 * i + 0, 1.0);
+        TSET(TA, 2 * (i + 1) + 0, 2 * i + 1, -rs * pow(k, 2));
+        TSET(TA, 2 * (i + 1) + 1, 2 * i + 0, rs);
+        TSET(TA, 2 * (i + 1) + 1, 2 * i + 1, 1.0);
+        TSET(TA, 2 * (i + 1) + 0, 2 * N + i, rs / L / pow(cos(delta), 2));
+        TSET(TA, 2 * (i + 1) + 1, 2 * N + i, 0.0);
+    }
+    for (int i = 0; i < 4 * N - 1; ++i) TSET(TA, 2 * N + i, i, 1.0);
+    for (int i = 0; i < N; ++i) {
+        TSET(TA, 6 * N - 1 + 3 * i + 0, 2 * i, p->d[0]);
+        TSET(TA, 6 * N - 1 + 3 * i + 0, 2 * i + 1, 1.0);
+        TSET(TA, 6 * N - 1 + 3 * i + 1, 2 * i, p->d[2]);
+        TSET(TA, 6 * N - 1 + 3 * i + 1, 2 * i + 1, 1.0);
+        TSET(TA, 6 * N - 1 + 3 * i + 2, 2 * i, p->d[3]);
+        TSET(TA, 6 * N - 1 + 3 * i + 2, 2 * i + 1, 1.0);
+        TSET(TA, 9 * N - 1 + i, 2 * i, p->d[1]);
+        TSET(TA, 9 * N - 1 + i, 2 * i + 1, 1.0);
+        TSET(TA, 10 * N - 1 + i, 2 * i, p->d[1]);
+        TSET(TA, 10 * N - 1 + i, 2 * i + 1, 1.0);
+        TSET(TA, 9 * N - 1 + i, 3 * N - 1 + i, -1.0);
+        TSET(TA, 10 * N - 1 + i, 3 * N - 1 + i, 1.0);
+    }
+    /* bounds, :152-206 */
+    l[0] = u[0] = -x0[1]; /* x0 << init_error[1], init_error[0] */
+    l[1] = u[1] = -x0[0];
+    for (int i = 0; i < N - 1; ++i) {
+        const double ds = ref_s[i + 1] - ref_s[i];
+        const double steer = atan(ref_k[i] * L);
+        const double c0 = ds * steer / L / pow(cos(steer), 2);
+        l[2 + 2 * i] = u[2 + 2 * i] = c0;
+        l[2 + 2 * i + 1] = u[2 + 2 * i + 1] = 0;
+    }
+    for (int i = 0; i < 2 * N; ++i) {
+        l[2 * N + i] = -INF;
+        u[2 * N + i] = INF;
+    }
+    double elo, ehi;
+    end_heading_window(p, goal_z, ref_z_last, &elo, &ehi);
+    if (elo > -INF) { /* only overwritten when the window applies (:171-177) */
+        l[2 * N + 2 * N - 2] = elo;
+        u[2 * N + 2 * N - 2] = ehi;
+    }
+    for (int i = 0; i < N - 1; ++i) {
+        l[4 * N + i] = -p->max_steer;
+        u[4 * N + i] = p->max_steer;
+    }
+    for (int i = 0; i < N; ++i) {
+        l[5 * N - 1 + i] = 0;
+        u[5 * N - 1 + i] = p->margin;
+    }
+    for (int i = 0; i < N; ++i) {
+        l[6 * N - 1 + 3 * i + 0] = BND(i, 0, 0);
+        u[6 * N - 1 + 3 * i + 0] = BND(i, 0, 1);
+        l[6 * N - 1 + 3 * i + 1] = BND(i, 2, 0);
+        u[6 * N - 1 + 3 * i + 1] = BND(i, 2, 1);
+        l[6 * N - 1 + 3 * i + 2] = BND(i, 3, 0);
+        u[6 * N - 1 + 3 * i + 2] = BND(i, 3, 1);
+        u[10 * N - 1 + i] = INF;
+        l[9 * N - 1 + i] = -INF;
+        u[9 * N - 1 + i] = BND(i, 1, 1) - p->margin;
+        l[10 * N - 1 + i] = BND(i, 1, 0) + p->margin;
+    }
+    return PO_OK;
+}
+
+int po_oracle_assemble(int form, const po_params *p, int N, int keep, const double *ref_k,
+                       const double *ref_s, const double *ref_z_last, const double *bounds,
+                       const double *x0, double goal_z, const double *max_k, const double *max_kp,
+                       int *Pp, int *Pi, double *Px, int *Ap, int *Ai, double *Ax, double *l,
+                       double *u) {
+    int n, m, C;
+    int rc = po_oracle_dims(form, N, keep, &n, &m, &C);
+    if (rc) return rc;
+    if (!p || !ref_k || !ref_s || !ref_z_last || !bounds || !x0) return PO_ERR_INVALID;
+    tripbuf TP = {0, 0, 0}, TA = {0, 0, 0};
+    if (form == PO_K) rc = assemble_k(p, N, ref_k, ref_s, *ref_z_last, bounds, x0, goal_z, &TP, &TA, l, u);
+    else rc = assemble_kp_like(form, p, N, keep, ref_k, ref_s, *ref_z_last, bounds, x0, goal_z, max_k, max_kp, &TP, &TA, l, u);
+    if (rc == PO_OK) {
+        tb_compress(&TP, n, 1, Pp, Pi, Px);
+        tb_compress(&TA, n, 0, Ap, Ai, Ax);
+    }
+    free(TP.t);
+    free(TA.t);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Part 2: OSQP-style ADMM                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+static double vnorm_inf(const double *v, int n) {
+    double r = 0;
+    for (int i = 0; i < n; ++i) {
+        double a = fabs(v[i]);
+        if (a > r) r = a;
+    }
+    return r;
+}
+static double vnorm_inf_scaled(const double *s, const double *v, int n) {
+    double r = 0;
+    for (int i = 0; i < n; ++i) {
+        double a = fabs(s[i] * v[i]);
+        if (a > r) r = a;
+    }
+    return r;
+}
+/* y = A x (CSC) */
+static void csc_mv(int ncol, int nrow, const int *Ap, const int *Ai, const double *Ax, const double *x, double *y) {
+    for (int i = 0; i < nrow; ++i) y[i] = 0;
+    for (int c = 0; c < ncol; ++c) {
+        double xc = x[c];
+        for (int k = Ap[c]; k < Ap[c + 1]; ++k) y[Ai[k]] += Ax[k] * xc;
+    }
+}
+/* y = A' x */
+static void csc_mtv(int ncol, const int *Ap, const int *Ai, const double *Ax, const double *x, double *y) {
+    for (int c = 0; c < ncol; ++c) {
+        double s = 0;
+        for (int k = Ap[c]; k < Ap[c + 1]; ++k) s += Ax[k] * x[Ai[k]];
+        y[c] = s;
+    }
+}
+/* y = P x, P symmetric stored upper */
+static void sym_mv(int n, const int *Pp, const int *Pi, const double *Px, const double *x, double *y) {
+    for (int i = 0; i < n; ++i) y[i] = 0;
+    for (int c = 0; c < n; ++c) {
+        for (int k = Pp[c]; k < Pp[c + 1]; ++k) {
+            int r = Pi[k];
+            y[r] += Px[k] * x[c];
+            if (r != c) y[c] += Px[k] * x[r];
+        }
+    }
+}
+
+static double limit_scaling(double v) {
+    v = v < OSQP_MIN_SCALING ? 1.0 : v;
+    v = v > OSQP_MAX_SCALING ? OSQP_MAX_SCALING : v;
+    return v;
+}
+
+/* --- sparse LDL' of a symmetric (quasi-definite) matrix given as upper-triangular CSC ---
+ * Elimination-tree based up-looking factorisation (the classic algorithm used by LDL/QDLDL). */
+typedef struct {
+    int n;
+    int *parent, *Lp, *Li, *Lnz, *flag, *pattern;
+    double *Lx, *D, *Dinv, *Y;
+} ldl_t;
+
+static void ldl_free(ldl_t *f) {
+    free(f->parent);
+    free(f->Lp);
+    free(f->Li);
+    free(f->Lnz);
+    free(f->flag);
+    free(f->pattern);
+    free(f->Lx);
+    free(f->D);
+    free(f->Dinv);
+    free(f->Y);
+    memset(f, 0, sizeof(*f));
+}
+
+static int ldl_symbolic(ldl_t *f, int n, const int *Kp, const int *Ki) {
+    memset(f, 0, sizeof(*f));
+    f->n = n;
+    f->parent = (int *)malloc(sizeof(int) * (size_t)n);
+    f->Lp = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+    f->Lnz = (int *)malloc(sizeof(int) * (size_t)n);
+    f->flag = (int *)malloc(sizeof(int) * (size_t)n);
+    f->pattern = (int *)malloc(sizeof(int) * (size_t)n);
+    f->D = (double *)malloc(sizeof(double) * (size_t)n);
+    f->Dinv = (double *)malloc(sizeof(double) * (size_t)n);
+    f->Y = (double *)malloc(sizeof(double) * (size_t)n);
+    if (!f->parent || !f->Lp || !f->Lnz || !f->flag || !f->pattern || !f->D || !f->Dinv || !f->Y) return -1;
+    for (int k = 0; k < n; ++k) {
+        f->parent[k] = -1;
+        f->flag[k] = k;
+        f->Lnz[k] = 0;
+        for (int p = Kp[k]; p < Kp[k + 1]; ++p) {
+            int i = Ki[p];
+            if (i > k) return -2; /* not upper triangular */
+            for (; f->flag[i] != k; i = f->parent[i]) {
+                if (f->parent[i] == -1) f->parent[i] = k;
+                f->Lnz[i]++;
+                f->flag[i] = k;
+            }
+        }
+    }
+    f->Lp[0] = 0;
+    for (int k = 0; k < n; ++k) f->Lp[k + 1] = f->Lp[k] + f->Lnz[k];
+    int lnz = f->Lp[n] > 0 ? f->Lp[n] : 1;
+    f->Li = (int *)malloc(sizeof(int) * (size_t)lnz);
+    f->Lx = (double *)malloc(sizeof(double) * (size_t)lnz);
+    if (!f->Li || !f->Lx) return -1;
+    return 0;
+}
+
+static int ldl_numeric(ldl_t *f, const int *Kp, const int *Ki, const double *Kx) {
+    const int n = f->n;
+    for (int k = 0; k < n; ++k) {
+        f->Y[k] = 0;
+        f->Lnz[k] = 0;
+    }
+    for (int k = 0; k < n; ++k) {
+        int top = n;
+        f->flag[k] = k;
+        for (int p = Kp[k]; p < Kp[k + 1]; ++p) {
+            int i = Ki[p];
+            f->Y[i] += Kx[p];
+            int len = 0;
+            for (; f->flag[i] != k; i = f->parent[i]) {
+                f->pattern[len++] = i;
+                f->flag[i] = k;
+            }
+            while (len > 0) f->pattern[--top] = f->pattern[--len];
+        }
+        f->D[k] = f->Y[k];
+        f->Y[k] = 0;
+        for (; top < n; ++top) {
+            int i = f->pattern[top];
+            double yi = f->Y[i];
+            f->Y[i] = 0;
+            int p2 = f->Lp[i] + f->Lnz[i];
+            for (int p = f->Lp[i]; p < p2; ++p) f->Y[f->Li[p]] -= f->Lx[p] * yi;
+            double lki = yi * f->Dinv[i];
+            f->D[k] -= lki * yi;
+            f->Li[p2] = k;
+            f->Lx[p2] = lki;
+            f->Lnz[i]++;
+        }
+        if (f->D[k] == 0.0) return -1;
+        f->Dinv[k] = 1.0 / f->D[k];
+    }
+    return 0;
+}
+
+static void ldl_solve(const ldl_t *f, double *x) {
+    const int n = f->n;
+    for (int j = 0; j < n; ++j) {
+        double xj = x[j];
+        for (int p = f->Lp[j]; p < f->Lp[j + 1]; ++p) x[f->Li[p]] -= f->Lx[p] * xj;
+    }
+    for (int j = 0; j < n; ++j) x[j] *= f->Dinv[j];
+    for (int j = n - 1; j >= 0; --j) {
+        double xj = x[j];
+        for (int p = f->Lp[j]; p < f->Lp[j + 1]; ++p) xj -= f->Lx[p] * x[f->Li[p]];
+        x[j] = xj;
+    }
+}
+
+/* Greedy minimum-degree ordering on the pattern of a symmetric matrix (upper CSC).
+ * Stand-in for OSQP's AMD: only the fill (speed of the CPU baseline) depends on it. */
+static int min_degree_order(int n, const int *Kp, const int *Ki, int *perm) {
+    int **adj = (int **)calloc((size_t)n, sizeof(int *));
+    int *deg = (int *)calloc((size_t)n, sizeof(int));
+    int *cap = (int *)calloc((size_t)n, sizeof(int));
+    int *mark = (int *)malloc(sizeof(int) * (size_t)n);
+    char *done = (char *)calloc((size_t)n, 1);
+    int *tmp = (int *)malloc(sizeof(int) * (size_t)n);
+    if (!adj || !deg || !cap || !mark || !done || !tmp) return -1;
+    for (int c = 0; c < n; ++c)
+        for (int p = Kp[c]; p < Kp[c + 1]; ++p)
+            if (Ki[p] != c) {
+                deg[c]++;
+                deg[Ki[p]]++;
+            }
+    for (int i = 0; i < n; ++i) {
+        cap[i] = deg[i] + 8;
+        adj[i] = (int *)malloc(sizeof(int) * (size_t)cap[i]);
+        deg[i] = 0;
+        mark[i] = -1;
+    }
+    for (int c = 0; c < n; ++c)
+        for (int p = Kp[c]; p < Kp[c + 1]; ++p) {
+            int r = Ki[p];
+            if (r != c) {
+                adj[c][deg[c]++] = r;
+                adj[r][deg[r]++] = c;
+            }
+        }
+    int stamp = 0;
+    for (int step = 0; step < n; ++step) {
+        int best = -1, bd = 1 << 30;
+        for (int i = 0; i < n; ++i)
+            if (!done[i] && deg[i] < bd) {
+                bd = deg[i];
+                best = i;
+            }
+        const int v = best;
+        perm[step] = v;
+        done[v] = 1;
+        const int nv = deg[v];
+        for (int a = 0; a < nv; ++a) {
+            const int x = adj[v][a];
+            /* new adj(x) = (adj(x) U adj(v)) \ {x, v}, deduplicated with a stamp */
+            int cnt = 0;
+            ++stamp;
+            mark[x] = stamp;
+            for (int q = 0; q < deg[x]; ++q) {
+                int w = adj[x][q];
+                if (w != v && !done[w] && mark[w] != stamp) {
+                    mark[w] = stamp;
+                    tmp[cnt++] = w;
+                }
+            }
+            for (int b = 0; b < nv; ++b) {
+                int w = adj[v][b];
+                if (mark[w] != stamp) {
+                    mark[w] = stamp;
+                    tmp[cnt++] = w;
+                }
+            }
+            if (cnt > cap[x]) {
+                cap[x] = cnt + 8;
+                free(adj[x]);
+                adj[x] = (int *)malloc(sizeof(int) * (size_t)cap[x]);
+            }
+            memcpy(adj[x], tmp, sizeof(int) * (size_t)cnt);
+            deg[x] = cnt;
+        }
+    }
+    for (int i = 0; i < n; ++i) free(adj[i]);
+    free(adj);
+    free(deg);
+    free(cap);
+    free(mark);
+    free(done);
+    free(tmp);
+    return 0;
+}
+
+/* Build the upper-triangular CSC pattern+values of K = [[P+sigma I, A'],[A, -diag(1/rho)]] under a
+ * symmetric permutation (perm: new -> old).  rho_pos[j] = position of constraint j's diagonal. */
+typedef struct {
+    int nk, *Kp, *Ki, *rho_pos;
+    double *Kx;
+} kkt_t;
+
+static int kkt_build(kkt_t *K, int n, int m, const int *Pp, const int *Pi, const double *Px,
+                     const int *Ap, const int *Ai, const double *Ax, double sigma,
+                     const double *rho_inv, const int *perm) {
+    const int nk = n + m;
+    int *pinv = (int *)malloc(sizeof(int) * (size_t)nk);
+    tripbuf T = {0, 0, 0};
+    if (!pinv) return -1;
+    for (int i = 0; i < nk; ++i) pinv[perm ? perm[i] : i] = i;
+#define KADD(i, j, v)                                    \
+    do {                                                 \
+        int a_ = pinv[i], b_ = pinv[j];                  \
+        if (a_ <= b_) tb_push(&T, a_, b_, (v), 1);       \
+        else tb_push(&T, b_, a_, (v), 1);                \
+    } while (0)
+    for (int c = 0; c < n; ++c) {
+        int has_diag = 0;
+        for (int k = Pp[c]; k < Pp[c + 1]; ++k) {
+            if (Pi[k] == c) {
+                KADD(c, c, Px[k] + sigma);
+                has_diag = 1;
+            } else {
+                KADD(Pi[k], c, Px[k]);
+            }
+        }
+        if (!has_diag) KADD(c, c, sigma);
+        for (int k = Ap[c]; k < Ap[c + 1]; ++k) KADD(c, n + Ai[k], Ax[k]);
+    }
+    for (int j = 0; j < m; ++j) KADD(n + j, n + j, -rho_inv[j]);
+#undef KADD
+    K->nk = nk;
+    K->Kp = (int *)malloc(sizeof(int) * (size_t)(nk + 1));
+    K->Ki = (int *)malloc(sizeof(int) * (size_t)(T.n + 1));
+    K->Kx = (double *)malloc(sizeof(double) * (size_t)(T.n + 1));
+    K->rho_pos = (int *)malloc(sizeof(int) * (size_t)(m + 1));
+    if (!K->Kp || !K->Ki || !K->Kx || !K->rho_pos) return -1;
+    /* like tb_compress but keeps explicit structure even if a value is 0 (pattern must be stable) */
+    qsort(T.t, (size_t)T.n, sizeof(trip_t), trip_cmp);
+    int nz = 0, k = 0;
+    for (int c = 0; c < nk; ++c) {
+        K->Kp[c] = nz;
+        while (k < T.n && T.t[k].c == c) {
+            int r = T.t[k].r;
+            double v = 0;
+            while (k < T.n && T.t[k].c == c && T.t[k].r == r) v += T.t[k++].v;
+            K->Ki[nz] = r;
+            K->Kx[nz] = v;
+            ++nz;
+        }
+    }
+    K->Kp[nk] = nz;
+    for (int j = 0; j < m; ++j) {
+        int c = pinv[n + j];
+        K->rho_pos[j] = K->Kp[c + 1] - 1; /* diagonal is the last entry of an upper-triangular column */
+    }
+    free(T.t);
+    free(pinv);
+    return 0;
+}
+static void kkt_free(kkt_t *K) {
+    free(K->Kp);
+    free(K->Ki);
+    free(K->Kx);
+    free(K->rho_pos);
+    memset(K, 0, sizeof(*K));
+}
+
+int po_oracle_qp_solve(int n, int m, const int *Pp0, const int *Pi0, const double *Px0,
+                       const double *q0, const int *Ap0, const int *Ai0, const double *Ax0,
+                       const double *l0, const double *u0, const po_params *prm, const int *perm_in,
+                       double *x, double *y, double *z, po_info *info) {
+    if (n <= 0 || m < 0 || !prm || !x || !y || !z || !info) return PO_ERR_INVALID;
+    const int pnz = Pp0[n], anz = Ap0[n];
+    int rc = PO_OK;
+    /* working (scaled) copies */
+    double *Px = (double *)malloc(sizeof(double) * (size_t)(pnz + 1));
+    double *Ax = (double *)malloc(sizeof(double) * (size_t)(anz + 1));
+    double *q = (double *)calloc((size_t)n, sizeof(double));
+    double *l = (double *)malloc(sizeof(double) * (size_t)(m + 1));
+    double *u = (double *)malloc(sizeof(double) * (size_t)(m + 1));
+    double *D = (double *)malloc(sizeof(double) * (size_t)n), *Dinv = (double *)malloc(sizeof(double) * (size_t)n);
+    double *E = (double *)malloc(sizeof(double) * (size_t)(m + 1)), *Einv = (double *)malloc(sizeof(double) * (size_t)(m + 1));
+    double *tn = (double *)malloc(sizeof(double) * (size_t)n), *tn2 = (double *)malloc(sizeof(double) * (size_t)n);
+    double *tm = (double *)malloc(sizeof(double) * (size_t)(m + 1));
+    double *rho_vec = (double *)malloc(sizeof(double) * (size_t)(m + 1));
+    double *rho_inv = (double *)malloc(sizeof(double) * (size_t)(m + 1));
+    int *ctype = (int *)malloc(sizeof(int) * (size_t)(m + 1));
+    double *x_prev = (double *)calloc((size_t)n, sizeof(double));
+    double *z_prev = (double *)calloc((size_t)(m + 1), sizeof(double));
+    double *dx = (double *)calloc((size_t)n, sizeof(double));
+    double *dy = (double *)calloc((size_t)(m + 1), sizeof(double));
+    double *xz = (double *)malloc(sizeof(double) * (size_t)(n + m));
+    double *rhs = (double *)malloc(sizeof(double) * (size_t)(n + m));
+    double *Axv = (double *)calloc((size_t)(m + 1), sizeof(double));
+    double *Pxv = (double *)calloc((size_t)n, sizeof(double));
+    double *Aty = (double *)calloc((size_t)n, sizeof(double));
+    int *perm = (int *)malloc(sizeof(int) * (size_t)(n + m));
+    int *pinv = (int *)malloc(sizeof(int) * (size_t)(n + m));
+    kkt_t K;
+    ldl_t F;
+    memset(&K, 0, sizeof(K));
+    memset(&F, 0, sizeof(F));
+    memcpy(Px, Px0, sizeof(double) * (size_t)pnz);
+    memcpy(Ax, Ax0, sizeof(double) * (size_t)anz);
+    if (q0) memcpy(q, q0, sizeof(double) * (size_t)n);
+    memcpy(l, l0, sizeof(double) * (size_t)m);
+    memcpy(u, u0, sizeof(double) * (size_t)m);
+    double cscale = 1.0;
+    for (int i = 0; i < n; ++i) D[i] = Dinv[i] = 1.0;
+    for (int i = 0; i < m; ++i) E[i] = Einv[i] = 1.0;
+
+    /* ---- Ruiz equilibration (OSQP scale_data); off (0 passes) on the device-matching path ---- */
+    for (int pass = 0; pass < prm->scaling; ++pass) {
+        for (int i = 0; i < n; ++i) tn[i] = 0;
+        for (int i = 0; i < m; ++i) tm[i] = 0;
+        for (int c = 0; c < n; ++c) { /* column inf-norms of [P; A], rows of A */
+            for (int k = Pp0[c]; k < Pp0[c + 1]; ++k) {
+                double a = fabs(Px[k]);
+                int r = Pi0[k];
+                if (a > tn[c]) tn[c] = a;
+                if (a > tn[r]) tn[r] = a;
+            }
+            for (int k = Ap0[c]; k < Ap0[c + 1]; ++k) {
+                double a = fabs(Ax[k]);
+                if (a > tn[c]) tn[c] = a;
+                if (a > tm[Ai0[k]]) tm[Ai0[k]] = a;
+            }
+        }
+        for (int i = 0; i < n; ++i) tn[i] = 1.0 / sqrt(limit_scaling(tn[i]));
+        for (int i = 0; i < m; ++i) tm[i] = 1.0 / sqrt(limit_scaling(tm[i]));
+        for (int c = 0; c < n; ++c) {
+            for (int k = Pp0[c]; k < Pp0[c + 1]; ++k) Px[k] *= tn[c] * tn[Pi0[k]];
+            for (int k = Ap0[c]; k < Ap0[c + 1]; ++k) Ax[k] *= tn[c] * tm[Ai0[k]];
+            q[c] *= tn[c];
+            D[c] *= tn[c];
+        }
+        for (int i = 0; i < m; ++i) E[i] *= tm[i];
+        /* cost scaling */
+        for (int i = 0; i < n; ++i) tn2[i] = 0;
+        for (int c = 0; c < n; ++c)
+            for (int k = Pp0[c]; k < Pp0[c + 1]; ++k) {
+                double a = fabs(Px[k]);
+                int r = Pi0[k];
+                if (a > tn2[c]) tn2[c] = a;
+                if (a > tn2[r]) tn2[r] = a;
+            }
+        double ct = 0;
+        for (int i = 0; i < n; ++i) ct += tn2[i];
+        ct /= n;
+        double qn = limit_scaling(vnorm_inf(q, n));
+        ct = ct > qn ? ct : qn;
+        ct = 1.0 / limit_scaling(ct);
+        for (int k = 0; k < pnz; ++k) Px[k] *= ct;
+        for (int i = 0; i < n; ++i) q[i] *= ct;
+        cscale *= ct;
+    }
+    if (prm->scaling > 0) {
+        for (int i = 0; i < n; ++i) Dinv[i] = 1.0 / D[i];
+        for (int i = 0; i < m; ++i) {
+            Einv[i] = 1.0 / E[i];
+            l[i] *= E[i];
+            u[i] *= E[i];
+        }
+    }
+    const double cinv = 1.0 / cscale;
+
+    /* ---- rho vector (OSQP set_rho_vec) ---- */
+    double rho = prm->rho0;
+    rho = rho < OSQP_RHO_MIN ? OSQP_RHO_MIN : (rho > OSQP_RHO_MAX ? OSQP_RHO_MAX : rho);
+    for (int i = 0; i < m; ++i) {
+        if (l[i] < -PO_ORACLE_INFTY * OSQP_MIN_SCALING && u[i] > PO_ORACLE_INFTY * OSQP_MIN_SCALING) {
+            ctype[i] = -1;
+            rho_vec[i] = OSQP_RHO_MIN;
+        } else if (u[i] - l[i] < OSQP_RHO_TOL) {
+            ctype[i] = 1;
+            rho_vec[i] = OSQP_RHO_EQ_OVER_INEQ * rho;
+        } else {
+            ctype[i] = 0;
+            rho_vec[i] = rho;
+        }
+        rho_inv[i] = 1.0 / rho_vec[i];
+    }
+
+    /* ---- KKT + ordering + factorisation ---- */
+    if (perm_in) {
+        memcpy(perm, perm_in, sizeof(int) * (size_t)(n + m));
+    } else {
+        kkt_t K0;
+        memset(&K0, 0, sizeof(K0));
+        if (kkt_build(&K0, n, m, Pp0, Pi0, Px, Ap0, Ai0, Ax, prm->sigma, rho_inv, NULL)) { rc = PO_ERR_NOMEM; goto done; }
+        if (min_degree_order(K0.nk, K0.Kp, K0.Ki, perm)) { kkt_free(&K0); rc = PO_ERR_NOMEM; goto done; }
+        kkt_free(&K0);
+    }
+    for (int i = 0; i < n + m; ++i) pinv[perm[i]] = i;
+    if (kkt_build(&K, n, m, Pp0, Pi0, Px, Ap0, Ai0, Ax, prm->sigma, rho_inv, perm)) { rc = PO_ERR_NOMEM; goto done; }
+    if (ldl_symbolic(&F, K.nk, K.Kp, K.Ki)) { rc = PO_ERR_NOMEM; goto done; }
+    if (ldl_numeric(&F, K.Kp, K.Ki, K.Kx)) { rc = PO_ERR_INVALID; goto done; }
+
+    /* ---- ADMM (OSQP osqp_solve), cold start ---- */
+    for (int i = 0; i < n; ++i) x[i] = 0;
+    for (int i = 0; i < m; ++i) y[i] = z[i] = 0;
+    memset(info, 0, sizeof(*info));
+    info->status = PO_STATUS_UNSOLVED;
+    const double alpha = prm->alpha, sigma = prm->sigma;
+    int iter = 0, n_refactor = 0, checked_this_iter = 0;
+    double pri_res = 0, dua_res = 0;
+    for (iter = 1; iter <= prm->max_iter; ++iter) {
+        memcpy(x_prev, x, sizeof(double) * (size_t)n);
+        memcpy(z_prev, z, sizeof(double) * (size_t)m);
+        /* update_xz_tilde */
+        for (int i = 0; i < n; ++i) rhs[pinv[i]] = sigma * x_prev[i] - q[i];
+        for (int i = 0; i < m; ++i) rhs[pinv[n + i]] = z_prev[i] - rho_inv[i] * y[i];
+        ldl_solve(&F, rhs);
+        for (int i = 0; i < n; ++i) xz[i] = rhs[pinv[i]];
+        for (int i = 0; i < m; ++i) xz[n + i] = z_prev[i] + rho_inv[i] * (rhs[pinv[n + i]] - y[i]);
+        /* update_x, update_z, update_y */
+        for (int i = 0; i < n; ++i) {
+            x[i] = alpha * xz[i] + (1.0 - alpha) * x_prev[i];
+            dx[i] = x[i] - x_prev[i];
+        }
+        for (int i = 0; i < m; ++i) {
+            double v = alpha * xz[n + i] + (1.0 - alpha) * z_prev[i] + rho_inv[i] * y[i];
+            z[i] = v < l[i] ? l[i] : (v > u[i] ? u[i] : v);
+        }
+        for (int i = 0; i < m; ++i) {
+            dy[i] = rho_vec[i] * (alpha * xz[n + i] + (1.0 - alpha) * z_prev[i] - z[i]);
+            y[i] += dy[i];
+        }
+        checked_this_iter = 0;
+        const int can_check = prm->check_every > 0 && (iter % prm->check_every == 0);
+        const int can_adapt = prm->adapt_every > 0 && (iter % prm->adapt_every == 0);
+        double pri_norm_s = 0, dua_norm_s = 0, pri_res_s = 0, dua_res_s = 0;
+        if (can_check || can_adapt || iter == prm->max_iter) {
+            /* update_info: residuals (unscaled for termination, scaled for the rho estimate) */
+            csc_mv(n, m, Ap0, Ai0, Ax, x, Axv);
+            sym_mv(n, Pp0, Pi0, Px, x, Pxv);
+            csc_mtv(n, Ap0, Ai0, Ax, y, Aty);
+            for (int i = 0; i < m; ++i) tm[i] = Axv[i] - z[i];
+            for (int i = 0; i < n; ++i) tn[i] = Pxv[i] + q[i] + Aty[i];
+            pri_res_s = vnorm_inf(tm, m);
+            dua_res_s = vnorm_inf(tn, n);
+            pri_res = vnorm_inf_scaled(Einv, tm, m);
+            dua_res = cinv * vnorm_inf_scaled(Dinv, tn, n);
+            double nz_s = vnorm_inf(z, m), nAx_s = vnorm_inf(Axv, m);
+            pri_norm_s = nz_s > nAx_s ? nz_s : nAx_s;
+            double nq_s = vnorm_inf(q, n), nAty_s = vnorm_inf(Aty, n), nPx_s = vnorm_inf(Pxv, n);
+            dua_norm_s = nq_s > nAty_s ? nq_s : nAty_s;
+            dua_norm_s = dua_norm_s > nPx_s ? dua_norm_s : nPx_s;
+            checked_this_iter = 1;
+        }
+        if (can_check || iter == prm->max_iter) {
+            double nz = vnorm_inf_scaled(Einv, z, m), nAx = vnorm_inf_scaled(Einv, Axv, m);
+            double eps_prim = prm->eps_abs + prm->eps_rel * (nz > nAx ? nz : nAx);
+            double nq = vnorm_inf_scaled(Dinv, q, n), nAty = vnorm_inf_scaled(Dinv, Aty, n), nPx = vnorm_inf_scaled(Dinv, Pxv, n);
+            double dn = nq > nAty ? nq : nAty;
+            dn = dn > nPx ? dn : nPx;
+            double eps_dual = prm->eps_abs + prm->eps_rel * cinv * dn;
+            int prim_ok = pri_res < eps_prim, dual_ok = dua_res < eps_dual; /* strict, as OSQP */
+            int prim_inf = 0, dual_inf = 0;
+            if (!prim_ok) { /* is_primal_infeasible */
+                for (int i = 0; i < m; ++i) {
+                    double d = dy[i];
+                    if (u[i] > PO_ORACLE_INFTY * OSQP_MIN_SCALING) {
+                        if (l[i] < -PO_ORACLE_INFTY * OSQP_MIN_SCALING) d = 0;
+                        else d = d < 0 ? d : 0;
+                    } else if (l[i] < -PO_ORACLE_INFTY * OSQP_MIN_SCALING) {
+                        d = d > 0 ? d : 0;
+                    }
+                    tm[i] = d;
+                }
+                double ndy = vnorm_inf_scaled(E, tm, m);
+                if (ndy > prm->eps_prim_inf) {
+                    double lhs = 0;
+                    for (int i = 0; i < m; ++i) lhs += u[i] * (tm[i] > 0 ? tm[i] : 0) + l[i] * (tm[i] < 0 ? tm[i] : 0);
+                    if (lhs < -prm->eps_prim_inf * ndy) {
+                        csc_mtv(n, Ap0, Ai0, Ax, tm, tn);
+                        prim_inf = vnorm_inf_scaled(Dinv, tn, n) < prm->eps_prim_inf * ndy;
+                    }
+                }
+            }
+            if (!dual_ok && !prim_inf) { /* is_dual_infeasible */
+                double ndx = vnorm_inf_scaled(D, dx, n);
+                if (ndx > prm->eps_dual_inf) {
+                    double qdx = 0;
+                    for (int i = 0; i < n; ++i) qdx += q[i] * dx[i];
+                    if (qdx < -cscale * prm->eps_dual_inf * ndx) {
+                        sym_mv(n, Pp0, Pi0, Px, dx, tn);
+                        if (vnorm_inf_scaled(Dinv, tn, n) < cscale * prm->eps_dual_inf * ndx) {
+                            csc_mv(n, m, Ap0, Ai0, Ax, dx, tm);
+                            dual_inf = 1;
+                            for (int i = 0; i < m; ++i) {
+                                double a = Einv[i] * tm[i];
+                                if ((u[i] < PO_ORACLE_INFTY * OSQP_MIN_SCALING && a > prm->eps_dual_inf * ndx) ||
+                                    (l[i] > -PO_ORACLE_INFTY * OSQP_MIN_SCALING && a < -prm->eps_dual_inf * ndx)) {
+                                    dual_inf = 0;
+                                    break;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (prim_ok && dual_ok) { info->status = PO_STATUS_SOLVED; break; }
+            if (prim_inf) { info->status = PO_STATUS_PRIMAL_INFEASIBLE; break; }
+            if (dual_inf) { info->status = PO_STATUS_DUAL_INFEASIBLE; break; }
+        }
+        if (can_adapt) { /* compute_rho_estimate + adapt_rho (scaled-space quantities) */
+            double pr = pri_res_s / (pri_norm_s + 1e-10);
+            double dr = dua_res_s / (dua_norm_s + 1e-10);
+            double rho_new = rho * sqrt(pr / (dr + 1e-10));
+            rho_new = rho_new < OSQP_RHO_MIN ? OSQP_RHO_MIN : (rho_new > OSQP_RHO_MAX ? OSQP_RHO_MAX : rho_new);
+            if (rho_new > rho * prm->adapt_tol || rho_new < rho / prm->adapt_tol) {
+                rho = rho_new;
+                for (int i = 0; i < m; ++i) {
+                    if (ctype[i] == 0) rho_vec[i] = rho;
+                    else if (ctype[i] == 1) rho_vec[i] = OSQP_RHO_EQ_OVER_INEQ * rho;
+                    rho_inv[i] = 1.0 / rho_vec[i];
+                    K.Kx[K.rho_pos[i]] = -rho_inv[i];
+                }
+                if (ldl_numeric(&F, K.Kp, K.Ki, K.Kx)) { rc = PO_ERR_INVALID; goto done; }
+                ++n_refactor;
+            }
+        }
+    }
+    if (iter > prm->max_iter) {
+        iter = prm->max_iter;
+        if (info->status == PO_STATUS_UNSOLVED) info->status = PO_STATUS_MAX_ITER;
+    }
+    (void)checked_this_iter;
+    info->iters = iter;
+    info->n_refactor = n_refactor;
+    info->r_prim = pri_res;
+    info->r_dual = dua_res;
+    info->rho = rho;
+    /* unscale solution */
+    for (int i = 0; i < n; ++i) x[i] *= D[i];
+    for (int i = 0; i < m; ++i) {
+        y[i] *= cinv * E[i];
+        z[i] *= Einv[i];
+    }
+    {
+        sym_mv(n, Pp0, Pi0, Px0, x, tn);
+        double o = 0;
+        for (int i = 0; i < n; ++i) o += 0.5 * x[i] * tn[i] + (q0 ? q0[i] * x[i] : 0.0);
+        info->obj = o;
+    }
+done:
+    ldl_free(&F);
+    kkt_free(&K);
+    free(Px); free(Ax); free(q); free(l); free(u); free(D); free(Dinv); free(E); free(Einv);
+    free(tn); free(tn2); free(tm); free(rho_vec); free(rho_inv); free(ctype); free(x_prev);
+    free(z_prev); free(dx); free(dy); free(xz); free(rhs); free(Axv); free(Pxv); free(Aty);
+    free(perm); free(pinv);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Part 3: output map                                                                           */
+/* ------------------------------------------------------------------------------------------ */
+int po_oracle_output(int form, int N, const double *xs, const double *ref_x, const double *ref_y,
+                     const double *ref_z, double *out) {
+    double tmp_s = 0, px = 0, py = 0;
+    for (int i = 0; i < N; ++i) {
+        double ey, ephi, k;
+        if (form == PO_K) { /* solver_k_as_input.cpp:22-44 */
+            ey = xs[2 * i + 1];
+            ephi = xs[2 * i];
+            k = (i != N - 1) ? xs[2 * N + i] : xs[3 * N - 2];
+        } else { /* solver_kp_as_input.cpp:26-43 (KPC identical) */
+            ey = xs[3 * i];
+            ephi = xs[3 * i + 1];
+            k = xs[3 * i + 2];
+        }
+        double angle = ref_z[i];
+        double new_angle = po_oracle_wrap_angle(angle + M_PI_2);
+        double tx = ref_x[i] + ey * cos(new_angle);
+        double ty = ref_y[i] + ey * sin(new_angle);
+        if (i != 0) tmp_s += sqrt(pow(tx - px, 2) + pow(ty - py, 2));
+        out[5 * i + 0] = tx;
+        out[5 * i + 1] = ty;
+        out[5 * i + 2] = angle + ephi;
+        out[5 * i + 3] = k;
+        out[5 * i + 4] = tmp_s;
+        px = tx;
+        py = ty;
+    }
+    return PO_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Part 4: drivers                                                                              */
+/* ------------------------------------------------------------------------------------------ */
+/* ordering cache: the sparsity pattern depends only on (form, N, keep) and on which data-dependent
+ * entries are exactly zero; we key on (form, N, keep, nnzA, nnzP) */
+typedef struct {
+    int form, N, keep, anz, pnz, len, *perm;
+} perm_cache_t;
+static perm_cache_t g_cache[8];
+static int g_cache_next = 0;
+
+int po_oracle_solve_path(int form, const po_params *p, int N, int keep, const double *ref_x,
+                         const double *ref_y, const double *ref_z, const double *ref_k,
+                         const double *ref_s, const double *bounds, const double *x0,
+                         double goal_z, const double *max_k, const double *max_kp,
+                         double *out_states, double *out_x, double *out_y, po_info *info) {
+    int n, m, C;
+    int rc = po_oracle_dims(form, N, keep, &n, &m, &C);
+    if (rc) return rc;
+    const int ab = po_oracle_nnz_bound_A(form, N, keep), pb = po_oracle_nnz_bound_P(form, N, keep);
+    int *Pp = (int *)malloc(sizeof(int) * (size_t)(n + 1)), *Pi = (int *)malloc(sizeof(int) * (size_t)pb);
+    int *Ap = (int *)malloc(sizeof(int) * (size_t)(n + 1)), *Ai = (int *)malloc(sizeof(int) * (size_t)ab);
+    double *Px = (double *)malloc(sizeof(double) * (size_t)pb), *Ax = (double *)malloc(sizeof(double) * (size_t)ab);
+    double *l = (double *)malloc(sizeof(double) * (size_t)m), *u = (double *)malloc(sizeof(double) * (size_t)m);
+    double *x = (double *)malloc(sizeof(double) * (size_t)n), *y = (double *)malloc(sizeof(double) * (size_t)m);
+    double *z = (double *)malloc(sizeof(double) * (size_t)m);
+    po_info li;
+    int ok = 0;
+    rc = po_oracle_assemble(form, p, N, keep, ref_k, ref_s, &ref_z[N - 1], bounds, x0, goal_z, max_k, max_kp, Pp, Pi, Px, Ap, Ai, Ax, l, u);
+    if (rc == PO_OK) {
+        const int *perm = NULL;
+        for (int i = 0; i < 8; ++i)
+            if (g_cache[i].perm && g_cache[i].form == form && g_cache[i].N == N && g_cache[i].keep == keep &&
+                g_cache[i].anz == Ap[n] && g_cache[i].pnz == Pp[n]) perm = g_cache[i].perm;
+        if (!perm) {
+            /* compute a minimum-degree ordering once for this structure */
+            double *ri = (double *)malloc(sizeof(double) * (size_t)m);
+            for (int i = 0; i < m; ++i) ri[i] = 1.0;
+            kkt_t K0;
+            memset(&K0, 0, sizeof(K0));
+            int *pm = (int *)malloc(sizeof(int) * (size_t)(n + m));
+            if (kkt_build(&K0, n, m, Pp, Pi, Px, Ap, Ai, Ax, 1.0, ri, NULL) == 0 && min_degree_order(K0.nk, K0.Kp, K0.Ki, pm) == 0) {
+                perm_cache_t *c = &g_cache[g_cache_next++ % 8];
+                free(c->perm);
+                c->form = form; c->N = N; c->keep = keep; c->anz = Ap[n]; c->pnz = Pp[n]; c->len = n + m; c->perm = pm;
+                perm = pm;
+            } else {
+                free(pm);
+            }
+            kkt_free(&K0);
+            free(ri);
+        }
+        rc = po_oracle_qp_solve(n, m, Pp, Pi, Px, NULL, Ap, Ai, Ax, l, u, p, perm, x, y, z, &li);
+    }
+    if (rc == PO_OK) {
+        ok = li.status == PO_STATUS_SOLVED;
+        if (info) *info = li;
+        if (out_x) memcpy(out_x, x, sizeof(double) * (size_t)n);
+        if (out_y) memcpy(out_y, y, sizeof(double) * (size_t)m);
+        if (out_states) po_oracle_output(form, N, x, ref_x, ref_y, ref_z, out_states);
+    }
+    free(Pp); free(Pi); free(Ap); free(Ai); free(Px); free(Ax); free(l); free(u); free(x); free(y); free(z);
+    return rc == PO_OK ? ok : rc;
+}
+
+int po_oracle_solve_batch(const po_params *p, const po_batch_in *in, const po_batch_out *out) {
+    if (!p || !in || !out) return PO_ERR_INVALID;
+    int n, m, C;
+    int rc = po_oracle_dims(in->formulation, in->N, in->keep, &n, &m, &C);
+    if (rc) return rc;
+    const int N = in->N;
+    for (int b = 0; b < in->B; ++b) {
+        const size_t o = (size_t)b * (size_t)N;
+        int r = po_oracle_solve_path(in->formulation, p, N, in->keep, in->ref_x + o, in->ref_y + o, in->ref_z + o,
+                                     in->ref_k + o, in->ref_s + o, in->bounds + o * 8, in->x0 + (size_t)b * 3,
+                                     in->goal_z[b], in->max_k ? in->max_k + o : NULL, in->max_kp ? in->max_kp + o : NULL,
+                                     out->states ? out->states + o * 5 : NULL, out->x ? out->x + (size_t)b * (size_t)n : NULL,
+                                     NULL, out->info ? &out->info[b] : NULL);
+        if (r < 0) return r;
+    }
+    return PO_OK;
+}
+
+int po_oracle_kkt_check(int n, int m, const int *Pp, const int *Pi, const double *Px, const double *q,
+                        const int *Ap, const int *Ai, const double *Ax, const double *l, const double *u,
+                        const double *x, const double *y, double *res) {
+    double *t = (double *)malloc(sizeof(double) * (size_t)n), *t2 = (double *)malloc(sizeof(double) * (size_t)n);
+    double *ax = (double *)malloc(sizeof(double) * (size_t)(m + 1));
+    if (!t || !t2 || !ax) return PO_ERR_NOMEM;
+    sym_mv(n, Pp, Pi, Px, x, t);
+    csc_mtv(n, Ap, Ai, Ax, y, t2);
+    double obj = 0, stat = 0;
+    for (int i = 0; i < n; ++i) {
+        obj += 0.5 * x[i] * t[i] + (q ? q[i] * x[i] : 0);
+        double g = t[i] + (q ? q[i] : 0) + t2[i];
+        if (fabs(g) > stat) stat = fabs(g);
+    }
+    csc_mv(n, m, Ap, Ai, Ax, x, ax);
+    double viol = 0, comp = 0;
+    for (int i = 0; i < m; ++i) {
+        double v = 0;
+        if (ax[i] < l[i]) v = l[i] - ax[i];
+        if (ax[i] > u[i]) v = ax[i] - u[i];
+        if (v > viol) viol = v;
+        double c = 0;
+        if (y[i] > 0) c = u[i] >= PO_ORACLE_INFTY * OSQP_MIN_SCALING ? fabs(y[i]) : fabs(y[i]) * fabs(u[i] - ax[i]);
+        else if (y[i] < 0) c = l[i] <= -PO_ORACLE_INFTY * OSQP_MIN_SCALING ? fabs(y[i]) : fabs(y[i]) * fabs(ax[i] - l[i]);
+        if (c > comp) comp = c;
+    }
+    res[0] = stat;
+    res[1] = viol;
+    res[2] = comp;
+    res[3] = obj;
+    free(t); free(t2); free(ax);
+    return PO_OK;
+}

@@ -1,0 +1,86 @@
+/*
+ * po_oracle.h — CPU oracle for the QP hot path.  TEST INFRASTRUCTURE, NOT PRODUCT.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product (libpo_hip.so) never links, loads or calls anything in oracle/.
+ *
+ * PARITY PINNING STATUS
+ *   - assembly (P, A, l, u) and the output map: pinned against the reference's own source files
+ *     compiled from /root/reference via oracle/ref_shim (see oracle/Makefile target `ref`,
+ *     tests/test_oracle_vs_reference.py, tests/golden/ref_assembly_*.npz).
+ *   - the ADMM arithmetic: the reference delegates it to OSQP + OsqpEigen, which are NOT in
+ *     /root/reference (cloned un-pinned from upstream master, scripts/install_deps.sh:102,116) and
+ *     are not installed here.  This file restates the published OSQP algorithm (Stellato et al.,
+ *     "OSQP: an operator splitting solver for quadratic programs", Math. Prog. Comp. 2020; OSQP
+ *     ~0.6 defaults).  => "parity unpinned" for the solver arithmetic: the reference holds no golden
+ *     vectors and no test asserting a numeric output.  Correctness is anchored on solver-independent
+ *     KKT certificates and an interior-point cross-check instead (tests/test_oracle.py).
+ */
+#ifndef PO_ORACLE_H_
+#define PO_ORACLE_H_
+
+#include "../include/po_hip.h" /* shared plain-C types only: po_params, po_info, enums */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PO_ORACLE_INFTY 1e30 /* OsqpEigen::INFTY == OSQP_INFTY */
+
+void po_oracle_default_params(po_params *p);
+int  po_oracle_dims(int form, int N, int keep, int *n, int *m, int *C);
+int  po_oracle_keep(int form, const double *ref_s, int N);
+/* constraintAngle (include/path_optimizer/tools/tools.hpp:24-35) */
+double po_oracle_wrap_angle(double a);
+
+/* Upper bounds on nnz so callers can size CSC buffers. */
+int po_oracle_nnz_bound_A(int form, int N, int keep);
+int po_oracle_nnz_bound_P(int form, int N, int keep);
+
+/* Assemble one path's QP in the REFERENCE variable/row order (App. A of SURVEY.md):
+ * P upper-triangular CSC (exact zeros dropped, like Eigen's sparseView()), A CSC, l, u. */
+int po_oracle_assemble(int form, const po_params *p, int N, int keep,
+                       const double *ref_k, const double *ref_s, const double *ref_z_last,
+                       const double *bounds /*[N][4][2]*/, const double *x0 /*[3]*/, double goal_z,
+                       const double *max_k, const double *max_kp,
+                       int *Pp, int *Pi, double *Px, int *Ap, int *Ai, double *Ax,
+                       double *l, double *u);
+
+/* OSQP-style ADMM on a general QP  min 0.5 x'Px + q'x  s.t. l <= Ax <= u.
+ * perm: optional fill-reducing permutation of the (n+m) KKT nodes (new -> old), or NULL.
+ * x,y,z are outputs (cold start x=z=y=0, as the reference's fresh solver per call). */
+int po_oracle_qp_solve(int n, int m, const int *Pp, const int *Pi, const double *Px, const double *q,
+                       const int *Ap, const int *Ai, const double *Ax, const double *l, const double *u,
+                       const po_params *p, const int *perm, double *x, double *y, double *z,
+                       po_info *info);
+
+/* Stage-interleaved KKT permutation for a formulation (keeps LDL' fill O(n)). perm has n+m entries. */
+int po_oracle_kkt_perm(int form, int N, int keep, int *perm);
+
+/* getOptimizedPath (solver_kp_as_input.cpp:26-43 etc.): out [N][5] = x,y,heading,k,s. */
+int po_oracle_output(int form, int N, const double *xsol, const double *ref_x, const double *ref_y,
+                     const double *ref_z, double *out);
+
+/* OsqpSolver::solve for one path (solver.cpp:46-77): returns 1 (true) iff status == solved. */
+int po_oracle_solve_path(int form, const po_params *p, int N, int keep,
+                         const double *ref_x, const double *ref_y, const double *ref_z,
+                         const double *ref_k, const double *ref_s,
+                         const double *bounds, const double *x0, double goal_z,
+                         const double *max_k, const double *max_kp,
+                         double *out_states /*[N][5]*/, double *out_x /*[n] or NULL*/,
+                         double *out_y /*[m] or NULL*/, po_info *info);
+
+/* Batch driver over po_oracle_solve_path (sequential; used by tests and the CPU baseline). */
+int po_oracle_solve_batch(const po_params *p, const po_batch_in *in, const po_batch_out *out);
+
+/* Solver-independent KKT certificate of (x,y) for the assembled QP:
+ * res[0]=||Px+q+A'y||_inf  res[1]=max bound violation of Ax  res[2]=max complementarity violation
+ * (y_i>0 needs (Ax)_i at u_i, y_i<0 at l_i: |y_i|*dist) res[3]=objective 0.5x'Px+q'x */
+int po_oracle_kkt_check(int n, int m, const int *Pp, const int *Pi, const double *Px, const double *q,
+                        const int *Ap, const int *Ai, const double *Ax, const double *l, const double *u,
+                        const double *x, const double *y, double *res);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

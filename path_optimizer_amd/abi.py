@@ -1,0 +1,44 @@
+"""ctypes mirror of include/po_hip.h (struct layouts and enums only; no behaviour)."""
+import ctypes as C
+
+PO_KP, PO_KPC, PO_K = 0, 1, 2
+PO_OK, PO_ERR_INVALID, PO_ERR_HIP, PO_ERR_UNSUPPORTED, PO_ERR_NOMEM = 0, -1, -2, -3, -4
+PO_STATUS_SOLVED, PO_STATUS_MAX_ITER = 1, -2
+PO_STATUS_PRIMAL_INFEASIBLE, PO_STATUS_DUAL_INFEASIBLE, PO_STATUS_UNSOLVED = -3, -4, -10
+FORM_BY_NAME = {"KP": PO_KP, "KPC": PO_KPC, "K": PO_K}  # OsqpSolver::create strings (solver.cpp:34-38)
+
+_dp = C.POINTER(C.c_double)
+
+
+class PoParams(C.Structure):
+    _fields_ = [
+        ("d", C.c_double * 4),
+        ("w_curv", C.c_double), ("w_curv_rate", C.c_double), ("w_dev", C.c_double), ("w_slack", C.c_double),
+        ("k_w_curv", C.c_double), ("k_w_curv_rate", C.c_double), ("k_w_dev", C.c_double),
+        ("w_k_slack", C.c_double), ("w_kp_slack", C.c_double),
+        ("margin", C.c_double), ("max_steer", C.c_double), ("wheel_base", C.c_double),
+        ("constraint_end_heading", C.c_int), ("scaling", C.c_int),
+        ("eps_abs", C.c_double), ("eps_rel", C.c_double), ("eps_prim_inf", C.c_double), ("eps_dual_inf", C.c_double),
+        ("rho0", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double), ("adapt_tol", C.c_double),
+        ("max_iter", C.c_int), ("check_every", C.c_int), ("adapt_every", C.c_int), ("reserved", C.c_int),
+    ]
+
+
+class PoInfo(C.Structure):
+    _fields_ = [("status", C.c_int), ("iters", C.c_int), ("n_refactor", C.c_int), ("reserved", C.c_int),
+                ("r_prim", C.c_double), ("r_dual", C.c_double), ("rho", C.c_double), ("obj", C.c_double)]
+
+
+class PoBatchIn(C.Structure):
+    _fields_ = [("formulation", C.c_int), ("B", C.c_int), ("N", C.c_int), ("keep", C.c_int),
+                ("ref_x", C.c_void_p), ("ref_y", C.c_void_p), ("ref_z", C.c_void_p), ("ref_k", C.c_void_p),
+                ("ref_s", C.c_void_p), ("bounds", C.c_void_p), ("x0", C.c_void_p), ("goal_z", C.c_void_p),
+                ("max_k", C.c_void_p), ("max_kp", C.c_void_p)]
+
+
+class PoBatchOut(C.Structure):
+    _fields_ = [("states", C.c_void_p), ("info", C.c_void_p), ("x", C.c_void_p)]
+
+
+INFO_DTYPE = [("status", "<i4"), ("iters", "<i4"), ("n_refactor", "<i4"), ("reserved", "<i4"),
+              ("r_prim", "<f8"), ("r_dual", "<f8"), ("rho", "<f8"), ("obj", "<f8")]

@@ -1,0 +1,147 @@
+"""Synthetic planning instances for the BASELINE.json configs.
+
+The reference ships no input fixtures for the QP stage beyond the benchmark's waypoint list
+(/root/reference/src/test/path_optimizer_benchmark.cpp:47-82), which needs grid_map/OpenCV to turn
+into corridor bounds.  These generators produce reference paths + corridor bounds of the same shape
+the solver reads through ReferencePath::{getReferenceStates,getBounds,getMaxKList,getMaxKpList}
+(/root/reference/include/path_optimizer/data_struct/reference_path.hpp:34-37).
+
+RNG: numpy default_rng(SeedSequence([20260924, config_id, path_id])), draws in the order listed in
+SURVEY.md §8d.  Arc length s_i = 0.25*i is exact in binary so keep_control_steps_ == 4
+(the truncation quirk of solver_kp_as_input.cpp:17 is exercised separately in the tests).
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+
+import numpy as np
+
+PO_KP, PO_KPC, PO_K = 0, 1, 2
+SEED0 = 20260924
+DS = 0.25
+# FLAGS_d1..d4 defaults (planning_flags.cpp:8-14,31-37)
+D_OFFSETS = (-3.0 / 8.0 * 4.9 + 1.45, -1.0 / 8.0 * 4.9 + 1.45, 1.0 / 8.0 * 4.9 + 1.45, 3.0 / 8.0 * 4.9 + 1.45)
+
+
+@dataclasses.dataclass
+class Batch:
+    """Host-side SoA batch in the layout of po_batch_in (include/po_hip.h)."""
+
+    formulation: int
+    B: int
+    N: int
+    keep: int
+    ref_x: np.ndarray  # [B,N]
+    ref_y: np.ndarray
+    ref_z: np.ndarray
+    ref_k: np.ndarray
+    ref_s: np.ndarray
+    bounds: np.ndarray  # [B,N,4,2] (lb, ub)
+    x0: np.ndarray  # [B,3]
+    goal_z: np.ndarray  # [B]
+    max_k: np.ndarray | None = None  # [B,N]
+    max_kp: np.ndarray | None = None
+
+    def slice(self, lo: int, hi: int) -> "Batch":
+        f = lambda a: None if a is None else np.ascontiguousarray(a[lo:hi])
+        return Batch(self.formulation, hi - lo, self.N, self.keep, f(self.ref_x), f(self.ref_y), f(self.ref_z),
+                     f(self.ref_k), f(self.ref_s), f(self.bounds), f(self.x0), f(self.goal_z), f(self.max_k), f(self.max_kp))
+
+
+CONFIGS = {
+    # id: (formulation, B, N, bounds kind)
+    1: (PO_KP, 1, 80, "fixed"),
+    2: (PO_KP, 1024, 120, "fixed"),
+    3: (PO_KP, 4096, 200, "obstacles"),
+    4: (PO_KP, 32768, 200, "obstacles"),
+    5: (PO_KPC, 4096, 400, "obstacles+limits"),
+}
+
+
+def _one_path(config_id: int, path_id: int, N: int, kind: str, form: int):
+    rng = np.random.default_rng(np.random.SeedSequence([SEED0, config_id, path_id]))
+    a1 = rng.uniform(0.0, 0.06)
+    a2 = rng.uniform(0.0, 0.03)
+    lam1 = rng.uniform(30.0, 80.0)
+    lam2 = rng.uniform(8.0, 20.0)
+    ph1 = rng.uniform(0.0, 2 * math.pi)
+    ph2 = rng.uniform(0.0, 2 * math.pi)
+    z0 = rng.uniform(-math.pi, math.pi)
+    ey0 = rng.uniform(-0.3, 0.3)
+    ephi0 = rng.uniform(-0.05, 0.05)
+    dgoal = rng.uniform(-0.05, 0.05)
+    s = DS * np.arange(N)
+    k = a1 * np.sin(2 * math.pi * s / lam1 + ph1) + a2 * np.sin(2 * math.pi * s / lam2 + ph2)
+    z = z0 + np.concatenate(([0.0], np.cumsum(k[:-1] * DS)))
+    x = np.concatenate(([0.0], np.cumsum(np.cos(z[:-1]) * DS)))
+    y = np.concatenate(([0.0], np.cumsum(np.sin(z[:-1]) * DS)))
+    bounds = np.empty((N, 4, 2))
+    if kind == "fixed":
+        bounds[:, :, 0] = -2.0
+        bounds[:, :, 1] = 2.0
+    else:
+        w = rng.uniform(1.8, 2.5)
+        nobs = int(rng.integers(1, 4))
+        left = np.full(N, w)
+        right = np.full(N, w)
+        idx = np.arange(N)
+        for _ in range(nobs):
+            side = int(rng.integers(0, 2))
+            c = int(rng.integers(20, N - 20 + 1))
+            hl = int(rng.integers(5, 21))
+            g = rng.uniform(0.4, w - 0.5)
+            t = np.where(np.abs(idx - c) <= hl, 0.5 * (1.0 + np.cos(math.pi * (idx - c) / hl)), 0.0)
+            if side == 0:
+                left = left - g * t
+            else:
+                right = right - g * t
+        left = np.maximum(left, 0.5)
+        right = np.maximum(right, 0.5)
+        for j, d in enumerate(D_OFFSETS):
+            sh = np.clip(idx + int(round(d / DS)), 0, N - 1)
+            bounds[:, j, 1] = left[sh]
+            bounds[:, j, 0] = -right[sh]
+    max_k = max_kp = None
+    if form == PO_KPC:
+        lamv = rng.uniform(40.0, 120.0)
+        phv = rng.uniform(0.0, 2 * math.pi)
+        v = 9.0 + 6.0 * np.sin(2 * math.pi * s / lamv + phv)
+        # ReferencePathImpl::updateLimits, directly-given reference (reference_path_impl.cpp:223-233), a = 0
+        ay = math.sqrt((0.4 * 9.8) ** 2 - 0.0)
+        max_k = ay / v ** 2
+        max_kp = 0.1 / v
+    x0 = np.array([ey0, ephi0, k[0]])
+    return x, y, z, k, s, bounds, x0, z[-1] + dgoal, max_k, max_kp
+
+
+def make_batch(config_id: int, B: int | None = None, first_path: int = 0, N: int | None = None,
+               formulation: int | None = None) -> Batch:
+    """Batch of `B` paths of BASELINE config `config_id`, path ids first_path..first_path+B-1."""
+    form, B0, N0, kind = CONFIGS[config_id]
+    if formulation is not None:
+        form = formulation
+    B = B0 if B is None else B
+    N = N0 if N is None else N
+    kind_eff = kind
+    if form == PO_KPC and "limits" not in kind_eff:
+        kind_eff = kind_eff + "+limits"
+    rx = np.empty((B, N)); ry = np.empty((B, N)); rz = np.empty((B, N)); rk = np.empty((B, N)); rs = np.empty((B, N))
+    bd = np.empty((B, N, 4, 2)); x0 = np.empty((B, 3)); gz = np.empty(B)
+    mk = np.empty((B, N)) if form == PO_KPC else None
+    mkp = np.empty((B, N)) if form == PO_KPC else None
+    for b in range(B):
+        x, y, z, k, s, bnd, xi, g, a, c = _one_path(config_id, first_path + b, N, "fixed" if kind == "fixed" else "obstacles", form)
+        rx[b], ry[b], rz[b], rk[b], rs[b], bd[b], x0[b], gz[b] = x, y, z, k, s, bnd, xi, g
+        if form == PO_KPC:
+            mk[b], mkp[b] = a, c
+    keep = 1 if form == PO_K else 4
+    return Batch(form, B, N, keep, rx, ry, rz, rk, rs, bd, x0, gz, mk, mkp)
+
+
+def replicate(batch: Batch, B: int) -> Batch:
+    """Tile a smaller batch up to B paths (used only to size throughput runs quickly)."""
+    reps = -(-B // batch.B)
+    f = lambda a: None if a is None else np.ascontiguousarray(np.concatenate([a] * reps, axis=0)[:B])
+    return Batch(batch.formulation, B, batch.N, batch.keep, f(batch.ref_x), f(batch.ref_y), f(batch.ref_z), f(batch.ref_k),
+                 f(batch.ref_s), f(batch.bounds), f(batch.x0), f(batch.goal_z), f(batch.max_k), f(batch.max_kp))
