@@ -935,6 +935,18 @@ int po_oracle_qp_solve(int n, int m, const int *Pp0, const int *Pi0, const doubl
     }
     const double cinv = 1.0 / cscale;
 
+    /* ---- data validation (OSQP validate_data: l <= u, else osqp_setup fails and the reference's
+     * initSolver() returns false, solver.cpp:72) ---- */
+    for (int i = 0; i < m; ++i)
+        if (l[i] > u[i]) {
+            memset(info, 0, sizeof(*info));
+            info->status = PO_STATUS_PRIMAL_INFEASIBLE;
+            info->rho = prm->rho0;
+            for (int j = 0; j < n; ++j) x[j] = 0;
+            for (int j = 0; j < m; ++j) y[j] = z[j] = 0;
+            goto done;
+        }
+
     /* ---- rho vector (OSQP set_rho_vec) ---- */
     double rho = prm->rho0;
     rho = rho < OSQP_RHO_MIN ? OSQP_RHO_MIN : (rho > OSQP_RHO_MAX ? OSQP_RHO_MAX : rho);

@@ -1,0 +1,237 @@
+"""CPU tests of the oracle itself (no GPU): structure, assembly vs the numpy twin (bit-exact),
+ADMM vs the twin, solver-independent KKT certificates, an interior-point cross-check, edge cases."""
+import math
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import np_twin as T
+from path_optimizer_amd import synth
+
+FORMS = [(T.PO_KP, "KP"), (T.PO_KPC, "KPC"), (T.PO_K, "K")]
+
+
+def _asm(oracle, p, form, N, keep, inst):
+    return oracle.assemble(form, p, N, keep, inst["ref_k"], inst["ref_s"], inst["ref_z"][-1], inst["bounds"], inst["x0"],
+                           inst["goal_z"], inst["max_k"], inst["max_kp"])
+
+
+@pytest.mark.parametrize("N,keep", [(2, 4), (3, 1), (10, 3), (80, 4), (200, 4), (400, 4)])
+def test_dims_closed_forms(oracle, N, keep):
+    # KP n=5N+C m=11N+C+2 ; KPC n=6N+C m=12N+3C+2 (keep==4) ; K n=4N-1 m=11N-1
+    C = (N + keep - 2) // keep
+    assert oracle.dims(T.PO_KP, N, keep) == (5 * N + C, 11 * N + C + 2, C)
+    assert oracle.dims(T.PO_K, N, 1) == (4 * N - 1, 11 * N - 1, N - 1)
+    if keep == 4:
+        assert oracle.dims(T.PO_KPC, N, 4) == (6 * N + C, 12 * N + 3 * C + 2, C)
+    with pytest.raises(ValueError):
+        oracle.dims(T.PO_KP, 1, keep)
+    with pytest.raises(ValueError):
+        oracle.dims(7, N, keep)
+
+
+def test_keep_truncation_quirk(oracle):
+    # solver_kp_as_input.cpp:17 truncates 1.2 / max-gap: s_i = 0.3*i gives 0.30000000000000027 -> keep 3
+    assert oracle.keep_steps(T.PO_KP, 0.25 * np.arange(30)) == 4
+    assert oracle.keep_steps(T.PO_KP, 0.3 * np.arange(30)) == 3
+    assert int(1.2 / 0.3) == 4  # the "obvious" value, which the reference does NOT produce
+    assert oracle.keep_steps(T.PO_KP, 2.0 * np.arange(30)) == 1
+    assert oracle.keep_steps(T.PO_KPC, 0.3 * np.arange(30)) == 4
+    # only the first <= 9 gaps are inspected (solver.cpp:22-27)
+    s = 0.25 * np.arange(30)
+    s[15:] += 5.0
+    assert oracle.keep_steps(T.PO_KP, s) == 4
+
+
+def test_wrap_angle(oracle):
+    L = oracle.lib()
+    for a in [0.0, 3.0, -3.0, math.pi, -math.pi, 4.0, -4.0, 10.0, -10.0, 100.0]:
+        assert L.po_oracle_wrap_angle(a) == T.wrap(a)
+    assert L.po_oracle_wrap_angle(math.pi) == math.pi  # boundary inclusive on both sides
+    assert L.po_oracle_wrap_angle(-math.pi) == -math.pi
+
+
+@pytest.mark.parametrize("form,name", FORMS)
+@pytest.mark.parametrize("N,ds", [(2, 0.25), (5, 0.3), (23, 0.25), (64, 0.5), (120, 0.25)])
+def test_assembly_bit_exact_vs_numpy_twin(oracle, params, form, name, N, ds):
+    rng = np.random.default_rng(100 * N + form)
+    inst = T.random_instance(rng, N, ds=ds)
+    keep = oracle.keep_steps(form, inst["ref_s"])
+    P, A, l, u = _asm(oracle, params, form, N, keep, inst)
+    P2, A2, l2, u2 = T.assemble_np(form, params, N, keep, inst["ref_k"], inst["ref_s"], inst["ref_z"][-1], inst["bounds"],
+                                   inst["x0"], inst["goal_z"], inst["max_k"], inst["max_kp"])
+    assert (P != P2).nnz == 0 and P.nnz == P2.nnz
+    assert (A != A2).nnz == 0 and A.nnz == A2.nnz
+    assert np.array_equal(l, l2) and np.array_equal(u, u2)
+
+
+def test_nnz_closed_forms(oracle, params):
+    # nnz(A)=28N+C-5 (KP), 28N+5C-5 (KPC), 23N-6 (K) when no k_ref is exactly 0
+    for N in (80, 200):
+        inst = T.random_instance(np.random.default_rng(N), N)
+        C = (N + 2) // 4
+        P, A, _, _ = _asm(oracle, params, T.PO_KP, N, 4, inst)
+        assert (A.nnz, P.nnz) == (28 * N + C - 5, 3 * N + C)  # w_dev = 0 vanishes like sparseView()
+        P, A, _, _ = _asm(oracle, params, T.PO_KPC, N, 4, inst)
+        assert (A.nnz, P.nnz) == (28 * N + 5 * C - 5, 3 * N + 2 * C)
+        P, A, _, _ = _asm(oracle, params, T.PO_K, N, 1, inst)
+        assert (A.nnz, P.nnz) == (23 * N - 6, 3 * N - 3)
+
+
+def test_sparseview_drops_exact_zeros(oracle, params):
+    inst = T.random_instance(np.random.default_rng(1), 12)
+    inst["ref_k"][3] = 0.0  # -k^2*ds == -0.0 is dropped by sparseView()
+    _, A, _, _ = _asm(oracle, params, T.PO_KP, 12, 4, inst)
+    assert A.nnz == 28 * 12 + 3 - 5 - 1
+
+
+def test_end_heading_window_is_signed(oracle, params):
+    # `end_psi < 70 deg` without fabs (solver_kp_as_input.cpp:197): -120 deg still gets a window, +80 deg does not
+    N = 8
+    inst = T.random_instance(np.random.default_rng(2), N)
+    m = oracle.dims(T.PO_KP, N, 4)[1]
+    for dpsi, windowed in ((math.radians(-120), True), (math.radians(80), False), (math.radians(20), True)):
+        inst["goal_z"] = inst["ref_z"][-1] + dpsi
+        _, _, l, u = _asm(oracle, params, T.PO_KP, N, 4, inst)
+        if windowed:
+            assert abs(l[m - 1] - (T.wrap(dpsi) - math.radians(5))) < 1e-12 and abs(u[m - 1] - l[m - 1] - math.radians(10)) < 1e-12
+        else:
+            assert l[m - 1] == -1e30 and u[m - 1] == 1e30
+    params.constraint_end_heading = 0
+    _, _, l, u = _asm(oracle, params, T.PO_KP, N, 4, inst)
+    assert l[m - 1] == -1e30 and u[m - 1] == 1e30
+    assert (l[m - 2], u[m - 2]) == (-1, 1)  # KP pins end e_y to +-1; KPC leaves it free
+    _, _, l, u = _asm(oracle, params, T.PO_KPC, N, 4, inst)
+    assert l[-2] == -1e30 and u[-2] == 1e30
+
+
+@pytest.mark.parametrize("form,name", FORMS)
+def test_admm_matches_numpy_twin(oracle, params, form, name):
+    N = 40
+    inst = T.random_instance(np.random.default_rng(7 + form), N)
+    keep = oracle.keep_steps(form, inst["ref_s"])
+    P, A, l, u = _asm(oracle, params, form, N, keep, inst)
+    x, y, z, info = oracle.qp_solve(P, A, l, u, params)
+    x2, y2, z2, info2 = T.admm_np(P, A, l, u, params)
+    assert info["status"] == 1 and info2["status"] == 1
+    assert info["iters"] == info2["iters"] and info["n_refactor"] == info2["n_refactor"]
+    assert np.abs(x - x2).max() < 1e-7 and np.abs(y - y2).max() < 1e-5
+    assert abs(info["rho"] - info2["rho"]) < 1e-6 * info["rho"]
+
+
+@pytest.mark.parametrize("form,name", FORMS)
+def test_tight_solution_satisfies_kkt(oracle, params, form, name):
+    N = 60
+    inst = T.random_instance(np.random.default_rng(11 + form), N, narrow=True)
+    keep = oracle.keep_steps(form, inst["ref_s"])
+    P, A, l, u = _asm(oracle, params, form, N, keep, inst)
+    params.eps_abs = params.eps_rel = 1e-9
+    params.max_iter = 20000
+    x, y, z, info = oracle.qp_solve(P, A, l, u, params)
+    assert info["status"] == 1
+    k = oracle.kkt_check(P, A, l, u, x, y)
+    assert k["stationarity"] < 1e-6 and k["primal_violation"] < 1e-7 and k["complementarity"] < 1e-6
+    # Ruiz-scaled run (OSQP default scaling=10) reaches the same optimum
+    params.scaling = 10
+    xs, ys, zs, infos = oracle.qp_solve(P, A, l, u, params)
+    assert infos["status"] == 1
+    assert np.abs(xs - x).max() < 1e-5
+
+
+def test_interior_point_cross_check(oracle, params):
+    """ADMM-independent check on a tiny instance with scipy trust-constr."""
+    from scipy.optimize import Bounds, LinearConstraint, minimize
+
+    N = 6
+    inst = T.random_instance(np.random.default_rng(5), N, narrow=True)
+    inst["x0"] = np.array([0.45, 0.02, inst["ref_k"][0]])
+    P, A, l, u = _asm(oracle, params, T.PO_KP, N, 4, inst)
+    params.eps_abs = params.eps_rel = 1e-9
+    params.max_iter = 50000
+    x, y, z, info = oracle.qp_solve(P, A, l, u, params)
+    assert info["status"] == 1
+    Pf = (P + sp.triu(P, 1).T).toarray()
+    Ad = A.toarray()
+    lc = np.where(l < -1e20, -np.inf, l)
+    uc = np.where(u > 1e20, np.inf, u)
+    res = minimize(lambda v: 0.5 * v @ Pf @ v, np.zeros(P.shape[0]), jac=lambda v: Pf @ v, hess=lambda v: Pf,
+                   constraints=[LinearConstraint(Ad, lc, uc)], method="trust-constr",
+                   options=dict(gtol=1e-12, xtol=1e-14, barrier_tol=1e-12, maxiter=3000))
+    assert abs(0.5 * x @ Pf @ x - res.fun) < 1e-6 * max(1.0, abs(res.fun))
+    ey = slice(0, 3 * N, 3)
+    assert np.abs(x[ey] - res.x[ey]).max() < 1e-4
+
+
+def test_unconstrained_lq_closed_form(oracle, params):
+    """N=3 straight reference, wide corridor, zero initial error: optimum is x = 0 (k = k_ref = 0)."""
+    N = 3
+    z = np.zeros(N)
+    inst = dict(ref_x=0.25 * np.arange(N), ref_y=z, ref_z=z, ref_k=z, ref_s=0.25 * np.arange(N),
+                bounds=np.tile(np.array([-5.0, 5.0]), (N, 4, 1)), x0=np.zeros(3), goal_z=0.0, max_k=None, max_kp=None)
+    P, A, l, u = _asm(oracle, params, T.PO_KP, N, 4, inst)
+    x, y, z_, info = oracle.qp_solve(P, A, l, u, params)
+    assert info["status"] == 1 and np.abs(x).max() < 1e-9
+
+
+def test_primal_infeasible_detected(oracle, params):
+    N = 20
+    inst = T.random_instance(np.random.default_rng(3), N)
+    inst["bounds"][10, 0] = [1.0, -1.0]  # lb > ub on a hard row
+    P, A, l, u = _asm(oracle, params, T.PO_KP, N, 4, inst)
+    x, y, z, info = oracle.qp_solve(P, A, l, u, params)
+    assert info["status"] == -3
+    st, infos, xs = oracle.solve_batch(synth.Batch(T.PO_KP, 1, N, 4, *(np.ascontiguousarray(inst[k][None]) for k in
+                                       ("ref_x", "ref_y", "ref_z", "ref_k", "ref_s", "bounds", "x0")), np.array([inst["goal_z"]])), params)
+    assert infos["status"][0] == -3 and infos["iters"][0] == 0  # rejected at setup, like osqp_setup's validate_data
+    # a genuinely infeasible corridor (1.9 m lateral jump in one 0.25 m step): ADMM certificate
+    inst = T.random_instance(np.random.default_rng(3), N)
+    inst["bounds"][10, :, :] = [0.9, 1.0]
+    inst["bounds"][11, :, :] = [-1.0, -0.9]
+    P, A, l, u = _asm(oracle, params, T.PO_KP, N, 4, inst)
+    x, y, z, info = oracle.qp_solve(P, A, l, u, params)
+    assert info["status"] == -3 and info["iters"] > 0
+
+
+def test_output_map(oracle):
+    N = 7
+    rng = np.random.default_rng(9)
+    inst = T.random_instance(rng, N)
+    x = rng.normal(size=5 * N + 2) * 0.1
+    out = oracle.output_map(T.PO_KP, N, x, inst["ref_x"], inst["ref_y"], inst["ref_z"])
+    s = 0.0
+    for i in range(N):
+        th = T.wrap(inst["ref_z"][i] + math.pi / 2)
+        px = inst["ref_x"][i] + x[3 * i] * math.cos(th)
+        py = inst["ref_y"][i] + x[3 * i] * math.sin(th)
+        if i:
+            s += math.sqrt((px - qx) ** 2 + (py - qy) ** 2)
+        assert out[i, 0] == px and out[i, 1] == py and out[i, 2] == inst["ref_z"][i] + x[3 * i + 1]
+        assert out[i, 3] == x[3 * i + 2] and abs(out[i, 4] - s) < 1e-15
+        qx, qy = px, py
+    xk = rng.normal(size=4 * N - 1) * 0.1
+    outk = oracle.output_map(T.PO_K, N, xk, inst["ref_x"], inst["ref_y"], inst["ref_z"])
+    assert outk[N - 1, 3] == xk[3 * N - 2] and outk[2, 3] == xk[2 * N + 2]  # steering reported as curvature; last duplicated
+    assert outk[3, 2] == inst["ref_z"][3] + xk[6]
+
+
+def test_baseline_configs_solve(oracle, params):
+    """A few paths of each BASELINE config converge at eps=1e-4 with KKT residuals at that level.
+
+    Finding recorded in DESIGN.md: with w_dev = 0 the QP is nearly flat in long-wavelength lateral shifts,
+    so OSQP's relative 1e-4 stop leaves e_y 1e-3..1e-1 m away from the exact optimum (the reference's own
+    eps = 1e-3 output is further still).  Distance to the exact optimum is therefore NOT the parity bar;
+    iterate-level agreement with this oracle at identical settings is (tests/test_gpu_parity.py)."""
+    for cfg, B in ((1, 1), (2, 2), (3, 3), (5, 1)):
+        b = synth.make_batch(cfg, B=B)
+        st, info, xs = oracle.solve_batch(b, params)
+        assert (info["status"] == 1).all(), (cfg, info)
+        assert (info["r_prim"] < 1e-3).all() and (info["r_dual"] < 1e-3).all()
+        tight = oracle.default_params()
+        tight.eps_abs = tight.eps_rel = 1e-8
+        tight.max_iter = 50000
+        st2, info2, xs2 = oracle.solve_batch(b, tight)
+        assert (info2["status"] == 1).all()
+        ey = xs[:, 0:3 * b.N:3] - xs2[:, 0:3 * b.N:3]
+        rms = np.sqrt((ey ** 2).mean(axis=1))
+        assert rms.max() < 0.5 and (info2["obj"] <= info["obj"] * (1 + 1e-2) + 1e-6).all(), (cfg, rms)
