@@ -1,0 +1,154 @@
+"""ctypes binding over the C ABI of libpo_hip.so (include/po_hip.h).
+
+Plumbing only: the product is the shared library.  There is NO CPU fallback — importing works without a
+GPU (so the symbol/ABI tests can run), but every compute call goes to the HIP kernels and raises
+PoError if the library or a device is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .abi import (INFO_DTYPE, PO_ERR_HIP, PO_OK, PoBatchIn, PoBatchOut, PoParams)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpo_hip.so")
+_LIB = None
+
+EXPORTS = ["po_default_params", "po_problem_dims", "po_keep_control_steps", "po_create", "po_destroy", "po_set_stream",
+           "po_solve_batch", "po_solve_batch_device", "po_assemble_batch", "po_last_kernel_ms", "po_strerror",
+           "po_last_hip_error", "po_version"]
+
+
+class PoError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise PoError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.po_strerror.restype = C.c_char_p
+        L.po_last_hip_error.restype = C.c_char_p
+        L.po_version.restype = C.c_char_p
+        L.po_create.argtypes = [C.c_int, C.POINTER(PoParams), C.POINTER(C.c_void_p)]
+        L.po_destroy.argtypes = [C.c_void_p]
+        L.po_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.po_solve_batch.argtypes = [C.c_void_p, C.POINTER(PoBatchIn), C.POINTER(PoBatchOut)]
+        L.po_solve_batch_device.argtypes = [C.c_void_p, C.POINTER(PoBatchIn), C.POINTER(PoBatchOut)]
+        L.po_assemble_batch.argtypes = [C.c_void_p, C.POINTER(PoBatchIn), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.po_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc: int):
+    if rc != PO_OK:
+        L = lib()
+        msg = L.po_strerror(rc).decode()
+        if rc == PO_ERR_HIP:
+            msg += ": " + L.po_last_hip_error().decode()
+        raise PoError(f"libpo_hip: {msg} (rc={rc})")
+
+
+def default_params() -> PoParams:
+    p = PoParams()
+    lib().po_default_params(C.byref(p))
+    return p
+
+
+def problem_dims(form: int, N: int, keep: int):
+    n, m, c = C.c_int(), C.c_int(), C.c_int()
+    _check(lib().po_problem_dims(form, N, keep, C.byref(n), C.byref(m), C.byref(c)))
+    return n.value, m.value, c.value
+
+
+def keep_control_steps(form: int, ref_s) -> int:
+    ref_s = np.ascontiguousarray(ref_s, dtype=np.float64)
+    k = lib().po_keep_control_steps(form, ref_s.ctypes.data_as(C.c_void_p), len(ref_s))
+    if k < 0:
+        _check(k)
+    return k
+
+
+def _np(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One handle = one HIP device + one stream (po_create / po_destroy)."""
+
+    def __init__(self, device: int = 0, params: PoParams | None = None):
+        self.params = params or default_params()
+        self._h = C.c_void_p()
+        _check(lib().po_create(device, C.byref(self.params), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().po_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, raw_stream: int | None):
+        _check(lib().po_set_stream(self._h, C.c_void_p(raw_stream or 0)))
+
+    # ---- host-pointer path (H2D + solve + D2H) ----
+    def solve_batch(self, batch, want_x: bool = False):
+        n, m, _ = problem_dims(batch.formulation, batch.N, batch.keep)
+        bi = PoBatchIn(batch.formulation, batch.B, batch.N, batch.keep, _np(batch.ref_x), _np(batch.ref_y), _np(batch.ref_z),
+                       _np(batch.ref_k), _np(batch.ref_s), _np(batch.bounds), _np(batch.x0), _np(batch.goal_z), _np(batch.max_k), _np(batch.max_kp))
+        states = np.zeros((batch.B, batch.N, 5))
+        info = np.zeros(batch.B, dtype=INFO_DTYPE)
+        xs = np.zeros((batch.B, n)) if want_x else None
+        bo = PoBatchOut(_np(states), _np(info), _np(xs))
+        _check(lib().po_solve_batch(self._h, C.byref(bi), C.byref(bo)))
+        return states, info, xs
+
+    def assemble_batch(self, batch):
+        n, m, _ = problem_dims(batch.formulation, batch.N, batch.keep)
+        bi = PoBatchIn(batch.formulation, batch.B, batch.N, batch.keep, _np(batch.ref_x), _np(batch.ref_y), _np(batch.ref_z),
+                       _np(batch.ref_k), _np(batch.ref_s), _np(batch.bounds), _np(batch.x0), _np(batch.goal_z), _np(batch.max_k), _np(batch.max_kp))
+        l = np.zeros((batch.B, m)); u = np.zeros((batch.B, m)); dyn = np.zeros((batch.B, batch.N - 1, 3))
+        _check(lib().po_assemble_batch(self._h, C.byref(bi), _np(l), _np(u), _np(dyn)))
+        return l, u, dyn
+
+    # ---- device-pointer path: tensors are torch CUDA(=HIP) tensors already resident in HBM ----
+    def solve_batch_device(self, dev: "DeviceBatch"):
+        bi = PoBatchIn(dev.formulation, dev.B, dev.N, dev.keep, *(None if t is None else t.data_ptr() for t in
+                       (dev.ref_x, dev.ref_y, dev.ref_z, dev.ref_k, dev.ref_s, dev.bounds, dev.x0, dev.goal_z, dev.max_k, dev.max_kp)))
+        bo = PoBatchOut(dev.out_states.data_ptr(), dev.out_info.data_ptr(), None if dev.out_x is None else dev.out_x.data_ptr())
+        _check(lib().po_solve_batch_device(self._h, C.byref(bi), C.byref(bo)))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        _check(lib().po_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+
+class DeviceBatch:
+    """A synth.Batch uploaded once into HBM as torch tensors (torch is only the allocator here)."""
+
+    def __init__(self, batch, device="cuda:0", want_x=False):
+        import torch
+
+        self.formulation, self.B, self.N, self.keep = batch.formulation, batch.B, batch.N, batch.keep
+        up = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.ref_x, self.ref_y, self.ref_z, self.ref_k, self.ref_s = map(up, (batch.ref_x, batch.ref_y, batch.ref_z, batch.ref_k, batch.ref_s))
+        self.bounds, self.x0, self.goal_z, self.max_k, self.max_kp = map(up, (batch.bounds, batch.x0, batch.goal_z, batch.max_k, batch.max_kp))
+        n, _, _ = problem_dims(batch.formulation, batch.N, batch.keep)
+        self.out_states = torch.zeros((batch.B, batch.N, 5), dtype=torch.float64, device=device)
+        self.out_info = torch.zeros((batch.B, 48), dtype=torch.uint8, device=device)  # sizeof(po_info) == 48
+        self.out_x = torch.zeros((batch.B, n), dtype=torch.float64, device=device) if want_x else None
+
+    def info_numpy(self):
+        return self.out_info.cpu().numpy().view(INFO_DTYPE).reshape(-1)

@@ -1,0 +1,329 @@
+// po_capi.cpp — the C ABI of libpo_hip.so (include/po_hip.h): handle management, host<->device staging,
+// kernel launches.  No torch types, no oracle, no CPU fallback: every entry point that computes runs the HIP
+// kernels or returns an error code.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+
+#include "../../include/po_hip.h"
+#include "po_device.hpp"
+
+extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out);
+extern "C" hipError_t po_launch_assemble(int form, const po::DevBatch *in, const po::DevParams *P, double *l, double *u, double *dyn, hipStream_t st);
+extern "C" size_t po_lds_bytes(int form, int N, int C);
+
+namespace {
+thread_local std::string g_hip_err;
+bool hip_ok(hipError_t e, const char *what) {
+    if (e == hipSuccess) return true;
+    g_hip_err = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+#define HIP_TRY(x)                                   \
+    do {                                             \
+        if (!hip_ok((x), #x)) return PO_ERR_HIP;     \
+    } while (0)
+
+struct DevBuf {  // grow-only device buffer
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return PO_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        if (!hip_ok(hipMalloc(&p, bytes), "hipMalloc")) return PO_ERR_NOMEM;
+        cap = bytes;
+        return PO_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+}  // namespace
+
+struct po_handle_s {
+    int device = 0;
+    po_params params{};
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    DevBuf in_buf, out_buf, asm_buf;
+    std::mutex mu;
+};
+
+extern "C" {
+
+void po_default_params(po_params *p) {
+    if (!p) return;
+    // car geometry and weights: /root/reference/src/config/planning_flags.cpp:8-14,18-43,102-119
+    const double car_length = 4.9, rear_axle_to_center = 1.45;
+    std::memset(p, 0, sizeof(*p));
+    p->d[0] = -3.0 / 8.0 * car_length + rear_axle_to_center;
+    p->d[1] = -1.0 / 8.0 * car_length + rear_axle_to_center;
+    p->d[2] = 1.0 / 8.0 * car_length + rear_axle_to_center;
+    p->d[3] = 3.0 / 8.0 * car_length + rear_axle_to_center;
+    p->w_curv = 10; p->w_curv_rate = 200; p->w_dev = 0; p->w_slack = 3;
+    p->k_w_curv = 50; p->k_w_curv_rate = 200; p->k_w_dev = 0;
+    p->w_k_slack = 500; p->w_kp_slack = 25000;
+    p->margin = 1.3;
+    p->max_steer = 30.0 * M_PI / 180.0;
+    p->wheel_base = 2.85;
+    p->constraint_end_heading = 1;
+    p->scaling = 0;
+    p->eps_abs = 1e-4; p->eps_rel = 1e-4; p->eps_prim_inf = 1e-4; p->eps_dual_inf = 1e-4;
+    p->rho0 = 0.1; p->sigma = 1e-6; p->alpha = 1.6; p->adapt_tol = 5.0;
+    p->max_iter = 4000; p->check_every = 25; p->adapt_every = 100;
+}
+
+int po_problem_dims(int form, int N, int keep, int *n, int *m, int *C) {
+    if (N < 2) return PO_ERR_INVALID;
+    int c, nn, mm;
+    if (form == PO_KP) {  // solver_kp_as_input.cpp:13-24
+        if (keep < 1) return PO_ERR_INVALID;
+        c = (N + keep - 2) / keep; nn = 5 * N + c; mm = 11 * N + c + 2;
+    } else if (form == PO_KPC) {  // solver_kp_as_input_constrained.cpp:13-24
+        if (keep != 4) return PO_ERR_INVALID;
+        c = (N + keep - 2) / keep; nn = 6 * N + c; mm = 12 * N + 3 * c + 2;
+    } else if (form == PO_K) {  // solver_k_as_input.cpp:14-20
+        c = N - 1; nn = 4 * N - 1; mm = 11 * N - 1;
+    } else {
+        return PO_ERR_INVALID;
+    }
+    if (n) *n = nn;
+    if (m) *m = mm;
+    if (C) *C = c;
+    return PO_OK;
+}
+
+int po_keep_control_steps(int form, const double *ref_s, int N) {
+    if (!ref_s || N < 2) return PO_ERR_INVALID;
+    if (form == PO_KPC) return 4;
+    if (form == PO_K) return 1;
+    if (form != PO_KP) return PO_ERR_INVALID;
+    double interval = 0;  // solver.cpp:19,22-27
+    for (int i = 1; i < N && i < 10; ++i) interval = std::fmax(interval, ref_s[i] - ref_s[i - 1]);
+    const double q = 1.2 / interval;  // solver_kp_as_input.cpp:17 (truncating cast)
+    const int k = (q >= 2147483647.0 || q != q) ? 1 : static_cast<int>(q);
+    return k > 1 ? k : 1;
+}
+
+int po_create(int device, const po_params *params, po_handle *out) {
+    if (!params || !out) return PO_ERR_INVALID;
+    if (params->scaling != 0) return PO_ERR_UNSUPPORTED;  // device path runs unscaled ADMM
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return PO_ERR_INVALID;
+    HIP_TRY(hipSetDevice(device));
+    po_handle_s *h = new (std::nothrow) po_handle_s;
+    if (!h) return PO_ERR_NOMEM;
+    h->device = device;
+    h->params = *params;
+    if (!hip_ok(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking), "hipStreamCreate") ||
+        !hip_ok(hipEventCreate(&h->ev0), "hipEventCreate") || !hip_ok(hipEventCreate(&h->ev1), "hipEventCreate")) {
+        delete h;
+        return PO_ERR_HIP;
+    }
+    h->stream = h->own_stream;
+    *out = h;
+    return PO_OK;
+}
+
+int po_destroy(po_handle h) {
+    if (!h) return PO_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    h->in_buf.release(); h->out_buf.release(); h->asm_buf.release();
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return PO_OK;
+}
+
+int po_set_stream(po_handle h, void *hip_stream) {
+    if (!h) return PO_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return PO_OK;
+}
+
+static int make_dev_params(const po_handle_s *h, int form, int keep, po::DevParams *D) {
+    const po_params &p = h->params;
+    D->d1 = p.d[0]; D->d2 = p.d[1]; D->d3 = p.d[2]; D->d4 = p.d[3];
+    if (form == PO_K) {
+        D->w_dev = p.k_w_dev; D->w_c = p.k_w_curv; D->w_cr = p.k_w_curv_rate; D->w_s1 = p.w_slack; D->w_s2 = 0; D->w_u = 0; D->w_su = 0;
+    } else {
+        D->w_dev = p.w_dev; D->w_c = p.w_curv; D->w_cr = p.w_curv_rate; D->w_s1 = p.w_slack;
+        D->w_s2 = (form == PO_KPC) ? p.w_k_slack : 0.0;
+        D->w_u = keep * p.w_curv_rate;
+        D->w_su = (form == PO_KPC) ? p.w_kp_slack * keep : 0.0;
+    }
+    D->margin = p.margin;
+    D->kmax = std::tan(p.max_steer) / p.wheel_base;
+    D->max_steer = p.max_steer;
+    D->wheel_base = p.wheel_base;
+    D->sigma = p.sigma; D->alpha = p.alpha; D->rho0 = p.rho0; D->eps_abs = p.eps_abs; D->eps_rel = p.eps_rel;
+    D->eps_pinf = p.eps_prim_inf; D->adapt_tol = p.adapt_tol;
+    D->max_iter = p.max_iter; D->check_every = p.check_every; D->adapt_every = p.adapt_every;
+    D->end_heading = p.constraint_end_heading;
+    return PO_OK;
+}
+
+static int validate(const po_batch_in *in, int *n, int *m, int *C) {
+    if (!in) return PO_ERR_INVALID;
+    if (in->B < 0) return PO_ERR_INVALID;
+    int rc = po_problem_dims(in->formulation, in->N, in->keep, n, m, C);
+    if (rc) return rc;
+    if (!in->ref_x || !in->ref_y || !in->ref_z || !in->ref_k || !in->ref_s || !in->bounds || !in->x0 || !in->goal_z) return PO_ERR_INVALID;
+    if (in->formulation == PO_KPC && (!in->max_k || !in->max_kp)) return PO_ERR_INVALID;
+    if (po_lds_bytes(in->formulation, in->N, *C) > 160 * 1024) return PO_ERR_UNSUPPORTED;
+    return PO_OK;
+}
+
+static void fill_dev_batch(po::DevBatch *D, const po_batch_in *in, const po_batch_out *out, int n, int m, int C) {
+    D->B = in->B; D->N = in->N; D->keep = in->keep; D->C = C;
+    D->ref_x = in->ref_x; D->ref_y = in->ref_y; D->ref_z = in->ref_z; D->ref_k = in->ref_k; D->ref_s = in->ref_s;
+    D->bounds = in->bounds; D->x0 = in->x0; D->goal_z = in->goal_z; D->max_k = in->max_k; D->max_kp = in->max_kp;
+    D->out_states = out ? out->states : nullptr;
+    D->out_info = out ? out->info : nullptr;
+    D->out_x = out ? out->x : nullptr;
+    D->n = n; D->m = m;
+}
+
+int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out *out) {
+    if (!h || !out || !out->states || !out->info) return PO_ERR_INVALID;
+    int n, m, C;
+    int rc = validate(in, &n, &m, &C);
+    if (rc) return rc;
+    if (in->B == 0) return PO_OK;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    po::DevParams P;
+    make_dev_params(h, in->formulation, in->keep, &P);
+    po::DevBatch D;
+    fill_dev_batch(&D, in, out, n, m, C);
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    HIP_TRY(po_launch_solve(in->formulation, &D, &P, h->stream, nullptr));
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return PO_OK;
+}
+
+int po_solve_batch(po_handle h, const po_batch_in *in, const po_batch_out *out) {
+    if (!h || !out || !out->states || !out->info) return PO_ERR_INVALID;
+    int n, m, C;
+    int rc = validate(in, &n, &m, &C);
+    if (rc) return rc;
+    if (in->B == 0) return PO_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t B = in->B, N = in->N;
+    const bool kpc = in->formulation == PO_KPC;
+    // one staging buffer: 5 ref arrays + bounds(8) + (max_k, max_kp) per point, x0(3) + goal per path
+    const size_t per_pt = 13 + (kpc ? 2 : 0);
+    const size_t in_bytes = sizeof(double) * (B * N * per_pt + B * 4);
+    const size_t out_bytes = sizeof(double) * (B * N * 5 + (out->x ? B * (size_t)n : 0)) + sizeof(po_info) * B;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        if ((rc = h->in_buf.ensure(in_bytes)) || (rc = h->out_buf.ensure(out_bytes))) return rc;
+    }
+    double *d = static_cast<double *>(h->in_buf.p);
+    po_batch_in din = *in;
+    size_t o = 0;
+    auto up = [&](const double *src, size_t cnt, const double **dst) -> int {
+        *dst = d + o;
+        if (!hip_ok(hipMemcpyAsync(d + o, src, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream), "H2D")) return PO_ERR_HIP;
+        o += cnt;
+        return PO_OK;
+    };
+    if ((rc = up(in->ref_x, B * N, &din.ref_x)) || (rc = up(in->ref_y, B * N, &din.ref_y)) || (rc = up(in->ref_z, B * N, &din.ref_z)) ||
+        (rc = up(in->ref_k, B * N, &din.ref_k)) || (rc = up(in->ref_s, B * N, &din.ref_s)) || (rc = up(in->bounds, B * N * 8, &din.bounds)) ||
+        (rc = up(in->x0, B * 3, &din.x0)) || (rc = up(in->goal_z, B, &din.goal_z)))
+        return rc;
+    if (kpc && ((rc = up(in->max_k, B * N, &din.max_k)) || (rc = up(in->max_kp, B * N, &din.max_kp)))) return rc;
+    po_batch_out dout;
+    char *ob = static_cast<char *>(h->out_buf.p);
+    dout.states = reinterpret_cast<double *>(ob);
+    dout.x = out->x ? dout.states + B * N * 5 : nullptr;
+    dout.info = reinterpret_cast<po_info *>(ob + sizeof(double) * (B * N * 5 + (out->x ? B * (size_t)n : 0)));
+    rc = po_solve_batch_device(h, &din, &dout);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out->states, dout.states, sizeof(double) * B * N * 5, hipMemcpyDeviceToHost, h->stream));
+    if (out->x) HIP_TRY(hipMemcpyAsync(out->x, dout.x, sizeof(double) * B * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(out->info, dout.info, sizeof(po_info) * B, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PO_OK;
+}
+
+int po_assemble_batch(po_handle h, const po_batch_in *in, double *l, double *u, double *dyn) {
+    if (!h || !l || !u || !dyn) return PO_ERR_INVALID;
+    int n, m, C;
+    int rc = validate(in, &n, &m, &C);
+    if (rc) return rc;
+    if (in->B == 0) return PO_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t B = in->B, N = in->N;
+    const bool kpc = in->formulation == PO_KPC;
+    const size_t per_pt = 13 + (kpc ? 2 : 0);
+    const size_t in_bytes = sizeof(double) * (B * N * per_pt + B * 4);
+    const size_t a_bytes = sizeof(double) * (2 * B * (size_t)m + B * (N - 1) * 3);
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        if ((rc = h->in_buf.ensure(in_bytes)) || (rc = h->asm_buf.ensure(a_bytes))) return rc;
+    }
+    double *d = static_cast<double *>(h->in_buf.p);
+    po_batch_in din = *in;
+    size_t o = 0;
+    auto up = [&](const double *src, size_t cnt, const double **dst) -> int {
+        *dst = d + o;
+        if (!hip_ok(hipMemcpyAsync(d + o, src, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream), "H2D")) return PO_ERR_HIP;
+        o += cnt;
+        return PO_OK;
+    };
+    if ((rc = up(in->ref_x, B * N, &din.ref_x)) || (rc = up(in->ref_y, B * N, &din.ref_y)) || (rc = up(in->ref_z, B * N, &din.ref_z)) ||
+        (rc = up(in->ref_k, B * N, &din.ref_k)) || (rc = up(in->ref_s, B * N, &din.ref_s)) || (rc = up(in->bounds, B * N * 8, &din.bounds)) ||
+        (rc = up(in->x0, B * 3, &din.x0)) || (rc = up(in->goal_z, B, &din.goal_z)))
+        return rc;
+    if (kpc && ((rc = up(in->max_k, B * N, &din.max_k)) || (rc = up(in->max_kp, B * N, &din.max_kp)))) return rc;
+    double *dl = static_cast<double *>(h->asm_buf.p), *du = dl + B * (size_t)m, *dd = du + B * (size_t)m;
+    HIP_TRY(hipMemsetAsync(dl, 0, a_bytes, h->stream));
+    po::DevParams P;
+    make_dev_params(h, in->formulation, in->keep, &P);
+    po::DevBatch D;
+    fill_dev_batch(&D, &din, nullptr, n, m, C);
+    HIP_TRY(po_launch_assemble(in->formulation, &D, &P, dl, du, dd, h->stream));
+    HIP_TRY(hipMemcpyAsync(l, dl, sizeof(double) * B * (size_t)m, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(u, du, sizeof(double) * B * (size_t)m, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(dyn, dd, sizeof(double) * B * (N - 1) * 3, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PO_OK;
+}
+
+int po_last_kernel_ms(po_handle h, float *ms) {
+    if (!h || !ms || !h->timed) return PO_ERR_INVALID;
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return PO_OK;
+}
+
+const char *po_strerror(int code) {
+    switch (code) {
+        case PO_OK: return "ok";
+        case PO_ERR_INVALID: return "invalid argument";
+        case PO_ERR_HIP: return "HIP runtime error (see po_last_hip_error)";
+        case PO_ERR_UNSUPPORTED: return "unsupported configuration (path too long for the LDS tile, or scaling != 0)";
+        case PO_ERR_NOMEM: return "out of memory";
+        default: return "unknown error";
+    }
+}
+const char *po_last_hip_error(void) { return g_hip_err.c_str(); }
+const char *po_version(void) { return "po_hip 0.1 (gfx950)"; }
+
+}  // extern "C"

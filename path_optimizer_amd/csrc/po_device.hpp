@@ -1,0 +1,239 @@
+// po_device.hpp — device-side model of the three QP formulations for gfx950.
+//
+// The reference assembles P and A into dense scratch matrices
+//   KP  /root/reference/src/solver/solver_kp_as_input.cpp:45-203
+//   KPC /root/reference/src/solver/solver_kp_as_input_constrained.cpp:45-221
+//   K   /root/reference/src/solver/solver_k_as_input.cpp:46-207
+// Here nothing is ever assembled: every constraint row is (re)generated on the fly from the few
+// data-dependent numbers it contains, in a STAGE-INTERLEAVED layout:
+//   node  Z_j = (e_y, e_phi, c)_j   c = curvature k (KP/KPC) or steering delta_j (K)
+//   slacks s1_j, s2_j local to a stage, held controls u_c (+ its slack su_c in KPC) local to a group
+// so that the reduced KKT matrix  M = P + sigma I + A' diag(rho) A  is block tri-diagonal in Z with
+// one scalar u_c attached to `keep` consecutive nodes.  See DESIGN.md §3.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/po_hip.h"
+
+namespace po {
+
+constexpr double kInf = 1e30;        // OsqpEigen::INFTY
+constexpr double kInfThresh = 1e26;  // OSQP_INFTY * MIN_SCALING: "infinite" bound test
+constexpr double kRhoMin = 1e-6, kRhoMax = 1e6, kRhoEqOverIneq = 1e3, kRhoTol = 1e-4;
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kPi2 = 1.57079632679489661923;
+
+enum { F_KP = 0, F_KPC = 1, F_K = 2 };
+enum { M_EY = 1, M_EPHI = 2, M_C = 4, M_S1 = 8, M_S2 = 16 };
+
+struct DevParams {
+    double d1, d2, d3, d4;
+    double w_dev, w_c, w_cr, w_s1, w_s2, w_u, w_su;  // P diagonal per variable class (w_u, w_su already x keep)
+    double margin, kmax, max_steer, wheel_base;
+    double sigma, alpha, rho0, eps_abs, eps_rel, eps_pinf, adapt_tol;
+    int max_iter, check_every, adapt_every, end_heading;
+};
+
+struct DevBatch {
+    int B, N, keep, C;
+    const double *ref_x, *ref_y, *ref_z, *ref_k, *ref_s;
+    const double *bounds, *x0, *goal_z, *max_k, *max_kp;
+    double *out_states;
+    po_info *out_info;
+    double *out_x;
+    int n, m;
+};
+
+template <int F> struct FormTraits;
+template <> struct FormTraits<F_KP> {
+    static constexpr int NLOC = 8, NEND = 2, NDYN = 3, NS = 1, HAS_U = 1, NCTL = 1, HAS_SU = 0;
+};
+template <> struct FormTraits<F_KPC> {
+    static constexpr int NLOC = 9, NEND = 2, NDYN = 3, NS = 2, HAS_U = 1, NCTL = 3, HAS_SU = 1;
+};
+template <> struct FormTraits<F_K> {
+    static constexpr int NLOC = 9, NEND = 0, NDYN = 2, NS = 1, HAS_U = 0, NCTL = 0, HAS_SU = 0;
+};
+
+__device__ __forceinline__ double clipd(double v, double l, double u) { return fmin(fmax(v, l), u); }
+
+// OSQP set_rho_vec: loose rows (both bounds infinite) get RHO_MIN, equalities (u-l < 1e-4) 1e3*rho.
+__device__ __forceinline__ double rho_of(double l, double u, double rho, double rho_eq) {
+    if (l < -kInfThresh && u > kInfThresh) return kRhoMin;
+    return (u - l < kRhoTol) ? rho_eq : rho;
+}
+
+// constraintAngle, /root/reference/include/path_optimizer/tools/tools.hpp:24-35
+__device__ __forceinline__ double wrap_angle(double a) {
+    for (int it = 0; it < 64; ++it) {
+        if (a > kPi) a -= 2 * kPi;
+        else if (a < -kPi) a += 2 * kPi;
+        else break;
+    }
+    return a;
+}
+
+// Per-stage inputs a lane needs to regenerate the rows of stage j.
+struct StageIn {
+    double lb[4], ub[4];  // covering-circle clearances c0..c3
+    double maxk;          // KPC
+    double elo, ehi;      // end-heading window (only meaningful at j == N-1)
+    int j, N, last;
+};
+
+// ---- stage-local rows.  fn.row<MASK>(r, c_ey, c_ephi, c_c, c_s1, c_s2, l, u) -------------------------
+template <int F, class Fn> __device__ __forceinline__ void local_rows(const StageIn &s, const DevParams &P, Fn &fn) {
+    if constexpr (F == F_KP) {
+        // solver_kp_as_input.cpp:100-134 (rows) and :153-188 (bounds)
+        fn.template row<M_C>(0, 0., 0., 1., 0., 0., -P.kmax, P.kmax);
+        fn.template row<M_S1>(1, 0., 0., 0., 1., 0., 0.0, P.margin);
+        fn.template row<M_EY | M_EPHI>(2, 1., P.d1, 0., 0., 0., s.lb[0], s.ub[0]);
+        fn.template row<M_EY | M_EPHI>(3, 1., P.d3, 0., 0., 0., s.lb[2], s.ub[2]);
+        fn.template row<M_EY | M_EPHI | M_S1>(4, 1., P.d4, 0., -1., 0., -kInf, s.ub[3] - P.margin);
+        fn.template row<M_EY | M_EPHI | M_S1>(5, 1., P.d4, 0., 1., 0., s.lb[3] + P.margin, kInf);
+        fn.template row<M_EY | M_EPHI | M_S1>(6, 1., P.d2, 0., -1., 0., -kInf, s.ub[1] - P.margin);
+        fn.template row<M_EY | M_EPHI | M_S1>(7, 1., P.d2, 0., 1., 0., s.lb[1] + P.margin, kInf);
+    } else if constexpr (F == F_KPC) {
+        // solver_kp_as_input_constrained.cpp:110-143 (rows) and :165-205 (bounds)
+        fn.template row<M_C | M_S2>(0, 0., 0., 1., 0., 1., -s.maxk, kInf);
+        fn.template row<M_C | M_S2>(1, 0., 0., 1., 0., -1., -kInf, s.maxk);
+        fn.template row<M_S1>(2, 0., 0., 0., 1., 0., 0.0, P.margin);
+        fn.template row<M_S2>(3, 0., 0., 0., 0., 1., 0.0, fmax(P.kmax - s.maxk, 0.0));
+        fn.template row<M_EY | M_EPHI>(4, 1., P.d1, 0., 0., 0., s.lb[0], s.ub[0]);
+        fn.template row<M_EY | M_EPHI>(5, 1., P.d2, 0., 0., 0., s.lb[1], s.ub[1]);
+        fn.template row<M_EY | M_EPHI>(6, 1., P.d4, 0., 0., 0., s.lb[3], s.ub[3]);
+        fn.template row<M_EY | M_EPHI | M_S1>(7, 1., P.d3, 0., -1., 0., -kInf, s.ub[2] - P.margin);
+        fn.template row<M_EY | M_EPHI | M_S1>(8, 1., P.d3, 0., 1., 0., s.lb[2] + P.margin, kInf);
+    } else {
+        // solver_k_as_input.cpp:123-147 (rows) and :167-206 (bounds); identity rows on every variable
+        const bool win = s.last && (s.elo > -kInf);
+        fn.template row<M_EPHI>(0, 0., 1., 0., 0., 0., win ? s.elo : -kInf, win ? s.ehi : kInf);
+        fn.template row<M_EY>(1, 1., 0., 0., 0., 0., -kInf, kInf);
+        if (!s.last) fn.template row<M_C>(2, 0., 0., 1., 0., 0., -P.max_steer, P.max_steer);
+        fn.template row<M_S1>(3, 0., 0., 0., 1., 0., 0.0, P.margin);
+        fn.template row<M_EY | M_EPHI>(4, 1., P.d1, 0., 0., 0., s.lb[0], s.ub[0]);
+        fn.template row<M_EY | M_EPHI>(5, 1., P.d3, 0., 0., 0., s.lb[2], s.ub[2]);
+        fn.template row<M_EY | M_EPHI>(6, 1., P.d4, 0., 0., 0., s.lb[3], s.ub[3]);
+        fn.template row<M_EY | M_EPHI | M_S1>(7, 1., P.d2, 0., -1., 0., -kInf, s.ub[1] - P.margin);
+        fn.template row<M_EY | M_EPHI | M_S1>(8, 1., P.d2, 0., 1., 0., s.lb[1] + P.margin, kInf);
+    }
+}
+
+// End-state rows of KP (:135-137,191-202) / KPC (:146-147,209-220); K has none (its window is row 0 above).
+template <int F, class Fn> __device__ __forceinline__ void end_rows(const StageIn &s, const DevParams &, Fn &fn) {
+    if constexpr (F == F_KP) {
+        fn.template row<M_EY>(0, 1., 0., 0., 0., 0., -1.0, 1.0);
+        fn.template row<M_EPHI>(1, 0., 1., 0., 0., 0., s.elo, s.ehi);
+    } else if constexpr (F == F_KPC) {
+        fn.template row<M_EY>(0, 1., 0., 0., 0., 0., -kInf, kInf);
+        fn.template row<M_EPHI>(1, 0., 1., 0., 0., 0., s.elo, s.ehi);
+    }
+}
+
+// Reference row index of a stage-local row (for the diagnostic assembly output only).
+template <int F> __device__ __forceinline__ int ref_row_local(int r, int j, int N, int C) {
+    if constexpr (F == F_KP) {
+        const int cb = 5 * N + C;
+        switch (r) {
+            case 0: return 3 * N + j;
+            case 1: return 4 * N + C + j;
+            case 2: return cb + 2 * j;
+            case 3: return cb + 2 * j + 1;
+            default: return cb + (r - 2) * N + j;  // r=4..7 -> cb+2N.. cb+5N
+        }
+    } else if constexpr (F == F_KPC) {
+        const int sb = 5 * N + 2 * C, cb = 7 * N + 3 * C;
+        switch (r) {
+            case 0: return 3 * N + j;
+            case 1: return 4 * N + j;
+            case 2: return sb + j;
+            case 3: return sb + N + j;
+            case 4: case 5: case 6: return cb + 3 * j + (r - 4);
+            case 7: return cb + 3 * N + j;
+            default: return cb + 4 * N + j;
+        }
+    } else {
+        switch (r) {
+            case 0: return 2 * N + 2 * j;
+            case 1: return 2 * N + 2 * j + 1;
+            case 2: return 4 * N + j;
+            case 3: return 5 * N - 1 + j;
+            case 4: case 5: case 6: return 6 * N - 1 + 3 * j + (r - 4);
+            case 7: return 9 * N - 1 + j;
+            default: return 10 * N - 1 + j;
+        }
+    }
+}
+template <int F> __device__ __forceinline__ int ref_row_end(int r, int N, int C) {
+    if constexpr (F == F_KP) return 11 * N + C + r;
+    else if constexpr (F == F_KPC) return 12 * N + 3 * C + r;
+    else return 0;
+}
+template <int F> __device__ __forceinline__ int ref_row_ctl(int r, int c, int N, int C) {
+    if constexpr (F == F_KP) return 4 * N + c;
+    else if constexpr (F == F_KPC) return r == 0 ? 5 * N + c : (r == 1 ? 5 * N + C + c : 5 * N + 2 * C + 2 * N + c);
+    else return 0;
+}
+
+// ---- dynamics rows of transition i (from node i into node i+1) -----------------------------------------
+// row r:  f[r] . Z_i + beta[r] * u_{c(i)} - Z_{i+1}[tau[r]] = b[r]     (equality: l = u = b)
+template <int F> struct Dyn {
+    double f[FormTraits<F>::NDYN][3];
+    double beta[FormTraits<F>::NDYN];
+    double b[FormTraits<F>::NDYN];
+};
+template <int F> __device__ __forceinline__ constexpr int dyn_tau(int r) {
+    if constexpr (F == F_K) return r == 0 ? 1 : 0;  // K: row 0 is the e_phi equation, row 1 the e_y equation
+    else return r;
+}
+template <int F> __device__ __forceinline__ Dyn<F> make_dyn(double k, double ds, const DevParams &P) {
+    Dyn<F> d;
+    if constexpr (F == F_K) {
+        // setDynamicMatrix, solver_k_as_input.cpp:89-103 ; c_i :159-166.  pow(x,2) == x*x (gcc folds it).
+        const double steer = atan(k * P.wheel_base);
+        const double cs = cos(steer);
+        const double c2 = __dmul_rn(cs, cs);
+        d.f[0][0] = __dmul_rn(-ds, __dmul_rn(k, k));  // on e_y
+        d.f[0][1] = 1.0;                             // on e_phi
+        d.f[0][2] = ds / P.wheel_base / c2;          // on delta
+        d.beta[0] = 0;
+        d.b[0] = __dmul_rn(ds, steer) / P.wheel_base / c2;
+        d.f[1][0] = 1.0;
+        d.f[1][1] = ds;
+        d.f[1][2] = 0;
+        d.beta[1] = 0;
+        d.b[1] = 0;
+    } else {
+        // A = a*ds + I, B = b*ds, bound = ds*k_ref   (solver_kp_as_input.cpp:78-98,148-151)
+        d.f[0][0] = 1.0; d.f[0][1] = ds; d.f[0][2] = 0; d.beta[0] = 0; d.b[0] = 0;
+        d.f[1][0] = __dmul_rn(-__dmul_rn(k, k), ds); d.f[1][1] = 1.0; d.f[1][2] = ds; d.beta[1] = 0;
+        d.b[1] = __dmul_rn(ds, k);
+        d.f[2][0] = 0; d.f[2][1] = 0; d.f[2][2] = 1.0; d.beta[2] = ds; d.b[2] = 0;
+    }
+    return d;
+}
+
+// P diagonal of node component `comp` (0 e_y, 1 e_phi, 2 c) at stage j.
+template <int F> __device__ __forceinline__ double p_diag_node(int comp, int j, int N, const DevParams &P) {
+    if (comp == 0) return P.w_dev;
+    if (comp == 1) return 0.0;
+    if constexpr (F == F_K) {
+        if (j >= N - 1) return 0.0;  // delta_{N-1} does not exist: padding variable
+        return (j == 0 || j == N - 2) ? P.w_c + P.w_cr : P.w_cr * 2 + P.w_c;  // matrix_R, :62-76
+    } else {
+        return P.w_c;
+    }
+}
+
+__device__ __forceinline__ int ctl_index(int i, int keep) { return keep == 4 ? (i >> 2) : (i / keep); }
+__device__ __forceinline__ bool last_of_group(int i, int N, int keep) {
+    return (i == N - 2) || (keep == 4 ? (((i + 1) & 3) == 0) : ((i + 1) % keep == 0));
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+
+}  // namespace po

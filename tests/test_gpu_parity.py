@@ -1,0 +1,154 @@
+"""GPU parity tests (run with -m gpu on the MI355X box).  Everything goes through the C ABI
+(libpo_hip.so via path_optimizer_amd.binding); the oracle is only the checker."""
+import numpy as np
+import pytest
+
+import np_twin as T
+from path_optimizer_amd import synth
+
+pytestmark = pytest.mark.gpu
+FORMS = [(T.PO_KP, "KP"), (T.PO_KPC, "KPC"), (T.PO_K, "K")]
+
+
+@pytest.fixture(scope="module")
+def binding():
+    from path_optimizer_amd import binding as b
+
+    b.lib()
+    return b
+
+
+def _rand_batch(form, B, N, ds=0.25, seed=0, narrow=False):
+    rng = np.random.default_rng(seed)
+    insts = [T.random_instance(rng, N, ds=ds, narrow=narrow) for _ in range(B)]
+    st = lambda k: np.ascontiguousarray(np.stack([i[k] for i in insts]))
+    keep = 1 if form == T.PO_K else (4 if form == T.PO_KPC else None)
+    return synth.Batch(form, B, N, keep or 4, st("ref_x"), st("ref_y"), st("ref_z"), st("ref_k"), st("ref_s"), st("bounds"),
+                       st("x0"), np.array([i["goal_z"] for i in insts]), st("max_k") if form == T.PO_KPC else None,
+                       st("max_kp") if form == T.PO_KPC else None)
+
+
+@pytest.mark.parametrize("form,name", FORMS)
+@pytest.mark.parametrize("N", [2, 5, 23, 64, 130])
+def test_device_assembly_matches_oracle(binding, oracle, form, name, N):
+    b = _rand_batch(form, 3, N, seed=N + form)
+    eng = binding.Engine(0)
+    l, u, dyn = eng.assemble_batch(b)
+    p = oracle.default_params()
+    for i in range(b.B):
+        P, A, lo, uo = oracle.assemble(form, p, N, b.keep, b.ref_k[i], b.ref_s[i], b.ref_z[i, -1], b.bounds[i], b.x0[i], b.goal_z[i],
+                                       None if b.max_k is None else b.max_k[i], None if b.max_kp is None else b.max_kp[i])
+        if form == T.PO_K:  # device atan/cos may differ from glibc in the last ulp
+            np.testing.assert_allclose(l[i], lo, rtol=4e-16, atol=0)
+            np.testing.assert_allclose(u[i], uo, rtol=4e-16, atol=0)
+        else:
+            assert np.array_equal(l[i], lo) and np.array_equal(u[i], uo)  # bit-exact
+        Ad = A.toarray()
+        for t in range(N - 1):
+            if form == T.PO_K:
+                ref = [Ad[2 * (t + 1), 2 * t + 1], Ad[2 * (t + 1) + 1, 2 * t], Ad[2 * (t + 1), 2 * N + t]]
+                np.testing.assert_allclose(dyn[i, t], ref, rtol=4e-16)
+            else:
+                ref = [Ad[3 * (t + 1), 3 * t + 1], Ad[3 * (t + 1) + 1, 3 * t], Ad[3 * (t + 1) + 2, 3 * N + t // b.keep]]
+                assert np.array_equal(dyn[i, t], ref)
+
+
+@pytest.mark.parametrize("form,name", FORMS)
+def test_fixed_iteration_iterates_match_oracle(binding, oracle, form, name):
+    """Same ADMM, same number of iterations, no termination test: iterates must agree to round-off."""
+    b = _rand_batch(form, 6, 50, seed=3 + form, narrow=True)
+    for iters, adapt in ((1, 0), (2, 0), (40, 0), (120, 50)):
+        p = binding.default_params()
+        p.max_iter, p.check_every, p.adapt_every = iters, 0, adapt
+        po = oracle.default_params()
+        po.max_iter, po.check_every, po.adapt_every = iters, 0, adapt
+        eng = binding.Engine(0, p)
+        st, info, xs = eng.solve_batch(b, want_x=True)
+        ost, oinfo, oxs = oracle.solve_batch(b, po)
+        assert (info["iters"] == iters).all() and (oinfo["iters"] == iters).all()
+        assert np.array_equal(info["n_refactor"], oinfo["n_refactor"])
+        np.testing.assert_allclose(info["rho"], oinfo["rho"], rtol=1e-8)
+        assert np.abs(xs - oxs).max() < 1e-8, (name, iters, np.abs(xs - oxs).max())
+        np.testing.assert_allclose(info["r_prim"], oinfo["r_prim"], rtol=1e-5, atol=1e-10)
+        np.testing.assert_allclose(info["r_dual"], oinfo["r_dual"], rtol=1e-5, atol=1e-10)
+
+
+@pytest.mark.parametrize("cfg,B", [(1, 1), (2, 24), (3, 24), (5, 6)])
+def test_baseline_configs_match_oracle(binding, oracle, cfg, B):
+    """BASELINE configs at the project's termination (eps 1e-4): same iteration counts, same solution."""
+    b = synth.make_batch(cfg, B=B)
+    eng = binding.Engine(0)
+    st, info, xs = eng.solve_batch(b, want_x=True)
+    ost, oinfo, oxs = oracle.solve_batch(b, oracle.default_params())
+    assert np.array_equal(info["status"], oinfo["status"])
+    same = info["iters"] == oinfo["iters"]
+    assert same.mean() >= 0.9, (info["iters"], oinfo["iters"])  # a residual within round-off of eps may flip one check
+    ey = (xs - oxs)[:, 0:3 * b.N:3]
+    rms = np.sqrt((ey ** 2).mean(axis=1))
+    assert rms[same].max() < 1e-6, rms  # bar: <= 1e-4 m lateral-offset RMS; measured ~1e-9
+    assert np.abs(st - ost)[same].max() < 1e-6
+
+
+def test_keep_quirk_and_ragged_sizes(binding, oracle):
+    """ds = 0.3 -> keep = 3 (truncation quirk); N not a multiple of 64 or of keep."""
+    for N, ds in ((7, 0.3), (65, 0.3), (127, 0.5), (200, 2.0)):
+        b = _rand_batch(T.PO_KP, 2, N, ds=ds, seed=N)
+        b.keep = binding.keep_control_steps(T.PO_KP, b.ref_s[0])
+        assert b.keep == oracle.keep_steps(T.PO_KP, b.ref_s[0])
+        p = binding.default_params(); p.max_iter, p.check_every, p.adapt_every = 60, 0, 0
+        po = oracle.default_params(); po.max_iter, po.check_every, po.adapt_every = 60, 0, 0
+        st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
+        ost, oinfo, oxs = oracle.solve_batch(b, po)
+        assert np.abs(xs - oxs).max() < 1e-8, (N, ds, np.abs(xs - oxs).max())
+
+
+def test_api_errors_and_empty(binding):
+    eng = binding.Engine(0)
+    b = _rand_batch(T.PO_KP, 2, 10)
+    b.B = 0
+    st, info, xs = eng.solve_batch(b)
+    assert st.shape[0] == 0
+    b = _rand_batch(T.PO_KP, 1, 10)
+    b.formulation = 7
+    with pytest.raises(binding.PoError):
+        eng.solve_batch(b)
+    b = _rand_batch(T.PO_KPC, 1, 10)
+    b.keep = 3
+    with pytest.raises(binding.PoError):
+        eng.solve_batch(b)
+    b = _rand_batch(T.PO_KP, 1, 10)
+    b.max_k = None
+    b.formulation = T.PO_KPC
+    with pytest.raises(binding.PoError):
+        eng.solve_batch(b)
+
+
+def test_infeasible_path_is_not_reported_solved(binding):
+    b = _rand_batch(T.PO_KP, 3, 30, seed=5)
+    b.bounds[1, 10, :, :] = [0.9, 1.0]
+    b.bounds[1, 11, :, :] = [-1.0, -0.9]
+    p = binding.default_params(); p.max_iter = 600
+    st, info, xs = binding.Engine(0, p).solve_batch(b)
+    assert info["status"][1] != 1 and info["status"][0] == 1 and info["status"][2] == 1
+
+
+def test_full_size_properties(binding):
+    """BASELINE config 3 at full size (B=4096, N=200) through size-independent properties."""
+    small = synth.make_batch(3, B=256)
+    big = synth.replicate(small, 4096)
+    eng = binding.Engine(0)
+    st, info, xs = eng.solve_batch(big, want_x=True)
+    assert (info["status"] == 1).all()
+    # determinism / independence of batch position: replicas are bit-identical
+    assert np.array_equal(xs[:256], xs[256:512]) and np.array_equal(xs[:256], xs[3840:])
+    # solution satisfies the hard corridor rows and the curvature box within the primal tolerance
+    N = 200
+    p = binding.default_params()
+    ey, ephi, k = xs[:, 0:3 * N:3], xs[:, 1:3 * N:3], xs[:, 2:3 * N:3]
+    for d, c in ((p.d[0], 0), (p.d[2], 2)):
+        val = ey + d * ephi
+        assert (val <= big.bounds[:, :, c, 1] + 2e-3).all() and (val >= big.bounds[:, :, c, 0] - 2e-3).all()
+    assert np.abs(k).max() <= np.tan(p.max_steer) / p.wheel_base + 2e-3
+    # initial state pinned, arc length monotone
+    assert np.abs(ey[:, 0] - big.x0[:, 0]).max() < 2e-3
+    assert (np.diff(st[:, :, 4], axis=1) > 0).all()
