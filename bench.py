@@ -65,7 +65,7 @@ def main():
     batch = synth.make_batch(cfg, B=B, first_path=rank * B)  # weak scaling: fixed work per GPU
     dbatch = binding.DeviceBatch(batch, device=dev)
     eng = binding.Engine(local_rank)
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream shared by torch events and the engine
     eng.set_stream(stream.cuda_stream)
 
     def barrier():

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -13,7 +14,7 @@
 #include "../../include/po_hip.h"
 #include "po_device.hpp"
 
-extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out);
+extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out, int variant);
 extern "C" hipError_t po_launch_assemble(int form, const po::DevBatch *in, const po::DevParams *P, double *l, double *u, double *dyn, hipStream_t st);
 extern "C" size_t po_lds_bytes(int form, int N, int C);
 
@@ -195,6 +196,7 @@ static void fill_dev_batch(po::DevBatch *D, const po_batch_in *in, const po_batc
     D->out_states = out ? out->states : nullptr;
     D->out_info = out ? out->info : nullptr;
     D->out_x = out ? out->x : nullptr;
+    D->dbg_cycles = nullptr;
     D->n = n; D->m = m;
 }
 
@@ -210,10 +212,22 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     make_dev_params(h, in->formulation, in->keep, &P);
     po::DevBatch D;
     fill_dev_batch(&D, in, out, n, m, C);
+    const bool dbg = std::getenv("PO_DEBUG_CYCLES") != nullptr;
+    if (dbg) {
+        if ((rc = h->asm_buf.ensure(sizeof(long long) * 4 * (size_t)in->B))) return rc;
+        D.dbg_cycles = static_cast<long long *>(h->asm_buf.p);
+    }
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    HIP_TRY(po_launch_solve(in->formulation, &D, &P, h->stream, nullptr));
+    const char *ve = std::getenv("PO_KERNEL_VARIANT");  // dev/test knob: 1 = generic LDS kernel, 2 = register-resident kernel
+    HIP_TRY(po_launch_solve(in->formulation, &D, &P, h->stream, nullptr, ve ? std::atoi(ve) : 0));
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
+    if (dbg) {
+        long long c4[4];
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipMemcpy(c4, D.dbg_cycles, sizeof(c4), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[po] path0 cycles: rhs %lld chain %lld update %lld over %lld iterations\n", c4[0], c4[1], c4[2], c4[3]);
+    }
     return PO_OK;
 }
 

@@ -41,6 +41,7 @@ struct DevBatch {
     double *out_states;
     po_info *out_info;
     double *out_x;
+    long long *dbg_cycles;  // optional [B][4] per-phase shader-clock totals (dev tool), or nullptr
     int n, m;
 };
 

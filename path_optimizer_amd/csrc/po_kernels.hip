@@ -887,11 +887,18 @@ template <int F> __global__ __launch_bounds__(64) void solve_kernel(DevBatch in,
     factor<F>(cx, rho);
     int status = PO_STATUS_UNSOLVED, it = 0, nref = 0;
     Resid R = {0, 0, 0, 0, 0, 0};
+    long long tc[5] = {0, 0, 0, 0, 0};
+    const bool prof = in.dbg_cycles != nullptr;
     for (it = 1; it <= P.max_iter; ++it) {
         const bool first = (it == 1);
+        long long t0 = prof ? __builtin_readcyclecounter() : 0;
         rhs_pass<F>(cx, rho, first);
+        long long t1 = prof ? __builtin_readcyclecounter() : 0;
         chain_solve<F>(cx);
+        long long t2 = prof ? __builtin_readcyclecounter() : 0;
         update_pass<F>(cx, first);
+        long long t3 = prof ? __builtin_readcyclecounter() : 0;
+        tc[0] += t1 - t0; tc[1] += t2 - t1; tc[2] += t3 - t2;
         const bool can_check = P.check_every > 0 && (it % P.check_every == 0);
         const bool can_adapt = P.adapt_every > 0 && (it % P.adapt_every == 0);
         if (can_check || can_adapt || it == P.max_iter) {
@@ -916,8 +923,11 @@ template <int F> __global__ __launch_bounds__(64) void solve_kernel(DevBatch in,
         }
     }
     if (it > P.max_iter) { it = P.max_iter; if (status == PO_STATUS_UNSOLVED) status = PO_STATUS_MAX_ITER; }
-    // objective 0.5 x'Px (diagnostic)
     output_pass<F>(cx);
+    if (prof && cx.lane == 0) {
+        long long *d = in.dbg_cycles + (size_t)b * 4;
+        d[0] = tc[0]; d[1] = tc[1]; d[2] = tc[2]; d[3] = it;
+    }
     if (cx.lane == 0) {
         po_info o;
         o.status = status; o.iters = it; o.n_refactor = nref; o.reserved = 0;
@@ -963,31 +973,45 @@ template <int F> __global__ __launch_bounds__(64) void assemble_kernel(DevBatch 
         }
 }
 
+#include "po_fast.inc"
+
 template <int F> size_t lds_bytes(int N, int C) { return sizeof(double) * (size_t)Layout<F>(N, C).total; }
 
 }  // namespace po
 
 // ---- launch wrappers used by the C ABI (po_capi.cpp) ----
-extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out) {
-    using namespace po;
-    size_t lds = form == F_KP ? lds_bytes<F_KP>(in->N, in->C) : (form == F_KPC ? lds_bytes<F_KPC>(in->N, in->C) : lds_bytes<F_K>(in->N, in->C));
+namespace po {
+template <class K> hipError_t launch1(K kern, const DevBatch *in, const DevParams *P, int nt, size_t lds, hipStream_t st) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(in->B), dim3(nt), lds, st, *in, *P);
+    return hipGetLastError();
+}
+template <int F> hipError_t launch_form(const DevBatch *in, const DevParams *P, hipStream_t st, size_t *lds_out, int variant) {
+    const int N = in->N, C = in->C;
+    // variant: 0 = auto, 1 = force generic (v1), 2 = force fast
+    const bool fast_ok = (N <= 512) && (C <= (N <= 256 ? 64 : 128));
+    if (variant != 1 && fast_ok) {
+        const size_t lds = lds_bytes_fast<F>(N, C);
+        if (lds_out) *lds_out = lds;
+        if (lds > 160 * 1024) return hipErrorInvalidValue;
+        if (N <= 128) return launch1(&solve_kernel_fast<F, 2, 64>, in, P, 64, lds, st);
+        if (N <= 256) return launch1(&solve_kernel_fast<F, 4, 64>, in, P, 64, lds, st);
+        return launch1(&solve_kernel_fast<F, 4, 128>, in, P, 128, lds, st);
+    }
+    if (variant == 2) return hipErrorInvalidValue;
+    const size_t lds = lds_bytes<F>(N, C);
     if (lds_out) *lds_out = lds;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    hipError_t e = hipSuccess;
-    if (form == F_KP) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_kernel<F_KP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(solve_kernel<F_KP>, dim3(in->B), dim3(64), lds, st, *in, *P);
-    } else if (form == F_KPC) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_kernel<F_KPC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(solve_kernel<F_KPC>, dim3(in->B), dim3(64), lds, st, *in, *P);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_kernel<F_K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(solve_kernel<F_K>, dim3(in->B), dim3(64), lds, st, *in, *P);
-    }
-    return hipGetLastError();
+    return launch1(&solve_kernel<F>, in, P, 64, lds, st);
+}
+}  // namespace po
+
+extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out, int variant) {
+    using namespace po;
+    if (form == F_KP) return launch_form<F_KP>(in, P, st, lds_out, variant);
+    if (form == F_KPC) return launch_form<F_KPC>(in, P, st, lds_out, variant);
+    return launch_form<F_K>(in, P, st, lds_out, variant);
 }
 
 extern "C" hipError_t po_launch_assemble(int form, const po::DevBatch *in, const po::DevParams *P, double *l, double *u, double *dyn, hipStream_t st) {
@@ -1000,5 +1024,7 @@ extern "C" hipError_t po_launch_assemble(int form, const po::DevBatch *in, const
 
 extern "C" size_t po_lds_bytes(int form, int N, int C) {
     using namespace po;
+    const bool fast_ok = (N <= 512) && (C <= (N <= 256 ? 64 : 128));
+    if (fast_ok) return form == F_KP ? lds_bytes_fast<F_KP>(N, C) : (form == F_KPC ? lds_bytes_fast<F_KPC>(N, C) : lds_bytes_fast<F_K>(N, C));
     return form == F_KP ? lds_bytes<F_KP>(N, C) : (form == F_KPC ? lds_bytes<F_KPC>(N, C) : lds_bytes<F_K>(N, C));
 }
