@@ -129,7 +129,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"BASELINE config {cfg}: KP, B={B} paths/GPU x {world} GPU, N={N} points, "
-                                   "per-path random obstacle clearances, eps_abs=eps_rel=1e-4, adaptive rho every 100 it",
+                                   "per-path random obstacle clearances, OSQP defaults (scaling 10, adaptive rho every 100 it) at eps_abs=eps_rel=1e-4",
                        "batch_per_gpu": B, "points": N, "formulation": "KP", "parallelism": f"batch-split x{world}"},
             "admm": {"iters_mean": iters_sum_all / (world * B), "iters_max": iters_max, "unsolved": int(unsolved_all),
                      "path_iters_per_s": iters_sum_all * args.steps / elapsed},
@@ -143,9 +143,9 @@ def main():
 
             ns = min(args.cpu_sample, B)
             sample = batch.slice(0, ns)
-            oracle_py.solve_batch(sample.slice(0, 2), oracle_py.default_params())  # warm the ordering cache
+            oracle_py.solve_batch(sample.slice(0, 2), oracle_py.device_equivalent_params())  # warm the ordering cache
             c0 = time.perf_counter()
-            _, oinfo, _ = oracle_py.solve_batch(sample, oracle_py.default_params(), want_x=False)
+            _, oinfo, _ = oracle_py.solve_batch(sample, oracle_py.device_equivalent_params(), want_x=False)
             c1 = time.perf_counter()
             out["cpu_baseline"] = {"value": ns / (c1 - c0), "unit": "paths/s", "cores": 1, "kind": "port",
                                    "sample": f"first {ns} paths of the same batch, oracle/libpo_oracle.so (OSQP-style ADMM, "

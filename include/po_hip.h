@@ -65,7 +65,8 @@ typedef struct po_params {
     double max_steer;       /* FLAGS_max_steering_angle        (30 deg)                            */
     double wheel_base;      /* FLAGS_wheel_base                (2.85)                              */
     int    constraint_end_heading; /* FLAGS_constraint_end_heading (true)                          */
-    int    scaling;         /* Ruiz passes. 0 on the device path; oracle supports 10 */
+    int    scaling;         /* equilibration passes: 10 = OSQP default (the reference never changes it);
+                               the engine runs the class-level form of Ruiz; 0 = off  */
     /* ADMM (OSQP names) */
     double eps_abs, eps_rel;            /* 1e-4, 1e-4 (project metric; OSQP default is 1e-3)       */
     double eps_prim_inf, eps_dual_inf;  /* 1e-4, 1e-4                                              */
@@ -140,6 +141,10 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
  * row order: l,u [B][m]; dyn [B][N-1][3] = per-transition data-dependent A entries
  * (KP/KPC: ds, -k^2*ds, ds ; K: -ds*k^2, ds, ds/L/cos^2) ; host pointers. */
 int po_assemble_batch(po_handle h, const po_batch_in *in, double *l, double *u, double *dyn);
+
+/* Test/diagnostic entry: the per-path equilibration block [B][64] the solve kernel consumes
+ * (layout in csrc/po_scale.hpp: W = E^2/c per row class, E, sigma/(c D^2) and c*D per variable class, c). */
+int po_scaling_batch(po_handle h, const po_batch_in *in, double *out);
 
 /* Kernel time (ms) of the last po_solve_batch* on this handle, measured with hipEvents on the
  * handle's stream (valid after the stream has been synchronised). */

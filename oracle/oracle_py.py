@@ -109,6 +109,25 @@ def kkt_check(P, A, l, u, x, y, q=None):
     return dict(stationarity=res[0], primal_violation=res[1], complementarity=res[2], objective=res[3])
 
 
+def class_scaling(form, params, N, keep, ds_nom, passes=10):
+    """Class-level Ruiz factors expanded to the reference ordering: D [n], E [m], c."""
+    n, m, _ = dims(form, N, keep)
+    D = np.ones(n); E = np.ones(m); c = C.c_double(1.0)
+    rc = lib().po_oracle_class_scaling(form, C.byref(params), N, keep, C.c_double(float(ds_nom)), passes, _p(D), _p(E), C.byref(c))
+    if rc:
+        raise ValueError(f"po_oracle_class_scaling rc={rc}")
+    return D, E, c.value
+
+
+def device_equivalent_params(params=None):
+    """Oracle parameters that run the SAME algorithm as the device engine with `params`
+    (device scaling = k class-level passes  <->  oracle scaling = -k)."""
+    p = default_params() if params is None else params
+    q = PoParams.from_buffer_copy(bytes(p))
+    q.scaling = -abs(p.scaling)
+    return q
+
+
 def _batch_structs(batch, want_x):
     n, m, _ = dims(batch.formulation, batch.N, batch.keep)
     bi = PoBatchIn(batch.formulation, batch.B, batch.N, batch.keep, _p(batch.ref_x), _p(batch.ref_y), _p(batch.ref_z),

@@ -57,7 +57,7 @@ void po_oracle_default_params(po_params *p) {
     p->max_steer = 30.0 * M_PI / 180.0;
     p->wheel_base = 2.85;
     p->constraint_end_heading = 1;
-    p->scaling = 0;
+    p->scaling = 10; /* OSQP default; > 0: true Ruiz passes, < 0: class-level form (what the device runs) */
     p->eps_abs = 1e-4;
     p->eps_rel = 1e-4;
     p->eps_prim_inf = 1e-4;
@@ -840,6 +840,16 @@ int po_oracle_qp_solve(int n, int m, const int *Pp0, const int *Pi0, const doubl
                        const double *q0, const int *Ap0, const int *Ai0, const double *Ax0,
                        const double *l0, const double *u0, const po_params *prm, const int *perm_in,
                        double *x, double *y, double *z, po_info *info) {
+    return po_oracle_qp_solve_ext(n, m, Pp0, Pi0, Px0, q0, Ap0, Ai0, Ax0, l0, u0, prm, perm_in, NULL, NULL, 1.0, x, y, z, info);
+}
+
+/* Same, with an externally supplied equilibration (Dext per variable, Eext per row, cost scale cext)
+ * instead of the Ruiz passes when Dext != NULL. */
+int po_oracle_qp_solve_ext(int n, int m, const int *Pp0, const int *Pi0, const double *Px0,
+                           const double *q0, const int *Ap0, const int *Ai0, const double *Ax0,
+                           const double *l0, const double *u0, const po_params *prm, const int *perm_in,
+                           const double *Dext, const double *Eext, double cext,
+                           double *x, double *y, double *z, po_info *info) {
     if (n <= 0 || m < 0 || !prm || !x || !y || !z || !info) return PO_ERR_INVALID;
     const int pnz = Pp0[n], anz = Ap0[n];
     int rc = PO_OK;
@@ -881,7 +891,18 @@ int po_oracle_qp_solve(int n, int m, const int *Pp0, const int *Pi0, const doubl
     for (int i = 0; i < m; ++i) E[i] = Einv[i] = 1.0;
 
     /* ---- Ruiz equilibration (OSQP scale_data); off (0 passes) on the device-matching path ---- */
-    for (int pass = 0; pass < prm->scaling; ++pass) {
+    const int ruiz_passes = Dext ? 0 : (prm->scaling > 0 ? prm->scaling : 0);
+    if (Dext) { /* external diagonal equilibration */
+        for (int c = 0; c < n; ++c) {
+            for (int k = Pp0[c]; k < Pp0[c + 1]; ++k) Px[k] *= Dext[c] * Dext[Pi0[k]] * cext;
+            for (int k = Ap0[c]; k < Ap0[c + 1]; ++k) Ax[k] *= Dext[c] * Eext[Ai0[k]];
+            q[c] *= Dext[c] * cext;
+            D[c] = Dext[c];
+        }
+        for (int i = 0; i < m; ++i) E[i] = Eext[i];
+        cscale = cext;
+    }
+    for (int pass = 0; pass < ruiz_passes; ++pass) {
         for (int i = 0; i < n; ++i) tn[i] = 0;
         for (int i = 0; i < m; ++i) tm[i] = 0;
         for (int c = 0; c < n; ++c) { /* column inf-norms of [P; A], rows of A */
@@ -925,7 +946,7 @@ int po_oracle_qp_solve(int n, int m, const int *Pp0, const int *Pi0, const doubl
         for (int i = 0; i < n; ++i) q[i] *= ct;
         cscale *= ct;
     }
-    if (prm->scaling > 0) {
+    if (ruiz_passes > 0 || Dext) {
         for (int i = 0; i < n; ++i) Dinv[i] = 1.0 / D[i];
         for (int i = 0; i < m; ++i) {
             Einv[i] = 1.0 / E[i];
@@ -1137,6 +1158,173 @@ done:
     return rc;
 }
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* Class-level equilibration ("structured Ruiz").                                               */
+/* OSQP's Ruiz passes on these QPs return the SAME factor for every variable / row of one kind   */
+/* (the pattern repeats along the path and the data-dependent entries never attain a column's    */
+/* inf-norm), so the same iteration is run once on a one-stage template with the path's nominal */
+/* arc-length step.  The device engine implements exactly this; mode scaling<0.   */
+/* variable classes: 0 e_y, 1 e_phi, 2 c (k or delta), 3 s1, 4 s2, 5 u, 6 su, 7 dead            */
+/* ------------------------------------------------------------------------------------------ */
+#define PO_NVC 8
+#define PO_NRC 24
+typedef struct {
+    int nr;
+    double Pmax[PO_NVC], cnt[PO_NVC];
+    double a[PO_NRC][PO_NVC];
+    int tgt[PO_NRC];
+} class_model_t;
+
+static void class_model_build(class_model_t *M, int form, const po_params *p, int N, int keep, double ds) {
+    int n, m, C;
+    po_oracle_dims(form, N, keep, &n, &m, &C);
+    memset(M, 0, sizeof(*M));
+    for (int r = 0; r < PO_NRC; ++r) M->tgt[r] = -1;
+    const double d1 = p->d[0], d2 = p->d[1], d3 = p->d[2], d4 = p->d[3];
+    int r = 0;
+#define ROW2(dv) do { M->a[r][0] = 1; M->a[r][1] = (dv); ++r; } while (0)
+#define ROW2S(dv, sg) do { M->a[r][0] = 1; M->a[r][1] = (dv); M->a[r][3] = (sg); ++r; } while (0)
+    if (form == PO_KP) {
+        M->a[r][2] = 1; ++r;            /* k box   */
+        M->a[r][3] = 1; ++r;            /* S box   */
+        ROW2(d1); ROW2(d3);             /* hard    */
+        ROW2S(d4, -1); ROW2S(d4, 1); ROW2S(d2, -1); ROW2S(d2, 1);
+        /* dyn rows */
+        M->a[r][0] = 1; M->a[r][1] = ds; M->tgt[r] = 0; ++r;
+        M->a[r][1] = 1; M->a[r][2] = ds; M->tgt[r] = 1; ++r;  /* a10 = -k^2 ds: template k = 0 */
+        M->a[r][2] = 1; M->a[r][5] = ds; M->tgt[r] = 2; ++r;
+        M->a[r][5] = 1; ++r;            /* U box   */
+        M->a[r][0] = 1; ++r;            /* end e_y */
+        M->a[r][1] = 1; ++r;            /* end e_phi */
+        const double Pm[PO_NVC] = {p->w_dev, 0, p->w_curv, p->w_slack, 0, keep * p->w_curv_rate, 0, p->w_slack};
+        const double cn[PO_NVC] = {N, N, N, N, 0, C, 0, N};
+        memcpy(M->Pmax, Pm, sizeof(Pm)); memcpy(M->cnt, cn, sizeof(cn));
+    } else if (form == PO_KPC) {
+        M->a[r][2] = 1; M->a[r][4] = 1; ++r;   /* kl */
+        M->a[r][2] = 1; M->a[r][4] = -1; ++r;  /* ku */
+        M->a[r][3] = 1; ++r;                   /* Sc box */
+        M->a[r][4] = 1; ++r;                   /* Sk box */
+        ROW2(d1); ROW2(d2); ROW2(d4);
+        ROW2S(d3, -1); ROW2S(d3, 1);
+        M->a[r][0] = 1; M->a[r][1] = ds; M->tgt[r] = 0; ++r;
+        M->a[r][1] = 1; M->a[r][2] = ds; M->tgt[r] = 1; ++r;
+        M->a[r][2] = 1; M->a[r][5] = ds; M->tgt[r] = 2; ++r;
+        M->a[r][5] = 1; M->a[r][6] = 1; ++r;   /* kpl */
+        M->a[r][5] = 1; M->a[r][6] = -1; ++r;  /* kpu */
+        M->a[r][6] = 1; ++r;                   /* Skp >= 0 */
+        M->a[r][0] = 1; ++r;
+        M->a[r][1] = 1; ++r;
+        const double Pm[PO_NVC] = {p->w_dev, 0, p->w_curv, p->w_slack, p->w_k_slack, keep * p->w_curv_rate, p->w_kp_slack * keep, 0};
+        const double cn[PO_NVC] = {N, N, N, N, N, C, C, N - C};
+        memcpy(M->Pmax, Pm, sizeof(Pm)); memcpy(M->cnt, cn, sizeof(cn));
+    } else {
+        M->a[r][1] = 1; ++r;  /* identity e_phi */
+        M->a[r][0] = 1; ++r;  /* identity e_y   */
+        M->a[r][2] = 1; ++r;  /* delta box      */
+        M->a[r][3] = 1; ++r;  /* S box          */
+        ROW2(d1); ROW2(d3); ROW2(d4);
+        ROW2S(d2, -1); ROW2S(d2, 1);
+        M->a[r][1] = 1; M->a[r][2] = ds / p->wheel_base; M->tgt[r] = 1; ++r;  /* e_phi equation, template k = 0 */
+        M->a[r][0] = 1; M->a[r][1] = ds; M->tgt[r] = 0; ++r;                   /* e_y equation */
+        const double Pm[PO_NVC] = {p->k_w_dev, 0, p->k_w_curv + 2 * p->k_w_curv_rate, p->w_slack, 0, 0, 0, 0};
+        const double cn[PO_NVC] = {N, N, N - 1, N, 0, 0, 0, 0};
+        memcpy(M->Pmax, Pm, sizeof(Pm)); memcpy(M->cnt, cn, sizeof(cn));
+    }
+#undef ROW2
+#undef ROW2S
+    M->nr = r;
+}
+
+/* Dv[8], Er[nr] (row classes in the order built above), *c. */
+static void class_ruiz(const class_model_t *M, int passes, double *Dv, double *Er, double *cs) {
+    double c = 1.0;
+    for (int v = 0; v < PO_NVC; ++v) Dv[v] = 1.0;
+    for (int r = 0; r < M->nr; ++r) Er[r] = 1.0;
+    double ntot = 0;
+    for (int v = 0; v < PO_NVC; ++v) ntot += M->cnt[v];
+    for (int pass = 0; pass < passes; ++pass) {
+        double cn[PO_NVC], rn[PO_NRC];
+        for (int v = 0; v < PO_NVC; ++v) cn[v] = fabs(c * M->Pmax[v] * Dv[v] * Dv[v]);
+        for (int r = 0; r < M->nr; ++r) {
+            double rmax = 0;
+            for (int v = 0; v < PO_NVC; ++v) {
+                double a = fabs(Er[r] * M->a[r][v] * Dv[v]);
+                if (a > rmax) rmax = a;
+                if (a > cn[v]) cn[v] = a;
+            }
+            if (M->tgt[r] >= 0) {
+                double a = fabs(Er[r] * Dv[M->tgt[r]]);
+                if (a > rmax) rmax = a;
+                if (a > cn[M->tgt[r]]) cn[M->tgt[r]] = a;
+            }
+            rn[r] = rmax;
+        }
+        for (int v = 0; v < PO_NVC; ++v) Dv[v] *= 1.0 / sqrt(limit_scaling(cn[v]));
+        for (int r = 0; r < M->nr; ++r) Er[r] *= 1.0 / sqrt(limit_scaling(rn[r]));
+        double mean = 0;
+        for (int v = 0; v < PO_NVC; ++v) mean += M->cnt[v] * fabs(c * M->Pmax[v] * Dv[v] * Dv[v]);
+        mean /= ntot;
+        double ct = mean > 1.0 ? mean : 1.0; /* ||q||_inf = 0 -> limit_scaling -> 1 */
+        ct = 1.0 / limit_scaling(ct);
+        c *= ct;
+    }
+    *cs = c;
+}
+
+/* Expand class factors to the reference variable/row ordering. */
+int po_oracle_class_scaling(int form, const po_params *p, int N, int keep, double ds_nom, int passes,
+                            double *D, double *E, double *cs) {
+    int n, m, C;
+    int rc = po_oracle_dims(form, N, keep, &n, &m, &C);
+    if (rc) return rc;
+    class_model_t M;
+    double Dv[PO_NVC], Er[PO_NRC];
+    class_model_build(&M, form, p, N, keep, ds_nom);
+    class_ruiz(&M, passes, Dv, Er, cs);
+    if (form == PO_KP) {
+        for (int i = 0; i < N; ++i) {
+            D[3 * i] = Dv[0]; D[3 * i + 1] = Dv[1]; D[3 * i + 2] = Dv[2];
+            D[3 * N + C + i] = Dv[3]; D[3 * N + C + N + i] = Dv[7];
+            E[3 * i] = Er[8]; E[3 * i + 1] = Er[9]; E[3 * i + 2] = Er[10];
+            E[3 * N + i] = Er[0]; E[4 * N + C + i] = Er[1];
+            const int cb = 5 * N + C;
+            E[cb + 2 * i] = Er[2]; E[cb + 2 * i + 1] = Er[3];
+            E[cb + 2 * N + i] = Er[4]; E[cb + 3 * N + i] = Er[5]; E[cb + 4 * N + i] = Er[6]; E[cb + 5 * N + i] = Er[7];
+        }
+        for (int c = 0; c < C; ++c) { D[3 * N + c] = Dv[5]; E[4 * N + c] = Er[11]; }
+        E[11 * N + C] = Er[12]; E[11 * N + C + 1] = Er[13];
+    } else if (form == PO_KPC) {
+        const int sb = 5 * N + 2 * C, cb = 7 * N + 3 * C, s0 = 3 * N + C;
+        for (int i = 0; i < N; ++i) {
+            D[3 * i] = Dv[0]; D[3 * i + 1] = Dv[1]; D[3 * i + 2] = Dv[2];
+            D[s0 + i] = Dv[3]; D[s0 + N + i] = Dv[4];
+            E[3 * i] = Er[9]; E[3 * i + 1] = Er[10]; E[3 * i + 2] = Er[11];
+            E[3 * N + i] = Er[0]; E[4 * N + i] = Er[1]; E[sb + i] = Er[2]; E[sb + N + i] = Er[3];
+            E[cb + 3 * i] = Er[4]; E[cb + 3 * i + 1] = Er[5]; E[cb + 3 * i + 2] = Er[6];
+            E[cb + 3 * N + i] = Er[7]; E[cb + 4 * N + i] = Er[8];
+        }
+        for (int c = 0; c < C; ++c) {
+            D[3 * N + c] = Dv[5]; D[s0 + 2 * N + c] = Dv[6];
+            E[5 * N + c] = Er[12]; E[5 * N + C + c] = Er[13]; E[sb + 2 * N + c] = Er[14];
+        }
+        for (int i = 0; i < N - C; ++i) D[s0 + 2 * N + C + i] = Dv[7];
+        E[cb + 5 * N] = Er[15]; E[cb + 5 * N + 1] = Er[16];
+    } else {
+        for (int i = 0; i < N; ++i) {
+            D[2 * i] = Dv[1]; D[2 * i + 1] = Dv[0]; D[3 * N - 1 + i] = Dv[3];
+            if (i < N - 1) D[2 * N + i] = Dv[2];
+            E[2 * i] = Er[9]; E[2 * i + 1] = Er[10];
+            E[2 * N + 2 * i] = Er[0]; E[2 * N + 2 * i + 1] = Er[1];
+            if (i < N - 1) E[4 * N + i] = Er[2];
+            E[5 * N - 1 + i] = Er[3];
+            E[6 * N - 1 + 3 * i] = Er[4]; E[6 * N - 1 + 3 * i + 1] = Er[5]; E[6 * N - 1 + 3 * i + 2] = Er[6];
+            E[9 * N - 1 + i] = Er[7]; E[10 * N - 1 + i] = Er[8];
+        }
+    }
+    return PO_OK;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* Part 3: output map                                                                           */
 /* ------------------------------------------------------------------------------------------ */
@@ -1222,7 +1410,18 @@ int po_oracle_solve_path(int form, const po_params *p, int N, int keep, const do
             kkt_free(&K0);
             free(ri);
         }
-        rc = po_oracle_qp_solve(n, m, Pp, Pi, Px, NULL, Ap, Ai, Ax, l, u, p, perm, x, y, z, &li);
+        if (p->scaling < 0) { /* class-level equilibration with the path's nominal step (max of the first <= 9 gaps) */
+            double ds_nom = 0;
+            for (int i = 1; i < N && i < 10; ++i) { double d = ref_s[i] - ref_s[i - 1]; if (d > ds_nom) ds_nom = d; }
+            double *Dx = (double *)malloc(sizeof(double) * (size_t)n), *Ex = (double *)malloc(sizeof(double) * (size_t)m), cs = 1.0;
+            for (int i = 0; i < n; ++i) Dx[i] = 1.0;
+            for (int i = 0; i < m; ++i) Ex[i] = 1.0;
+            po_oracle_class_scaling(form, p, N, keep, ds_nom, -p->scaling, Dx, Ex, &cs);
+            rc = po_oracle_qp_solve_ext(n, m, Pp, Pi, Px, NULL, Ap, Ai, Ax, l, u, p, perm, Dx, Ex, cs, x, y, z, &li);
+            free(Dx); free(Ex);
+        } else {
+            rc = po_oracle_qp_solve(n, m, Pp, Pi, Px, NULL, Ap, Ai, Ax, l, u, p, perm, x, y, z, &li);
+        }
     }
     if (rc == PO_OK) {
         ok = li.status == PO_STATUS_SOLVED;

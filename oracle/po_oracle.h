@@ -54,6 +54,18 @@ int po_oracle_qp_solve(int n, int m, const int *Pp, const int *Pi, const double 
                        const po_params *p, const int *perm, double *x, double *y, double *z,
                        po_info *info);
 
+/* As po_oracle_qp_solve but with an externally supplied diagonal equilibration (D per variable, E per row,
+ * cost scale c) replacing the Ruiz passes when D != NULL. */
+int po_oracle_qp_solve_ext(int n, int m, const int *Pp, const int *Pi, const double *Px, const double *q,
+                           const int *Ap, const int *Ai, const double *Ax, const double *l, const double *u,
+                           const po_params *p, const int *perm, const double *D, const double *E, double c,
+                           double *x, double *y, double *z, po_info *info);
+
+/* Class-level ("structured") Ruiz equilibration expanded to the reference ordering; used when
+ * po_params.scaling < 0 (|scaling| passes).  This is what the device engine implements. */
+int po_oracle_class_scaling(int form, const po_params *p, int N, int keep, double ds_nom, int passes,
+                            double *D, double *E, double *c);
+
 /* Stage-interleaved KKT permutation for a formulation (keeps LDL' fill O(n)). perm has n+m entries. */
 int po_oracle_kkt_perm(int form, int N, int keep, int *perm);
 

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libpo_hip.so")
 _LIB = None
 
 EXPORTS = ["po_default_params", "po_problem_dims", "po_keep_control_steps", "po_create", "po_destroy", "po_set_stream",
-           "po_solve_batch", "po_solve_batch_device", "po_assemble_batch", "po_last_kernel_ms", "po_strerror",
+           "po_solve_batch", "po_solve_batch_device", "po_assemble_batch", "po_scaling_batch", "po_last_kernel_ms", "po_strerror",
            "po_last_hip_error", "po_version"]
 
 
@@ -42,6 +42,7 @@ def lib():
         L.po_solve_batch.argtypes = [C.c_void_p, C.POINTER(PoBatchIn), C.POINTER(PoBatchOut)]
         L.po_solve_batch_device.argtypes = [C.c_void_p, C.POINTER(PoBatchIn), C.POINTER(PoBatchOut)]
         L.po_assemble_batch.argtypes = [C.c_void_p, C.POINTER(PoBatchIn), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.po_scaling_batch.argtypes = [C.c_void_p, C.POINTER(PoBatchIn), C.c_void_p]
         L.po_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         _LIB = L
     return _LIB
@@ -121,6 +122,13 @@ class Engine:
         l = np.zeros((batch.B, m)); u = np.zeros((batch.B, m)); dyn = np.zeros((batch.B, batch.N - 1, 3))
         _check(lib().po_assemble_batch(self._h, C.byref(bi), _np(l), _np(u), _np(dyn)))
         return l, u, dyn
+
+    def scaling_batch(self, batch):
+        bi = PoBatchIn(batch.formulation, batch.B, batch.N, batch.keep, _np(batch.ref_x), _np(batch.ref_y), _np(batch.ref_z),
+                       _np(batch.ref_k), _np(batch.ref_s), _np(batch.bounds), _np(batch.x0), _np(batch.goal_z), _np(batch.max_k), _np(batch.max_kp))
+        out = np.zeros((batch.B, 64))
+        _check(lib().po_scaling_batch(self._h, C.byref(bi), _np(out)))
+        return out
 
     # ---- device-pointer path: tensors are torch CUDA(=HIP) tensors already resident in HBM ----
     def solve_batch_device(self, dev: "DeviceBatch"):

@@ -14,7 +14,8 @@
 #include "../../include/po_hip.h"
 #include "po_device.hpp"
 
-extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out, int variant);
+extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out);
+extern "C" hipError_t po_launch_scale(int form, const po::DevBatch *in, const po::DevParams *P, int passes, double *sc, hipStream_t st);
 extern "C" hipError_t po_launch_assemble(int form, const po::DevBatch *in, const po::DevParams *P, double *l, double *u, double *dyn, hipStream_t st);
 extern "C" size_t po_lds_bytes(int form, int N, int C);
 
@@ -56,7 +57,7 @@ struct po_handle_s {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    DevBuf in_buf, out_buf, asm_buf;
+    DevBuf in_buf, out_buf, asm_buf, scale_buf, dbg_buf;
     std::mutex mu;
 };
 
@@ -78,7 +79,7 @@ void po_default_params(po_params *p) {
     p->max_steer = 30.0 * M_PI / 180.0;
     p->wheel_base = 2.85;
     p->constraint_end_heading = 1;
-    p->scaling = 0;
+    p->scaling = 10;  // OSQP default (the reference leaves it untouched)
     p->eps_abs = 1e-4; p->eps_rel = 1e-4; p->eps_prim_inf = 1e-4; p->eps_dual_inf = 1e-4;
     p->rho0 = 0.1; p->sigma = 1e-6; p->alpha = 1.6; p->adapt_tol = 5.0;
     p->max_iter = 4000; p->check_every = 25; p->adapt_every = 100;
@@ -118,7 +119,7 @@ int po_keep_control_steps(int form, const double *ref_s, int N) {
 
 int po_create(int device, const po_params *params, po_handle *out) {
     if (!params || !out) return PO_ERR_INVALID;
-    if (params->scaling != 0) return PO_ERR_UNSUPPORTED;  // device path runs unscaled ADMM
+    if (params->scaling < 0 || params->scaling > 100) return PO_ERR_INVALID;
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return PO_ERR_INVALID;
@@ -141,7 +142,7 @@ int po_destroy(po_handle h) {
     if (!h) return PO_ERR_INVALID;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    h->in_buf.release(); h->out_buf.release(); h->asm_buf.release();
+    h->in_buf.release(); h->out_buf.release(); h->asm_buf.release(); h->scale_buf.release(); h->dbg_buf.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -197,6 +198,7 @@ static void fill_dev_batch(po::DevBatch *D, const po_batch_in *in, const po_batc
     D->out_info = out ? out->info : nullptr;
     D->out_x = out ? out->x : nullptr;
     D->dbg_cycles = nullptr;
+    D->scale = nullptr;
     D->n = n; D->m = m;
 }
 
@@ -214,12 +216,15 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     fill_dev_batch(&D, in, out, n, m, C);
     const bool dbg = std::getenv("PO_DEBUG_CYCLES") != nullptr;
     if (dbg) {
-        if ((rc = h->asm_buf.ensure(sizeof(long long) * 4 * (size_t)in->B))) return rc;
-        D.dbg_cycles = static_cast<long long *>(h->asm_buf.p);
+        if ((rc = h->dbg_buf.ensure(sizeof(long long) * 4 * (size_t)in->B))) return rc;
+        D.dbg_cycles = static_cast<long long *>(h->dbg_buf.p);
     }
+    if ((rc = h->scale_buf.ensure(sizeof(double) * 64 * (size_t)in->B))) return rc;
+    D.scale = static_cast<double *>(h->scale_buf.p);
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    const char *ve = std::getenv("PO_KERNEL_VARIANT");  // dev/test knob: 1 = generic LDS kernel, 2 = register-resident kernel
-    HIP_TRY(po_launch_solve(in->formulation, &D, &P, h->stream, nullptr, ve ? std::atoi(ve) : 0));
+    // per-path equilibration (h->params.scaling class-level Ruiz passes; 0 -> identity), then the fused solve
+    HIP_TRY(po_launch_scale(in->formulation, &D, &P, h->params.scaling, static_cast<double *>(h->scale_buf.p), h->stream));
+    HIP_TRY(po_launch_solve(in->formulation, &D, &P, h->stream, nullptr));
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     if (dbg) {
@@ -320,6 +325,31 @@ int po_assemble_batch(po_handle h, const po_batch_in *in, double *l, double *u, 
     return PO_OK;
 }
 
+int po_scaling_batch(po_handle h, const po_batch_in *in, double *out) {
+    if (!h || !out) return PO_ERR_INVALID;
+    int n, m, C;
+    int rc = validate(in, &n, &m, &C);
+    if (rc) return rc;
+    if (in->B == 0) return PO_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t B = in->B, N = in->N;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        if ((rc = h->in_buf.ensure(sizeof(double) * B * N)) || (rc = h->scale_buf.ensure(sizeof(double) * 64 * B))) return rc;
+    }
+    po_batch_in din = *in;
+    HIP_TRY(hipMemcpyAsync(h->in_buf.p, in->ref_s, sizeof(double) * B * N, hipMemcpyHostToDevice, h->stream));
+    din.ref_s = static_cast<const double *>(h->in_buf.p);
+    po::DevParams P;
+    make_dev_params(h, in->formulation, in->keep, &P);
+    po::DevBatch D;
+    fill_dev_batch(&D, &din, nullptr, n, m, C);
+    HIP_TRY(po_launch_scale(in->formulation, &D, &P, h->params.scaling, static_cast<double *>(h->scale_buf.p), h->stream));
+    HIP_TRY(hipMemcpyAsync(out, h->scale_buf.p, sizeof(double) * 64 * B, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PO_OK;
+}
+
 int po_last_kernel_ms(po_handle h, float *ms) {
     if (!h || !ms || !h->timed) return PO_ERR_INVALID;
     HIP_TRY(hipEventSynchronize(h->ev1));
@@ -332,7 +362,7 @@ const char *po_strerror(int code) {
         case PO_OK: return "ok";
         case PO_ERR_INVALID: return "invalid argument";
         case PO_ERR_HIP: return "HIP runtime error (see po_last_hip_error)";
-        case PO_ERR_UNSUPPORTED: return "unsupported configuration (path too long for the LDS tile, or scaling != 0)";
+        case PO_ERR_UNSUPPORTED: return "unsupported configuration (path too long for the on-chip tile)";
         case PO_ERR_NOMEM: return "out of memory";
         default: return "unknown error";
     }

@@ -41,6 +41,7 @@ struct DevBatch {
     double *out_states;
     po_info *out_info;
     double *out_x;
+    const double *scale;    // [B][64] per-path equilibration block (po_scale.hpp)
     long long *dbg_cycles;  // optional [B][4] per-phase shader-clock totals (dev tool), or nullptr
     int n, m;
 };
@@ -236,5 +237,140 @@ __device__ __forceinline__ double wave_max(double v) {
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
     return v;
 }
+
+// -------------------------------------------------------------------------------------------------------
+// row functors
+// -------------------------------------------------------------------------------------------------------
+// Every functor carries the per-path equilibration of the row kind it is visiting: W[r] = E_r^2 / c (step
+// multiplier) and E[r] (bounds are classified on the SCALED problem, like OSQP's set_rho_vec).
+__device__ __forceinline__ double row_rho(double l, double u, double e, double w, double rho, double rho_eq) {
+    return rho_of(l * e, u * e, rho, rho_eq) * w;
+}
+
+struct HessFn {  // H(5x5 sym, upper, row-major packed 15) += rho * a a'
+    double H[15];
+    double rho, rho_eq;
+    const double *W, *E;
+    __device__ HessFn(double r, double re, const double *W_, const double *E_) : rho(r), rho_eq(re), W(W_), E(E_) {
+#pragma unroll
+        for (int i = 0; i < 15; ++i) H[i] = 0;
+    }
+    static __device__ __forceinline__ constexpr int idx(int a, int b) { return a * 5 - a * (a - 1) / 2 + (b - a); }
+    template <int MASK> __device__ __forceinline__ void row(int ri, double c0, double c1, double c2, double c3, double c4, double l, double u) {
+        const double r = row_rho(l, u, E[ri], W[ri], rho, rho_eq);
+        const double c[5] = {c0, c1, c2, c3, c4};
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+            for (int b = a; b < 5; ++b)
+                if ((MASK >> a & 1) && (MASK >> b & 1)) H[idx(a, b)] += r * c[a] * c[b];
+    }
+};
+
+// rhs pass: t = 2*zc - v (zc = clip(v), or 0 on the very first iteration); g += rho * t * a
+struct RhsFn {
+    double g[5];
+    const double *v;  // LDS, element r at v[r*stride]
+    int stride;
+    double rho, rho_eq;
+    const double *W, *E;
+    bool first;
+    template <int MASK> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, double l, double u) {
+        const double rr = row_rho(l, u, E[r], W[r], rho, rho_eq);
+        const double vv = v[r * stride];
+        const double zc = first ? 0.0 : clipd(vv, l, u);
+        const double t = rr * (2.0 * zc - vv);
+        const double c[5] = {c0, c1, c2, c3, c4};
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+            if (MASK >> a & 1) g[a] += t * c[a];
+    }
+};
+
+// update pass: ztilde = a . xtilde ; v += alpha (ztilde - zc)
+struct UpdFn {
+    double xt[5];
+    double *v;
+    int stride;
+    double alpha;
+    bool first;
+    template <int MASK> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, double l, double u) {
+        const double c[5] = {c0, c1, c2, c3, c4};
+        double zt = 0;
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+            if (MASK >> a & 1) zt += c[a] * xt[a];
+        const double vv = v[r * stride];
+        const double zc = first ? 0.0 : clipd(vv, l, u);
+        v[r * stride] = vv + alpha * (zt - zc);
+    }
+};
+
+// residual pass: Ax, z = clip(v), y = rho (v - z)
+struct ResFn {
+    double x[5];
+    double aty[5];
+    const double *v;
+    int stride;
+    double rho, rho_eq;
+    const double *W, *E;
+    double rp, nAx, nz;     // unscaled (termination)
+    double rps, nAxs, nzs;  // scaled by E (rho estimate)
+    template <int MASK> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, double l, double u) {
+        const double rr = row_rho(l, u, E[r], W[r], rho, rho_eq);
+        const double c[5] = {c0, c1, c2, c3, c4};
+        double ax = 0;
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+            if (MASK >> a & 1) ax += c[a] * x[a];
+        const double vv = v[r * stride];
+        const double z = clipd(vv, l, u);
+        const double y = rr * (vv - z);
+        const double e = E[r];
+        rp = fmax(rp, fabs(ax - z)); nAx = fmax(nAx, fabs(ax)); nz = fmax(nz, fabs(z));
+        rps = fmax(rps, e * fabs(ax - z)); nAxs = fmax(nAxs, e * fabs(ax)); nzs = fmax(nzs, e * fabs(z));
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+            if (MASK >> a & 1) aty[a] += y * c[a];
+    }
+};
+
+// rho change: keep z and y, re-express v = z + y/rho_new = zc + (rho_old/rho_new)(v - zc)
+struct RescaleFn {
+    double *v;
+    int stride;
+    double ratio;
+    const double *E;
+    template <int MASK> __device__ __forceinline__ void row(int r, double, double, double, double, double, double l, double u) {
+        const double vv = v[r * stride];
+        const double zc = clipd(vv, l, u);
+        const bool loose = (l * E[r] < -kInfThresh && u * E[r] > kInfThresh);
+        v[r * stride] = loose ? vv : zc + ratio * (vv - zc);
+    }
+};
+
+// diagnostic assembly: l,u into the reference row order
+template <int F> struct AsmFn {
+    double *l, *u;
+    int j, N, C, kind;  // kind 0 local, 1 end, 2 ctl (j = control id)
+    template <int MASK> __device__ __forceinline__ void row(int r, double, double, double, double, double, double lo, double hi) {
+        const int rr = kind == 0 ? ref_row_local<F>(r, j, N, C) : (kind == 1 ? ref_row_end<F>(r, N, C) : ref_row_ctl<F>(r, j, N, C));
+        l[rr] = lo;
+        u[rr] = hi;
+    }
+};
+
+// Control-local rows.  KP: the vacuous row -inf <= u_c <= inf (solver_kp_as_input.cpp:105-107,160-163).
+// KPC: kpl / kpu / Skp >= 0 (solver_kp_as_input_constrained.cpp:119-125,178-187).  coefficient slots: (unused,unused,u,su,unused)
+template <int F, class Fn> __device__ __forceinline__ void ctl_rows(double maxkp, Fn &fn) {
+    if constexpr (F == F_KP) {
+        fn.template row<M_C>(0, 0., 0., 1., 0., 0., -kInf, kInf);
+    } else if constexpr (F == F_KPC) {
+        fn.template row<M_C | M_S1>(0, 0., 0., 1., 1., 0., -maxkp, kInf);
+        fn.template row<M_C | M_S1>(1, 0., 0., 1., -1., 0., -kInf, maxkp);
+        fn.template row<M_S1>(2, 0., 0., 0., 1., 0., 0.0, kInf);
+    }
+}
+
 
 }  // namespace po

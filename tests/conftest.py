@@ -23,4 +23,6 @@ def oracle():
 
 @pytest.fixture()
 def params(oracle):
-    return oracle.default_params()
+    p = oracle.default_params()
+    p.scaling = 0  # plain ADMM for the twin comparisons; tests that exercise equilibration set it explicitly
+    return p

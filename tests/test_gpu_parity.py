@@ -54,14 +54,50 @@ def test_device_assembly_matches_oracle(binding, oracle, form, name, N):
 
 
 @pytest.mark.parametrize("form,name", FORMS)
-def test_fixed_iteration_iterates_match_oracle(binding, oracle, form, name):
+def test_device_scaling_block_matches_oracle(binding, oracle, form, name):
+    """The per-path equilibration the kernel consumes equals the oracle's class-level Ruiz factors."""
+    for N, ds in ((40, 0.25), (77, 0.3), (30, 1.0)):
+        b = _rand_batch(form, 2, N, ds=ds, seed=N)
+        if form == T.PO_KP:
+            b.keep = binding.keep_control_steps(form, b.ref_s[0])
+        p = binding.default_params()
+        blk = binding.Engine(0, p).scaling_batch(b)
+        po = oracle.default_params()
+        ds_nom = np.max(np.diff(b.ref_s[0])[:9])
+        D, E, c = oracle.class_scaling(form, po, N, b.keep, ds_nom, 10)
+        n, m, C = oracle.dims(form, N, b.keep)
+        if form == T.PO_K:
+            dv = [D[3], D[2], D[2 * N + 1], D[3 * N]]          # e_y, e_phi, delta, S
+            er_dyn = [E[2], E[3]]
+            er_loc = [E[2 * N + 2], E[2 * N + 3], E[4 * N + 1], E[5 * N], E[6 * N - 1 + 3], E[6 * N - 1 + 4], E[6 * N - 1 + 5], E[9 * N], E[10 * N]]
+        else:
+            dv = [D[3], D[4], D[5], D[3 * N + C + 1]]
+            er_dyn = [E[3], E[4], E[5]]
+            if form == T.PO_KP:
+                cb = 5 * N + C
+                er_loc = [E[3 * N + 1], E[4 * N + C + 1], E[cb + 2], E[cb + 3], E[cb + 2 * N + 1], E[cb + 3 * N + 1], E[cb + 4 * N + 1], E[cb + 5 * N + 1]]
+            else:
+                sb, cb = 5 * N + 2 * C, 7 * N + 3 * C
+                er_loc = [E[3 * N + 1], E[4 * N + 1], E[sb + 1], E[sb + N + 1], E[cb + 3], E[cb + 4], E[cb + 5], E[cb + 3 * N + 1], E[cb + 4 * N + 1]]
+        er = np.array(er_loc + er_dyn)
+        for i in range(b.B):
+            np.testing.assert_allclose(blk[i, 63], c, rtol=1e-13)
+            np.testing.assert_allclose(blk[i, 24:24 + len(er)], er, rtol=1e-13)
+            np.testing.assert_allclose(blk[i, 0:len(er)], er ** 2 / c, rtol=1e-13)
+            np.testing.assert_allclose(blk[i, 48:52], po.sigma / (c * np.array(dv) ** 2), rtol=1e-13)
+            np.testing.assert_allclose(blk[i, 56:60], c * np.array(dv), rtol=1e-13)
+
+
+@pytest.mark.parametrize("form,name", FORMS)
+@pytest.mark.parametrize("scaling", [0, 10])
+def test_fixed_iteration_iterates_match_oracle(binding, oracle, form, name, scaling):
     """Same ADMM, same number of iterations, no termination test: iterates must agree to round-off."""
     b = _rand_batch(form, 6, 50, seed=3 + form, narrow=True)
     for iters, adapt in ((1, 0), (2, 0), (40, 0), (120, 50)):
         p = binding.default_params()
-        p.max_iter, p.check_every, p.adapt_every = iters, 0, adapt
+        p.max_iter, p.check_every, p.adapt_every, p.scaling = iters, 0, adapt, scaling
         po = oracle.default_params()
-        po.max_iter, po.check_every, po.adapt_every = iters, 0, adapt
+        po.max_iter, po.check_every, po.adapt_every, po.scaling = iters, 0, adapt, -scaling
         eng = binding.Engine(0, p)
         st, info, xs = eng.solve_batch(b, want_x=True)
         ost, oinfo, oxs = oracle.solve_batch(b, po)
@@ -79,7 +115,7 @@ def test_baseline_configs_match_oracle(binding, oracle, cfg, B):
     b = synth.make_batch(cfg, B=B)
     eng = binding.Engine(0)
     st, info, xs = eng.solve_batch(b, want_x=True)
-    ost, oinfo, oxs = oracle.solve_batch(b, oracle.default_params())
+    ost, oinfo, oxs = oracle.solve_batch(b, oracle.device_equivalent_params())
     assert np.array_equal(info["status"], oinfo["status"])
     same = info["iters"] == oinfo["iters"]
     assert same.mean() >= 0.9, (info["iters"], oinfo["iters"])  # a residual within round-off of eps may flip one check
@@ -96,7 +132,7 @@ def test_keep_quirk_and_ragged_sizes(binding, oracle):
         b.keep = binding.keep_control_steps(T.PO_KP, b.ref_s[0])
         assert b.keep == oracle.keep_steps(T.PO_KP, b.ref_s[0])
         p = binding.default_params(); p.max_iter, p.check_every, p.adapt_every = 60, 0, 0
-        po = oracle.default_params(); po.max_iter, po.check_every, po.adapt_every = 60, 0, 0
+        po = oracle.device_equivalent_params(); po.max_iter, po.check_every, po.adapt_every = 60, 0, 0
         st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
         ost, oinfo, oxs = oracle.solve_batch(b, po)
         assert np.abs(xs - oxs).max() < 1e-8, (N, ds, np.abs(xs - oxs).max())

@@ -228,6 +228,7 @@ def test_baseline_configs_solve(oracle, params):
         assert (info["status"] == 1).all(), (cfg, info)
         assert (info["r_prim"] < 1e-3).all() and (info["r_dual"] < 1e-3).all()
         tight = oracle.default_params()
+        tight.scaling = 0
         tight.eps_abs = tight.eps_rel = 1e-6
         tight.max_iter = 50000
         st2, info2, xs2 = oracle.solve_batch(b, tight)
@@ -235,3 +236,19 @@ def test_baseline_configs_solve(oracle, params):
         ey = xs[:, 0:3 * b.N:3] - xs2[:, 0:3 * b.N:3]
         rms = np.sqrt((ey ** 2).mean(axis=1))
         assert rms.max() < 0.5 and (info2["obj"] <= info["obj"] * (1 + 1e-2) + 1e-6).all(), (cfg, rms)
+
+
+def test_class_level_ruiz_reproduces_osqp_ruiz(oracle):
+    """The class-level equilibration the device runs (scaling < 0) behaves exactly like OSQP's Ruiz passes
+    (scaling > 0) on the BASELINE workloads: identical iteration counts and the same solution."""
+    b = synth.make_batch(3, B=12)
+    pr = oracle.default_params(); pr.scaling = 10
+    pc = oracle.default_params(); pc.scaling = -10
+    _, ir, xr = oracle.solve_batch(b, pr)
+    _, ic, xc = oracle.solve_batch(b, pc)
+    assert np.array_equal(ir["iters"], ic["iters"]) and np.array_equal(ir["n_refactor"], ic["n_refactor"])
+    assert np.abs(xr - xc).max() < 1e-6
+    # and equilibration pays: fewer iterations than plain ADMM
+    p0 = oracle.default_params(); p0.scaling = 0
+    _, i0, _ = oracle.solve_batch(b, p0)
+    assert ic["iters"].mean() < i0["iters"].mean()
