@@ -1,0 +1,26 @@
+#!/bin/bash
+# rocprofv3 recipe for the bench (run on the GPU box through gpurun): kernel-trace stats in one run, PMC
+# counters in their own runs (never combined with trace domains), outputs under gpurun_out/prof_<tag>/.
+TAG=${1:-r1}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $R/bench.py --steps 3 --warmup 1 --cpu-sample 0"
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.log
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- $BENCH > /dev/null 2> $OUT/pmc_fetch.log
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o write -- $BENCH > /dev/null 2> $OUT/pmc_write.log
+rocprofv3 --output-format csv --pmc SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU -d $OUT/pmc_sq -o sq -- $BENCH > /dev/null 2> $OUT/pmc_sq.log
+find $OUT -name "*.csv" | head -30
+for f in $(find $OUT/trace -name "*kernel_stats.csv"); do echo "== $f"; head -8 $f; done
+for f in $(find $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq -name "*counter_collection.csv"); do echo "== $f"; head -3 $f; python - "$f" <<'PY'
+import csv, sys, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r.get("Kernel_Name", "")[:60]
+    agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
+for k, d in agg.items():
+    print(k, dict(d))
+PY
+done
+cat $OUT/bench_trace.json | tail -1
