@@ -17,7 +17,7 @@
 extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out);
 extern "C" hipError_t po_launch_scale(int form, const po::DevBatch *in, const po::DevParams *P, int passes, double *sc, hipStream_t st);
 extern "C" hipError_t po_launch_assemble(int form, const po::DevBatch *in, const po::DevParams *P, double *l, double *u, double *dyn, hipStream_t st);
-extern "C" size_t po_lds_bytes(int form, int N, int C);
+extern "C" size_t po_lds_bytes(int form, int N, int C, int keep);
 
 namespace {
 thread_local std::string g_hip_err;
@@ -186,7 +186,7 @@ static int validate(const po_batch_in *in, int *n, int *m, int *C) {
     if (rc) return rc;
     if (!in->ref_x || !in->ref_y || !in->ref_z || !in->ref_k || !in->ref_s || !in->bounds || !in->x0 || !in->goal_z) return PO_ERR_INVALID;
     if (in->formulation == PO_KPC && (!in->max_k || !in->max_kp)) return PO_ERR_INVALID;
-    if (po_lds_bytes(in->formulation, in->N, *C) > 160 * 1024) return PO_ERR_UNSUPPORTED;
+    if (po_lds_bytes(in->formulation, in->N, *C, in->keep) > 160 * 1024) return PO_ERR_UNSUPPORTED;
     return PO_OK;
 }
 
@@ -216,7 +216,7 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     fill_dev_batch(&D, in, out, n, m, C);
     const bool dbg = std::getenv("PO_DEBUG_CYCLES") != nullptr;
     if (dbg) {
-        if ((rc = h->dbg_buf.ensure(sizeof(long long) * 4 * (size_t)in->B))) return rc;
+        if ((rc = h->dbg_buf.ensure(sizeof(long long) * 16 * (size_t)in->B))) return rc;
         D.dbg_cycles = static_cast<long long *>(h->dbg_buf.p);
     }
     if ((rc = h->scale_buf.ensure(sizeof(double) * 64 * (size_t)in->B))) return rc;
@@ -228,10 +228,11 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     if (dbg) {
-        long long c4[4];
+        long long c4[16];
         HIP_TRY(hipStreamSynchronize(h->stream));
         HIP_TRY(hipMemcpy(c4, D.dbg_cycles, sizeof(c4), hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "[po] path0 cycles: rhs %lld chain %lld update %lld over %lld iterations\n", c4[0], c4[1], c4[2], c4[3]);
+        std::fprintf(stderr, "[po] path0 cycles: rhs %lld solve %lld update %lld over %lld iterations | solve phases F1 %lld F2 %lld F3B1 %lld B2 %lld B3 %lld\n",
+                     c4[0], c4[1], c4[2], c4[3], c4[4], c4[5], c4[6], c4[7], c4[8]);
     }
     return PO_OK;
 }

@@ -137,24 +137,41 @@ template <class K> hipError_t launch1(K kern, const DevBatch *in, const DevParam
     hipLaunchKernelGGL(kern, dim3(in->B), dim3(nt), lds, st, *in, *P);
     return hipGetLastError();
 }
-// thread-block shape: NT threads x SPL stages per thread must cover N, and NT >= C (one control per thread)
-inline bool pick_shape(int N, int C, int *nt, int *spl) {
+// thread-block shape: NT threads x SPL stages per thread must cover N, and NT >= C (one control per thread).
+// Two-level mode needs chunk == control group (SPL == keep), or no held controls at all (K).
+struct Shape { int nt, spl; bool two; };
+inline bool pick_shape(int form, int N, int C, int keep, Shape *s) {
+    const bool no_u = (form == F_K);
+    if (no_u || (keep >= 2 && keep <= 4)) {
+        const int spl = no_u ? (N <= 128 ? 2 : 4) : keep;
+        for (int nt : {64, 128}) if (N <= nt * spl && C <= nt) { *s = {nt, spl, true}; return true; }
+    }
     const int cand[5][2] = {{64, 2}, {64, 4}, {128, 4}, {256, 2}, {256, 4}};
     for (auto &c : cand)
-        if (N <= c[0] * c[1] && C <= c[0]) { *nt = c[0]; *spl = c[1]; return true; }
+        if (N <= c[0] * c[1] && C <= c[0]) { *s = {c[0], c[1], false}; return true; }
     return false;
 }
 template <int F> hipError_t launch_form(const DevBatch *in, const DevParams *P, hipStream_t st, size_t *lds_out) {
-    int nt, spl;
-    if (!pick_shape(in->N, in->C, &nt, &spl)) return hipErrorInvalidValue;
-    const size_t lds = lds_bytes_fast<F>(in->N, in->C);
+    Shape s;
+    if (!pick_shape(F, in->N, in->C, in->keep, &s)) return hipErrorInvalidValue;
+    const size_t lds = lds_bytes_fast<F>(in->N, in->C, s.spl, s.two);
     if (lds_out) *lds_out = lds;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    if (nt == 64 && spl == 2) return launch1(&solve_kernel_fast<F, 2, 64>, in, P, 64, lds, st);
-    if (nt == 64) return launch1(&solve_kernel_fast<F, 4, 64>, in, P, 64, lds, st);
-    if (nt == 128) return launch1(&solve_kernel_fast<F, 4, 128>, in, P, 128, lds, st);
-    if (spl == 2) return launch1(&solve_kernel_fast<F, 2, 256>, in, P, 256, lds, st);
-    return launch1(&solve_kernel_fast<F, 4, 256>, in, P, 256, lds, st);
+#define PO_L(SPL_, NT_, TWO_) return launch1(&solve_kernel_fast<F, SPL_, NT_, TWO_>, in, P, NT_, lds, st)
+    if (s.two) {
+        if (s.spl == 2 && s.nt == 64) PO_L(2, 64, true);
+        if (s.spl == 2) PO_L(2, 128, true);
+        if (s.spl == 3 && s.nt == 64) PO_L(3, 64, true);
+        if (s.spl == 3) PO_L(3, 128, true);
+        if (s.nt == 64) PO_L(4, 64, true);
+        PO_L(4, 128, true);
+    }
+    if (s.nt == 64 && s.spl == 2) PO_L(2, 64, false);
+    if (s.nt == 64) PO_L(4, 64, false);
+    if (s.nt == 128) PO_L(4, 128, false);
+    if (s.spl == 2) PO_L(2, 256, false);
+    PO_L(4, 256, false);
+#undef PO_L
 }
 }  // namespace po
 
@@ -182,9 +199,9 @@ extern "C" hipError_t po_launch_assemble(int form, const po::DevBatch *in, const
     return hipGetLastError();
 }
 
-extern "C" size_t po_lds_bytes(int form, int N, int C) {
+extern "C" size_t po_lds_bytes(int form, int N, int C, int keep) {
     using namespace po;
-    int nt, spl;
-    if (!pick_shape(N, C, &nt, &spl)) return (size_t)1 << 30;
-    return form == F_KP ? lds_bytes_fast<F_KP>(N, C) : (form == F_KPC ? lds_bytes_fast<F_KPC>(N, C) : lds_bytes_fast<F_K>(N, C));
+    Shape s;
+    if (!pick_shape(form, N, C, keep, &s)) return (size_t)1 << 30;
+    return form == F_KP ? lds_bytes_fast<F_KP>(N, C, s.spl, s.two) : (form == F_KPC ? lds_bytes_fast<F_KPC>(N, C, s.spl, s.two) : lds_bytes_fast<F_K>(N, C, s.spl, s.two));
 }
