@@ -62,7 +62,10 @@ def main():
 
     cfg = args.config or (3 if world == 1 else 4)
     B = args.batch
-    batch = synth.make_batch(cfg, B=B, first_path=rank * B)  # weak scaling: fixed work per GPU
+    from path_optimizer_amd.shard import shard_range
+
+    lo, hi = shard_range(world * B, world, rank)  # weak scaling: fixed work per GPU, contiguous path ids
+    batch = synth.make_batch(cfg, B=hi - lo, first_path=lo)
     dbatch = binding.DeviceBatch(batch, device=dev)
     eng = binding.Engine(local_rank)
     stream = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream shared by torch events and the engine

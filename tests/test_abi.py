@@ -1,0 +1,70 @@
+"""CPU-only checks of the drop-in boundary: the shared library loads without a GPU, exports every entry point
+include/po_hip.h declares, the ctypes struct mirror has the C layout, host-side helpers agree with the oracle,
+and compute calls fail loudly (no CPU fallback) when no device is present."""
+import ctypes
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from path_optimizer_amd import abi, binding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "po_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(po_[a-z_0-9]+)\s*\(", hdr))
+    assert {"po_create", "po_solve_batch", "po_solve_batch_device", "po_destroy", "po_assemble_batch", "po_scaling_batch"} <= names
+    L = binding.lib()
+    for n in sorted(names):
+        assert hasattr(L, n), f"{n} declared in include/po_hip.h but not exported"
+    assert set(binding.EXPORTS) <= names
+
+
+def test_struct_layouts_match_c():
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "po_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(po_params), sizeof(po_info), sizeof(po_batch_in), sizeof(po_batch_out), offsetof(po_params, eps_abs), offsetof(po_params, max_iter));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        out = subprocess.check_output([os.path.join(d, "t")]).split()
+    got = [int(x) for x in out]
+    assert got[:4] == [ctypes.sizeof(abi.PoParams), ctypes.sizeof(abi.PoInfo), ctypes.sizeof(abi.PoBatchIn), ctypes.sizeof(abi.PoBatchOut)]
+    assert got[4] == abi.PoParams.eps_abs.offset and got[5] == abi.PoParams.max_iter.offset
+    assert np.dtype(abi.INFO_DTYPE).itemsize == ctypes.sizeof(abi.PoInfo)
+
+
+def test_host_helpers_agree_with_oracle(oracle):
+    po, pd = oracle.default_params(), binding.default_params()
+    for name, _ in abi.PoParams._fields_:
+        a, b = getattr(po, name), getattr(pd, name)
+        assert (list(a) == list(b)) if name == "d" else (a == b), name
+    for form in (0, 1, 2):
+        for N, keep in ((2, 4), (80, 4), (200, 4), (77, 3 if form == 0 else 4)):
+            k = 4 if form == 1 else keep
+            assert binding.problem_dims(form, N, k) == oracle.dims(form, N, k)
+    for ds in (0.15, 0.25, 0.3, 0.5, 1.0, 2.0):
+        s = ds * np.arange(40)
+        assert binding.keep_control_steps(0, s) == oracle.keep_steps(0, s)
+    with pytest.raises(binding.PoError):
+        binding.problem_dims(0, 1, 4)
+    with pytest.raises(binding.PoError):
+        binding.problem_dims(1, 50, 3)  # KPC hard-codes keep = 4
+
+
+def test_no_cpu_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(binding.PoError):
+        binding.Engine(0)  # po_create fails loudly: there is no CPU path behind the C ABI
+
+
+def test_host_mirror_compiles():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "path_optimizer_amd", "host")], stdout=subprocess.DEVNULL)
+    assert os.path.exists(os.path.join(ROOT, "path_optimizer_amd", "host", "host_test"))

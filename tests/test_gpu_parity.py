@@ -189,3 +189,17 @@ def test_full_size_properties(binding):
     # initial state pinned, arc length monotone
     assert np.abs(ey[ok, 0] - big.x0[ok, 0]).max() < 2e-3
     assert (np.diff(st[:, :, 4], axis=1) > 0).all()
+
+
+def test_host_side_cpp_mirror(binding):
+    """The C++ OsqpSolver mirror (path_optimizer_amd/host) driven like path_optimizer.cpp:182-183."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "path_optimizer_amd", "host")], stdout=subprocess.DEVNULL)
+    for form in ("KP", "KPC", "K"):
+        r = subprocess.run([os.path.join(root, "path_optimizer_amd", "host", "host_test"), form, "60", "3"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "single ok=1" in r.stdout and "batch rc=0" in r.stdout and "create(KCP)=nullptr" in r.stdout
+        assert r.stdout.count("status=1") == 3
