@@ -142,6 +142,7 @@ template <class K> hipError_t launch1(K kern, const DevBatch *in, const DevParam
 struct Shape { int nt, spl; bool two; };
 inline bool pick_shape(int form, int N, int C, int keep, Shape *s) {
     const bool no_u = (form == F_K);
+    if (no_u) C = 0;  // K has no held controls: its N-1 steering variables live inside the nodes
     if (no_u || (keep >= 2 && keep <= 4)) {
         const int spl = no_u ? (N <= 128 ? 2 : 4) : keep;
         for (int nt : {64, 128}) if (N <= nt * spl && C <= nt) { *s = {nt, spl, true}; return true; }
@@ -154,7 +155,7 @@ inline bool pick_shape(int form, int N, int C, int keep, Shape *s) {
 template <int F> hipError_t launch_form(const DevBatch *in, const DevParams *P, hipStream_t st, size_t *lds_out) {
     Shape s;
     if (!pick_shape(F, in->N, in->C, in->keep, &s)) return hipErrorInvalidValue;
-    const size_t lds = lds_bytes_fast<F>(in->N, in->C, s.spl, s.two);
+    const size_t lds = lds_bytes_fast<F>(in->N, in->C, s.spl, s.two, s.nt);
     if (lds_out) *lds_out = lds;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
 #define PO_L(SPL_, NT_, TWO_) return launch1(&solve_kernel_fast<F, SPL_, NT_, TWO_>, in, P, NT_, lds, st)
@@ -203,5 +204,5 @@ extern "C" size_t po_lds_bytes(int form, int N, int C, int keep) {
     using namespace po;
     Shape s;
     if (!pick_shape(form, N, C, keep, &s)) return (size_t)1 << 30;
-    return form == F_KP ? lds_bytes_fast<F_KP>(N, C, s.spl, s.two) : (form == F_KPC ? lds_bytes_fast<F_KPC>(N, C, s.spl, s.two) : lds_bytes_fast<F_K>(N, C, s.spl, s.two));
+    return form == F_KP ? lds_bytes_fast<F_KP>(N, C, s.spl, s.two, s.nt) : (form == F_KPC ? lds_bytes_fast<F_KPC>(N, C, s.spl, s.two, s.nt) : lds_bytes_fast<F_K>(N, C, s.spl, s.two, s.nt));
 }
