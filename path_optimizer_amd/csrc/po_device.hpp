@@ -246,18 +246,37 @@ __device__ __forceinline__ double wave_max(double v) {
 __device__ __forceinline__ double row_rho(double l, double u, double e, double w, double rho, double rho_eq) {
     return rho_of(l * e, u * e, rho, rho_eq) * w;
 }
+// The class of a row (0 inequality, 1 equality, 2 free) depends only on its scaled bounds, i.e. it is fixed for the
+// whole solve: it is computed once per path and packed 2 bits per row; the passes decode instead of re-deriving it.
+__device__ __forceinline__ unsigned row_class(double l, double u, double e) {
+    const double ls = l * e, us = u * e;
+    if (ls < -kInfThresh && us > kInfThresh) return 2u;
+    return (us - ls < kRhoTol) ? 1u : 0u;
+}
+__device__ __forceinline__ double class_rho(unsigned cls, int r, double w, double rho, double rho_eq) {
+    const unsigned c = (cls >> (2 * r)) & 3u;
+    return w * (c == 0u ? rho : (c == 1u ? rho_eq : kRhoMin));
+}
+struct ClassFn {  // packs the row classes of one stage / control
+    unsigned cls;
+    const double *E;
+    template <int MASK> __device__ __forceinline__ void row(int r, double, double, double, double, double, double l, double u) {
+        cls |= row_class(l, u, E[r]) << (2 * r);
+    }
+};
 
 struct HessFn {  // H(5x5 sym, upper, row-major packed 15) += rho * a a'
     double H[15];
     double rho, rho_eq;
     const double *W, *E;
-    __device__ HessFn(double r, double re, const double *W_, const double *E_) : rho(r), rho_eq(re), W(W_), E(E_) {
+    unsigned cls;
+    __device__ HessFn(double r, double re, const double *W_, const double *E_, unsigned cls_) : rho(r), rho_eq(re), W(W_), E(E_), cls(cls_) {
 #pragma unroll
         for (int i = 0; i < 15; ++i) H[i] = 0;
     }
     static __device__ __forceinline__ constexpr int idx(int a, int b) { return a * 5 - a * (a - 1) / 2 + (b - a); }
     template <int MASK> __device__ __forceinline__ void row(int ri, double c0, double c1, double c2, double c3, double c4, double l, double u) {
-        const double r = row_rho(l, u, E[ri], W[ri], rho, rho_eq);
+        const double r = class_rho(cls, ri, W[ri], rho, rho_eq);
         const double c[5] = {c0, c1, c2, c3, c4};
 #pragma unroll
         for (int a = 0; a < 5; ++a)
@@ -274,9 +293,10 @@ struct RhsFn {
     int stride;
     double rho, rho_eq;
     const double *W, *E;
+    unsigned cls;
     bool first;
     template <int MASK> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, double l, double u) {
-        const double rr = row_rho(l, u, E[r], W[r], rho, rho_eq);
+        const double rr = class_rho(cls, r, W[r], rho, rho_eq);
         const double vv = v[r * stride];
         const double zc = first ? 0.0 : clipd(vv, l, u);
         const double t = rr * (2.0 * zc - vv);
@@ -314,10 +334,11 @@ struct ResFn {
     int stride;
     double rho, rho_eq;
     const double *W, *E;
+    unsigned cls;
     double rp, nAx, nz;     // unscaled (termination)
     double rps, nAxs, nzs;  // scaled by E (rho estimate)
     template <int MASK> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, double l, double u) {
-        const double rr = row_rho(l, u, E[r], W[r], rho, rho_eq);
+        const double rr = class_rho(cls, r, W[r], rho, rho_eq);
         const double c[5] = {c0, c1, c2, c3, c4};
         double ax = 0;
 #pragma unroll
@@ -340,11 +361,11 @@ struct RescaleFn {
     double *v;
     int stride;
     double ratio;
-    const double *E;
+    unsigned cls;
     template <int MASK> __device__ __forceinline__ void row(int r, double, double, double, double, double, double l, double u) {
         const double vv = v[r * stride];
         const double zc = clipd(vv, l, u);
-        const bool loose = (l * E[r] < -kInfThresh && u * E[r] > kInfThresh);
+        const bool loose = ((cls >> (2 * r)) & 3u) == 2u;
         v[r * stride] = loose ? vv : zc + ratio * (vv - zc);
     }
 };
