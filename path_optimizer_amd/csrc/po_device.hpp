@@ -232,6 +232,11 @@ __device__ __forceinline__ bool last_of_group(int i, int N, int keep) {
     return (i == N - 2) || (keep == 4 ? (((i + 1) & 3) == 0) : ((i + 1) % keep == 0));
 }
 
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
@@ -323,6 +328,42 @@ struct UpdFn {
         const double vv = v[r * stride];
         const double zc = first ? 0.0 : clipd(vv, l, u);
         v[r * stride] = vv + alpha * (zt - zc);
+    }
+};
+
+// update pass at a termination check: additionally accumulates OSQP's primal-infeasibility certificate on
+// delta_y = y_new - y_old of THIS iteration (is_primal_infeasible): ||dy||, u.dy+ + l.dy-, and A' dy.
+struct UpdCertFn {
+    double xt[5];
+    double *v;
+    int stride;
+    double alpha;
+    bool first;
+    double rho, rho_eq;
+    const double *W, *E;
+    unsigned cls;
+    double ady[5];        // A' dy contribution to the local variables
+    double ndy, sup;      // max |dy| (projected), sum of u*dy+ + l*dy-
+    template <int MASK> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, double l, double u) {
+        const double c[5] = {c0, c1, c2, c3, c4};
+        double zt = 0;
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+            if (MASK >> a & 1) zt += c[a] * xt[a];
+        const double vv = v[r * stride];
+        const double zc = first ? 0.0 : clipd(vv, l, u);
+        const double vn = vv + alpha * (zt - zc);
+        v[r * stride] = vn;
+        const double rr = class_rho(cls, r, W[r], rho, rho_eq);
+        double dy = rr * ((vn - clipd(vn, l, u)) - (vv - zc));
+        const bool uinf = u * E[r] > kInfThresh, linf = l * E[r] < -kInfThresh;
+        if (uinf) dy = linf ? 0.0 : fmin(dy, 0.0);
+        else if (linf) dy = fmax(dy, 0.0);
+        ndy = fmax(ndy, fabs(dy));
+        sup += (uinf ? 0.0 : u * fmax(dy, 0.0)) + (linf ? 0.0 : l * fmin(dy, 0.0));
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+            if (MASK >> a & 1) ady[a] += dy * c[a];
     }
 };
 

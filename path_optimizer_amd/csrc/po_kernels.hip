@@ -10,6 +10,8 @@
 // setConstraintMatrix, osqp_setup, osqp_solve, getOptimizedPath).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "../../include/po_hip.h"
 #include "po_device.hpp"
 #include "po_scale.hpp"
