@@ -32,6 +32,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise PoError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        try:  # if torch lives in this process too, let it load ITS libamdhip64 first so that both share one HIP runtime
+            import torch  # noqa: F401
+        except Exception:  # torch is optional plumbing (allocator / streams), never required by the library
+            pass
         L = C.CDLL(LIB_PATH)
         L.po_strerror.restype = C.c_char_p
         L.po_last_hip_error.restype = C.c_char_p

@@ -127,7 +127,7 @@ def test_baseline_configs_match_oracle(binding, oracle, cfg, B):
 
 def test_keep_quirk_and_ragged_sizes(binding, oracle):
     """ds = 0.3 -> keep = 3 (truncation quirk); N not a multiple of 64 or of keep."""
-    for N, ds in ((7, 0.3), (65, 0.3), (127, 0.5), (200, 2.0)):
+    for N, ds in ((7, 0.3), (65, 0.3), (127, 0.5), (200, 2.0), (90, 0.2), (150, 0.15), (300, 0.25), (511, 0.3)):
         b = _rand_batch(T.PO_KP, 2, N, ds=ds, seed=N)
         b.keep = binding.keep_control_steps(T.PO_KP, b.ref_s[0])
         assert b.keep == oracle.keep_steps(T.PO_KP, b.ref_s[0])
@@ -209,3 +209,40 @@ def test_host_side_cpp_mirror(binding):
         assert r.returncode == 0, r.stdout + r.stderr
         assert "single ok=1" in r.stdout and "batch rc=0" in r.stdout and "create(KCP)=nullptr" in r.stdout
         assert r.stdout.count("status=1") == 3
+
+
+def test_deterministic_and_device_pointer_entry(binding):
+    """Same inputs twice -> bit-identical outputs; the device-pointer entry (inputs resident in HBM, caller's stream)
+    returns exactly what the host-pointer entry returns."""
+    import torch
+
+    b = synth.make_batch(3, B=48)
+    eng = binding.Engine(0)
+    st1, info1, xs1 = eng.solve_batch(b, want_x=True)
+    st2, info2, xs2 = eng.solve_batch(b, want_x=True)
+    assert np.array_equal(xs1, xs2) and np.array_equal(st1, st2) and np.array_equal(info1["iters"], info2["iters"])
+    db = binding.DeviceBatch(b, want_x=True)
+    s = torch.cuda.Stream()
+    eng.set_stream(s.cuda_stream)
+    eng.solve_batch_device(db)
+    s.synchronize()
+    assert eng.last_kernel_ms() > 0
+    assert np.array_equal(db.out_x.cpu().numpy(), xs1) and np.array_equal(db.out_states.cpu().numpy(), st1)
+    assert np.array_equal(db.info_numpy()["iters"], info1["iters"])
+    eng.set_stream(None)
+
+
+@pytest.mark.parametrize("form,name", FORMS)
+def test_tiny_and_unsupported_sizes(binding, oracle, form, name):
+    """N = 2 and N = 3 (one or two transitions) solve like the oracle; sizes beyond the on-chip tile are refused with
+    PO_ERR_UNSUPPORTED instead of being computed somewhere else."""
+    for N in (2, 3):
+        b = _rand_batch(form, 2, N, seed=N)
+        p = binding.default_params(); p.max_iter, p.check_every, p.adapt_every = 30, 0, 0
+        po = oracle.device_equivalent_params(); po.max_iter, po.check_every, po.adapt_every = 30, 0, 0
+        st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
+        ost, oinfo, oxs = oracle.solve_batch(b, po)
+        assert np.abs(xs - oxs).max() < 1e-8
+    big = _rand_batch(form, 1, 1200, seed=1)
+    with pytest.raises(binding.PoError, match="unsupported"):
+        binding.Engine(0).solve_batch(big)
