@@ -105,6 +105,8 @@ typedef struct po_batch_in {
     const double *goal_z;   /* [B]: end_state.z                                                     */
     const double *max_k;    /* [B][N] KPC only (else NULL)                                          */
     const double *max_kp;   /* [B][N] KPC only; indexed by CONTROL id like the reference (:179-183) */
+    const int    *n_points; /* optional [B]: points of each path, 2 <= n_points[b] <= N (ragged batch); NULL = all N.
+                               Every array keeps its stride N; outputs beyond n_points[b] are zero.              */
 } po_batch_in;
 
 typedef struct po_batch_out {

@@ -36,6 +36,18 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+_KEEP = []
+
+
+def _i32(a):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    _KEEP.append(a)
+    del _KEEP[:-4]
+    return a
+
+
 def default_params() -> PoParams:
     p = PoParams()
     lib().po_oracle_default_params(C.byref(p))
@@ -131,7 +143,7 @@ def device_equivalent_params(params=None):
 def _batch_structs(batch, want_x):
     n, m, _ = dims(batch.formulation, batch.N, batch.keep)
     bi = PoBatchIn(batch.formulation, batch.B, batch.N, batch.keep, _p(batch.ref_x), _p(batch.ref_y), _p(batch.ref_z),
-                   _p(batch.ref_k), _p(batch.ref_s), _p(batch.bounds), _p(batch.x0), _p(batch.goal_z), _p(batch.max_k), _p(batch.max_kp))
+                   _p(batch.ref_k), _p(batch.ref_s), _p(batch.bounds), _p(batch.x0), _p(batch.goal_z), _p(batch.max_k), _p(batch.max_kp), _p(_i32(getattr(batch, 'n_points', None))))
     states = np.zeros((batch.B, batch.N, 5)); info = np.zeros(batch.B, dtype=INFO_DTYPE)
     xs = np.zeros((batch.B, n)) if want_x else None
     bo = PoBatchOut(_p(states), _p(info), _p(xs))

@@ -1439,14 +1439,20 @@ int po_oracle_solve_batch(const po_params *p, const po_batch_in *in, const po_ba
     int n, m, C;
     int rc = po_oracle_dims(in->formulation, in->N, in->keep, &n, &m, &C);
     if (rc) return rc;
-    const int N = in->N;
+    const int N = in->N;  /* stride of every array; a ragged batch gives each path its own length n_points[b] <= N */
     for (int b = 0; b < in->B; ++b) {
         const size_t o = (size_t)b * (size_t)N;
-        int r = po_oracle_solve_path(in->formulation, p, N, in->keep, in->ref_x + o, in->ref_y + o, in->ref_z + o,
+        const int Nb = in->n_points ? in->n_points[b] : N;
+        if (Nb < 2 || Nb > N) return PO_ERR_INVALID;
+        int nb, mb, Cb;
+        po_oracle_dims(in->formulation, Nb, in->keep, &nb, &mb, &Cb);
+        double *xb = out->x ? out->x + (size_t)b * (size_t)n : NULL;
+        if (out->states) memset(out->states + o * 5, 0, sizeof(double) * (size_t)N * 5);
+        if (xb) memset(xb, 0, sizeof(double) * (size_t)n);
+        int r = po_oracle_solve_path(in->formulation, p, Nb, in->keep, in->ref_x + o, in->ref_y + o, in->ref_z + o,
                                      in->ref_k + o, in->ref_s + o, in->bounds + o * 8, in->x0 + (size_t)b * 3,
                                      in->goal_z[b], in->max_k ? in->max_k + o : NULL, in->max_kp ? in->max_kp + o : NULL,
-                                     out->states ? out->states + o * 5 : NULL, out->x ? out->x + (size_t)b * (size_t)n : NULL,
-                                     NULL, out->info ? &out->info[b] : NULL);
+                                     out->states ? out->states + o * 5 : NULL, xb, NULL, out->info ? &out->info[b] : NULL);
         if (r < 0) return r;
     }
     return PO_OK;

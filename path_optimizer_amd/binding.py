@@ -85,6 +85,18 @@ def _np(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+_KEEP = []
+
+
+def _i32(a):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    _KEEP.append(a)  # keep alive for the duration of the call
+    del _KEEP[:-4]
+    return a
+
+
 class Engine:
     """One handle = one HIP device + one stream (po_create / po_destroy)."""
 
@@ -111,7 +123,7 @@ class Engine:
     def solve_batch(self, batch, want_x: bool = False):
         n, m, _ = problem_dims(batch.formulation, batch.N, batch.keep)
         bi = PoBatchIn(batch.formulation, batch.B, batch.N, batch.keep, _np(batch.ref_x), _np(batch.ref_y), _np(batch.ref_z),
-                       _np(batch.ref_k), _np(batch.ref_s), _np(batch.bounds), _np(batch.x0), _np(batch.goal_z), _np(batch.max_k), _np(batch.max_kp))
+                       _np(batch.ref_k), _np(batch.ref_s), _np(batch.bounds), _np(batch.x0), _np(batch.goal_z), _np(batch.max_k), _np(batch.max_kp), _np(_i32(getattr(batch, 'n_points', None))))
         states = np.zeros((batch.B, batch.N, 5))
         info = np.zeros(batch.B, dtype=INFO_DTYPE)
         xs = np.zeros((batch.B, n)) if want_x else None
@@ -122,14 +134,14 @@ class Engine:
     def assemble_batch(self, batch):
         n, m, _ = problem_dims(batch.formulation, batch.N, batch.keep)
         bi = PoBatchIn(batch.formulation, batch.B, batch.N, batch.keep, _np(batch.ref_x), _np(batch.ref_y), _np(batch.ref_z),
-                       _np(batch.ref_k), _np(batch.ref_s), _np(batch.bounds), _np(batch.x0), _np(batch.goal_z), _np(batch.max_k), _np(batch.max_kp))
+                       _np(batch.ref_k), _np(batch.ref_s), _np(batch.bounds), _np(batch.x0), _np(batch.goal_z), _np(batch.max_k), _np(batch.max_kp), _np(_i32(getattr(batch, 'n_points', None))))
         l = np.zeros((batch.B, m)); u = np.zeros((batch.B, m)); dyn = np.zeros((batch.B, batch.N - 1, 3))
         _check(lib().po_assemble_batch(self._h, C.byref(bi), _np(l), _np(u), _np(dyn)))
         return l, u, dyn
 
     def scaling_batch(self, batch):
         bi = PoBatchIn(batch.formulation, batch.B, batch.N, batch.keep, _np(batch.ref_x), _np(batch.ref_y), _np(batch.ref_z),
-                       _np(batch.ref_k), _np(batch.ref_s), _np(batch.bounds), _np(batch.x0), _np(batch.goal_z), _np(batch.max_k), _np(batch.max_kp))
+                       _np(batch.ref_k), _np(batch.ref_s), _np(batch.bounds), _np(batch.x0), _np(batch.goal_z), _np(batch.max_k), _np(batch.max_kp), _np(_i32(getattr(batch, 'n_points', None))))
         out = np.zeros((batch.B, 64))
         _check(lib().po_scaling_batch(self._h, C.byref(bi), _np(out)))
         return out
@@ -137,7 +149,7 @@ class Engine:
     # ---- device-pointer path: tensors are torch CUDA(=HIP) tensors already resident in HBM ----
     def solve_batch_device(self, dev: "DeviceBatch"):
         bi = PoBatchIn(dev.formulation, dev.B, dev.N, dev.keep, *(None if t is None else t.data_ptr() for t in
-                       (dev.ref_x, dev.ref_y, dev.ref_z, dev.ref_k, dev.ref_s, dev.bounds, dev.x0, dev.goal_z, dev.max_k, dev.max_kp)))
+                       (dev.ref_x, dev.ref_y, dev.ref_z, dev.ref_k, dev.ref_s, dev.bounds, dev.x0, dev.goal_z, dev.max_k, dev.max_kp, dev.n_points)))
         bo = PoBatchOut(dev.out_states.data_ptr(), dev.out_info.data_ptr(), None if dev.out_x is None else dev.out_x.data_ptr())
         _check(lib().po_solve_batch_device(self._h, C.byref(bi), C.byref(bo)))
 
@@ -157,6 +169,8 @@ class DeviceBatch:
         up = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(device)
         self.ref_x, self.ref_y, self.ref_z, self.ref_k, self.ref_s = map(up, (batch.ref_x, batch.ref_y, batch.ref_z, batch.ref_k, batch.ref_s))
         self.bounds, self.x0, self.goal_z, self.max_k, self.max_kp = map(up, (batch.bounds, batch.x0, batch.goal_z, batch.max_k, batch.max_kp))
+        npts = getattr(batch, 'n_points', None)
+        self.n_points = None if npts is None else torch.from_numpy(np.ascontiguousarray(npts, dtype=np.int32)).to(device)
         n, _, _ = problem_dims(batch.formulation, batch.N, batch.keep)
         self.out_states = torch.zeros((batch.B, batch.N, 5), dtype=torch.float64, device=device)
         self.out_info = torch.zeros((batch.B, 48), dtype=torch.uint8, device=device)  # sizeof(po_info) == 48

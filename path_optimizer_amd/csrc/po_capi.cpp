@@ -194,6 +194,7 @@ static void fill_dev_batch(po::DevBatch *D, const po_batch_in *in, const po_batc
     D->B = in->B; D->N = in->N; D->keep = in->keep; D->C = C;
     D->ref_x = in->ref_x; D->ref_y = in->ref_y; D->ref_z = in->ref_z; D->ref_k = in->ref_k; D->ref_s = in->ref_s;
     D->bounds = in->bounds; D->x0 = in->x0; D->goal_z = in->goal_z; D->max_k = in->max_k; D->max_kp = in->max_kp;
+    D->n_points = in->n_points;
     D->out_states = out ? out->states : nullptr;
     D->out_info = out ? out->info : nullptr;
     D->out_x = out ? out->x : nullptr;
@@ -248,7 +249,10 @@ int po_solve_batch(po_handle h, const po_batch_in *in, const po_batch_out *out) 
     const bool kpc = in->formulation == PO_KPC;
     // one staging buffer: 5 ref arrays + bounds(8) + (max_k, max_kp) per point, x0(3) + goal per path
     const size_t per_pt = 13 + (kpc ? 2 : 0);
-    const size_t in_bytes = sizeof(double) * (B * N * per_pt + B * 4);
+    if (in->n_points)
+        for (size_t b = 0; b < B; ++b)
+            if (in->n_points[b] < 2 || in->n_points[b] > in->N) return PO_ERR_INVALID;
+    const size_t in_bytes = sizeof(double) * (B * N * per_pt + B * 4 + (B + 1) / 2 + 1);
     const size_t out_bytes = sizeof(double) * (B * N * 5 + (out->x ? B * (size_t)n : 0)) + sizeof(po_info) * B;
     {
         std::lock_guard<std::mutex> g(h->mu);
@@ -268,6 +272,11 @@ int po_solve_batch(po_handle h, const po_batch_in *in, const po_batch_out *out) 
         (rc = up(in->x0, B * 3, &din.x0)) || (rc = up(in->goal_z, B, &din.goal_z)))
         return rc;
     if (kpc && ((rc = up(in->max_k, B * N, &din.max_k)) || (rc = up(in->max_kp, B * N, &din.max_kp)))) return rc;
+    if (in->n_points) {
+        int *dn = reinterpret_cast<int *>(d + o);
+        HIP_TRY(hipMemcpyAsync(dn, in->n_points, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+        din.n_points = dn;
+    }
     po_batch_out dout;
     char *ob = static_cast<char *>(h->out_buf.p);
     dout.states = reinterpret_cast<double *>(ob);
@@ -284,6 +293,7 @@ int po_solve_batch(po_handle h, const po_batch_in *in, const po_batch_out *out) 
 
 int po_assemble_batch(po_handle h, const po_batch_in *in, double *l, double *u, double *dyn) {
     if (!h || !l || !u || !dyn) return PO_ERR_INVALID;
+    if (in && in->n_points) return PO_ERR_INVALID;  // diagnostics work on uniform batches only
     int n, m, C;
     int rc = validate(in, &n, &m, &C);
     if (rc) return rc;
@@ -328,6 +338,7 @@ int po_assemble_batch(po_handle h, const po_batch_in *in, double *l, double *u, 
 
 int po_scaling_batch(po_handle h, const po_batch_in *in, double *out) {
     if (!h || !out) return PO_ERR_INVALID;
+    if (in && in->n_points) return PO_ERR_INVALID;  // diagnostics work on uniform batches only
     int n, m, C;
     int rc = validate(in, &n, &m, &C);
     if (rc) return rc;

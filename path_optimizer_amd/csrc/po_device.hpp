@@ -41,6 +41,7 @@ struct DevBatch {
     double *out_states;
     po_info *out_info;
     double *out_x;
+    const int *n_points;    // optional [B]: ragged batch (points of each path <= N); arrays keep stride N
     const double *scale;    // [B][64] per-path equilibration block (po_scale.hpp)
     long long *dbg_cycles;  // optional [B][4] per-phase shader-clock totals (dev tool), or nullptr
     int n, m;

@@ -112,9 +112,11 @@ template <int F> __global__ void scale_kernel(DevBatch in, DevParams P, int pass
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= in.B) return;
     const double *s = in.ref_s + (size_t)b * in.N;
+    int N = in.N, C = in.C;
+    if (in.n_points) { N = in.n_points[b]; N = N < 2 ? 2 : (N > in.N ? in.N : N); C = (F == F_K) ? N - 1 : (N + in.keep - 2) / in.keep; }
     double ds_nom = 0;  // solver.cpp:22-27
-    for (int i = 1; i < in.N && i < 10; ++i) ds_nom = fmax(ds_nom, __dsub_rn(s[i], s[i - 1]));
-    class_scaling<F>(P, in.N, in.keep, in.C, ds_nom, passes, sc + (size_t)b * kScStride);
+    for (int i = 1; i < N && i < 10; ++i) ds_nom = fmax(ds_nom, __dsub_rn(s[i], s[i - 1]));
+    class_scaling<F>(P, N, in.keep, C, ds_nom, passes, sc + (size_t)b * kScStride);
 }
 
 }  // namespace po

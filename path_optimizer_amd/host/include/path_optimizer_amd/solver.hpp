@@ -114,7 +114,7 @@ class OsqpSolver {
         int rc = po_problem_dims(formulation, (int)N, keep, &n, &m, &C);
         if (rc) return rc;
         po_batch_in in{formulation, (int)B, (int)N, keep, rx.data(), ry.data(), rz.data(), rk.data(), rs.data(), bd.data(), x0.data(), gz.data(),
-                       formulation == PO_KPC ? mk.data() : nullptr, formulation == PO_KPC ? mkp.data() : nullptr};
+                       formulation == PO_KPC ? mk.data() : nullptr, formulation == PO_KPC ? mkp.data() : nullptr, nullptr};
         std::vector<double> states(B * N * 5);
         info->assign(B, po_info{});
         po_batch_out out{states.data(), info->data(), nullptr};

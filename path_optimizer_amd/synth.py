@@ -42,11 +42,12 @@ class Batch:
     goal_z: np.ndarray  # [B]
     max_k: np.ndarray | None = None  # [B,N]
     max_kp: np.ndarray | None = None
+    n_points: np.ndarray | None = None  # optional [B] int32: ragged batch (paths shorter than N)
 
     def slice(self, lo: int, hi: int) -> "Batch":
         f = lambda a: None if a is None else np.ascontiguousarray(a[lo:hi])
         return Batch(self.formulation, hi - lo, self.N, self.keep, f(self.ref_x), f(self.ref_y), f(self.ref_z),
-                     f(self.ref_k), f(self.ref_s), f(self.bounds), f(self.x0), f(self.goal_z), f(self.max_k), f(self.max_kp))
+                     f(self.ref_k), f(self.ref_s), f(self.bounds), f(self.x0), f(self.goal_z), f(self.max_k), f(self.max_kp), f(self.n_points))
 
 
 CONFIGS = {

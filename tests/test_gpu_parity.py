@@ -246,3 +246,21 @@ def test_tiny_and_unsupported_sizes(binding, oracle, form, name):
     big = _rand_batch(form, 1, 1200, seed=1)
     with pytest.raises(binding.PoError, match="unsupported"):
         binding.Engine(0).solve_batch(big)
+
+
+@pytest.mark.parametrize("form,name", FORMS)
+def test_ragged_batch(binding, oracle, form, name):
+    """Paths of different lengths in one launch (po_batch_in.n_points): every path equals its own single-path solve."""
+    N = 150
+    b = _rand_batch(form, 6, N, seed=11 + form)
+    b.n_points = np.array([150, 2, 37, 149, 64, 101], dtype=np.int32)
+    st, info, xs = binding.Engine(0).solve_batch(b, want_x=True)
+    ost, oinfo, oxs = oracle.solve_batch(b, oracle.device_equivalent_params())
+    assert np.array_equal(info["status"], oinfo["status"]) and np.array_equal(info["iters"], oinfo["iters"]), (info, oinfo)
+    assert np.abs(xs - oxs).max() < 1e-6 and np.abs(st - ost).max() < 1e-6
+    for i, n in enumerate(b.n_points):
+        assert not st[i, n:].any()  # rows beyond the path's length are zero
+    bad = _rand_batch(form, 2, 20, seed=1)
+    bad.n_points = np.array([20, 21], dtype=np.int32)
+    with pytest.raises(binding.PoError):
+        binding.Engine(0).solve_batch(bad)

@@ -252,3 +252,18 @@ def test_class_level_ruiz_reproduces_osqp_ruiz(oracle):
     p0 = oracle.default_params(); p0.scaling = 0
     _, i0, _ = oracle.solve_batch(b, p0)
     assert ic["iters"].mean() < i0["iters"].mean()
+
+
+def test_ragged_batch_equals_individual_solves(oracle):
+    from path_optimizer_amd import synth as S
+
+    full = S.make_batch(2, B=3, N=60)
+    full.n_points = np.array([60, 25, 41], dtype=np.int32)
+    p = oracle.default_params()
+    st, info, xs = oracle.solve_batch(full, p)
+    for i, n in enumerate(full.n_points):
+        one = S.Batch(full.formulation, 1, int(n), full.keep, *(np.ascontiguousarray(a[i:i + 1, :n]) for a in (full.ref_x, full.ref_y, full.ref_z, full.ref_k, full.ref_s, full.bounds)),
+                      full.x0[i:i + 1].copy(), full.goal_z[i:i + 1].copy())
+        st1, info1, xs1 = oracle.solve_batch(one, p)
+        assert info1["iters"][0] == info["iters"][i]
+        assert np.array_equal(st1[0], st[i, :n]) and not st[i, n:].any()
