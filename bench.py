@@ -48,15 +48,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))  # RCCL; used for the barrier and 4 scalars only
 
     from path_optimizer_amd import binding, synth
 
@@ -137,7 +137,7 @@ def main():
             "admm": {"iters_mean": iters_sum_all / (world * B), "iters_max": iters_max, "unsolved": int(unsolved_all),
                      "path_iters_per_s": iters_sum_all * args.steps / elapsed},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic, "kernel": "po::solve_kernel<KP>", "kernel_ms": kernel_ms,
+                         "traffic": traffic, "kernel": "po::solve_kernel_fast<KP,SPL=4,NT=64,two-level>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_path_iter": b_iter,
                          "note": "algorithmic bytes / kernel time; state is LDS-resident so this is not HBM traffic"},
         }
