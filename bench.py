@@ -139,7 +139,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "kernel": "po::solve_kernel_fast<KP,SPL=4,NT=64,two-level>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_path_iter": b_iter,
-                         "note": "algorithmic bytes / kernel time; state is LDS-resident so this is not HBM traffic"},
+                         "note": "algorithmic bytes / kernel time; state is LDS-resident so this is not HBM traffic",
+                         # the bound that actually limits the kernel: fp64 VALU issue, v_fma_f64 = 8 cycles per
+                         # wave-instruction measured (tools/ubench) -> 1024 SIMDs x 2.4 GHz x 64 lanes x 2 / 8 = 39.3 TFLOP/s
+                         "secondary": {"bound": "fp64_valu", "unit": "TFLOP/s", "peak": 39.3,
+                                       "achieved": float(info["iters"].sum()) * 1.0e5 / (kernel_ms * 1e-3) / 1e12,
+                                       "note": "0.1 MFLOP per path-iteration (SURVEY.md §8a10)"}},
         }
         if world == 1 and args.cpu_sample > 0:
             from oracle import oracle_py  # CPU baseline leg only
