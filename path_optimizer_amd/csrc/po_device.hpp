@@ -216,6 +216,26 @@ template <int F> __device__ __forceinline__ Dyn<F> make_dyn(double k, double ds,
     return d;
 }
 
+// K only: the two trigonometric coefficients of a transition, computed once per path at load time
+//   tr[0] = ds / L / cos^2(atan(k L))   (coefficient on delta),   tr[1] = ds * atan(k L) / L / cos^2(...)   (rhs)
+__device__ __forceinline__ void k_trig(double k, double ds, const DevParams &P, double tr[2]) {
+    const double steer = atan(k * P.wheel_base);
+    const double cs = cos(steer);
+    const double c2 = __dmul_rn(cs, cs);
+    tr[0] = ds / P.wheel_base / c2;
+    tr[1] = __dmul_rn(ds, steer) / P.wheel_base / c2;
+}
+template <int F> __device__ __forceinline__ Dyn<F> make_dyn_tr(double k, double ds, const double tr[2], const DevParams &P) {
+    if constexpr (F == F_K) {
+        Dyn<F> d;
+        d.f[0][0] = __dmul_rn(-ds, __dmul_rn(k, k)); d.f[0][1] = 1.0; d.f[0][2] = tr[0]; d.beta[0] = 0; d.b[0] = tr[1];
+        d.f[1][0] = 1.0; d.f[1][1] = ds; d.f[1][2] = 0; d.beta[1] = 0; d.b[1] = 0;
+        return d;
+    } else {
+        return make_dyn<F>(k, ds, P);
+    }
+}
+
 // P diagonal of node component `comp` (0 e_y, 1 e_phi, 2 c) at stage j.
 template <int F> __device__ __forceinline__ double p_diag_node(int comp, int j, int N, const DevParams &P) {
     if (comp == 0) return P.w_dev;
