@@ -145,23 +145,49 @@ struct Shape { int nt, spl; bool two; };
 inline bool pick_shape(int form, int N, int C, int keep, Shape *s) {
     const bool no_u = (form == F_K);
     if (no_u) C = 0;  // K has no held controls: its N-1 steering variables live inside the nodes
-    if (no_u || (keep >= 2 && keep <= 4)) {
+    // two-level path: one chunk of `spl` stages per thread; with held controls the chunk IS the control group (spl == keep).
+    // keep 1..8 covers what the reference produces (spacing 0.15..1.0 m, path_optimizer.cpp:171-172); KPC is keep == 4 only.
+    const int keep_max = form == F_KP ? 8 : 4;
+    if (no_u || (keep >= 1 && keep <= keep_max)) {
         const int spl = no_u ? (N <= 128 ? 2 : 4) : keep;
-        for (int nt : {64, 128}) if (N <= nt * spl && C <= nt) { *s = {nt, spl, true}; return true; }
+        for (int nt : {64, 128, 256}) {
+            if (nt == 256 && spl != 1) break;
+            if (nt == 128 && spl > 4) break;
+            if (N <= nt * spl && C <= nt) { *s = {nt, spl, true}; return true; }
+        }
     }
     const int cand[5][2] = {{64, 2}, {64, 4}, {128, 4}, {256, 2}, {256, 4}};
     for (auto &c : cand)
         if (N <= c[0] * c[1] && C <= c[0]) { *s = {c[0], c[1], false}; return true; }
     return false;
 }
+inline size_t lds_of(int form, int N, int C, const Shape &s) {
+    return form == F_KP ? lds_bytes_fast<F_KP>(N, C, s.spl, s.two, s.nt) : (form == F_KPC ? lds_bytes_fast<F_KPC>(N, C, s.spl, s.two, s.nt) : lds_bytes_fast<F_K>(N, C, s.spl, s.two, s.nt));
+}
+// pick_shape, then fall back to the single-level path when the two-level tables of a long, finely chunked path
+// (prefix products: 9 * chunks * log2(chunks) doubles) exceed the 160 KB of LDS
+inline bool resolve_shape(int form, int N, int C, int keep, Shape *s) {
+    if (!pick_shape(form, N, C, keep, s)) return false;
+    if (s->two && lds_of(form, N, C, *s) > 160 * 1024) return pick_shape(form, N, C, /*keep (forces the single-level candidates)*/ 0, s);
+    return true;
+}
 template <int F> hipError_t launch_form(const DevBatch *in, const DevParams *P, hipStream_t st, size_t *lds_out) {
     Shape s;
-    if (!pick_shape(F, in->N, in->C, in->keep, &s)) return hipErrorInvalidValue;
+    if (!resolve_shape(F, in->N, in->C, in->keep, &s)) return hipErrorInvalidValue;
     const size_t lds = lds_bytes_fast<F>(in->N, in->C, s.spl, s.two, s.nt);
     if (lds_out) *lds_out = lds;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
 #define PO_L(SPL_, NT_, TWO_) return launch1(&solve_kernel_fast<F, SPL_, NT_, TWO_>, in, P, NT_, lds, st)
     if (s.two) {
+        if constexpr (F == F_KP) {
+            if (s.spl == 1 && s.nt == 64) PO_L(1, 64, true);
+            if (s.spl == 1 && s.nt == 128) PO_L(1, 128, true);
+            if (s.spl == 1) PO_L(1, 256, true);
+            if (s.spl == 5) PO_L(5, 64, true);
+            if (s.spl == 6) PO_L(6, 64, true);
+            if (s.spl == 7) PO_L(7, 64, true);
+            if (s.spl == 8) PO_L(8, 64, true);
+        }
         if (s.spl == 2 && s.nt == 64) PO_L(2, 64, true);
         if (s.spl == 2) PO_L(2, 128, true);
         if (s.spl == 3 && s.nt == 64) PO_L(3, 64, true);
@@ -205,6 +231,6 @@ extern "C" hipError_t po_launch_assemble(int form, const po::DevBatch *in, const
 extern "C" size_t po_lds_bytes(int form, int N, int C, int keep) {
     using namespace po;
     Shape s;
-    if (!pick_shape(form, N, C, keep, &s)) return (size_t)1 << 30;
-    return form == F_KP ? lds_bytes_fast<F_KP>(N, C, s.spl, s.two, s.nt) : (form == F_KPC ? lds_bytes_fast<F_KPC>(N, C, s.spl, s.two, s.nt) : lds_bytes_fast<F_K>(N, C, s.spl, s.two, s.nt));
+    if (!resolve_shape(form, N, C, keep, &s)) return (size_t)1 << 30;
+    return lds_of(form, N, C, s);
 }

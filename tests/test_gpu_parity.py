@@ -138,6 +138,34 @@ def test_keep_quirk_and_ragged_sizes(binding, oracle):
         assert np.abs(xs - oxs).max() < 1e-8, (N, ds, np.abs(xs - oxs).max())
 
 
+@pytest.mark.parametrize("keep", [1, 2, 3, 4, 5, 6, 7, 8, 9, 12])
+def test_every_keep_control_steps_value(binding, oracle, keep):
+    """keep_control_steps_ = int(1.2 / spacing) takes every value 1..8 in the reference's own pipeline (spacing 0.15..1.0 m,
+    path_optimizer.cpp:171-172); larger values through the API.  Fixed-iteration iterates, then the full run (termination,
+    adaptive rho, infeasibility certificate) against the oracle, for sizes that are / are not multiples of keep."""
+    ds = 1.2 / keep * 0.999
+    for N in (keep + 2, 41, 97 if keep == 1 else 150):
+        b = _rand_batch(T.PO_KP, 3, N, ds=ds, seed=keep * 100 + N, narrow=True)
+        b.keep = keep
+        assert binding.keep_control_steps(T.PO_KP, b.ref_s[0]) == keep
+        p = binding.default_params(); p.max_iter, p.check_every, p.adapt_every = 60, 0, 25
+        po = oracle.device_equivalent_params(); po.max_iter, po.check_every, po.adapt_every = 60, 0, 25
+        st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
+        ost, oinfo, oxs = oracle.solve_batch(b, po)
+        assert np.abs(xs - oxs).max() < 1e-8, (keep, N, np.abs(xs - oxs).max())
+        assert np.array_equal(info["n_refactor"], oinfo["n_refactor"])
+        if N > 20:  # one path gets a corridor that jumps sideways within one step: primal infeasible
+            j = N // 2
+            b.bounds[1, j, :, :] = [0.9, 1.0]
+            b.bounds[1, j + 1, :, :] = [-1.0, -0.9]
+        st, info, xs = binding.Engine(0).solve_batch(b, want_x=True)
+        ost, oinfo, oxs = oracle.solve_batch(b, oracle.device_equivalent_params())
+        assert np.array_equal(info["status"], oinfo["status"]), (keep, N, info, oinfo)
+        assert np.array_equal(info["iters"], oinfo["iters"]), (keep, N, info["iters"], oinfo["iters"])
+        ok = info["status"] == 1
+        assert np.abs(xs - oxs)[ok].max() < 1e-6
+
+
 def test_api_errors_and_empty(binding):
     eng = binding.Engine(0)
     b = _rand_batch(T.PO_KP, 2, 10)
