@@ -33,6 +33,15 @@ def algorithmic_bytes(form, N, keep, iters_sum, B):
     return 8.0 * vals * iters_sum + 8.0 * (18 * N + 8) * B, 8.0 * vals
 
 
+def _cpu_slice(arg):
+    """Worker of the all-cores CPU baseline leg (oracle, test infrastructure)."""
+    from oracle import oracle_py
+
+    batch, _ = arg
+    oracle_py.solve_batch(batch, oracle_py.device_equivalent_params(), want_x=False)
+    return batch.B
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -40,6 +49,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4096, help="paths per GPU")
     ap.add_argument("--config", type=int, default=0, help="BASELINE config id (default: 3 at N=1, 4 at N>1)")
+    ap.add_argument("--streams", type=int, default=3, help="handles/HIP streams the consecutive steps are issued on round-robin "
+                    "(independent batches: the stragglers of step k drain while step k+1 fills the CUs); 1 = strictly serial steps")
     ap.add_argument("--cpu-sample", type=int, default=768, help="paths timed on the CPU oracle (rank 0, N=1 only)")
     args = ap.parse_args()
 
@@ -67,9 +78,15 @@ def main():
     lo, hi = shard_range(world * B, world, rank)  # weak scaling: fixed work per GPU, contiguous path ids
     batch = synth.make_batch(cfg, B=hi - lo, first_path=lo)
     dbatch = binding.DeviceBatch(batch, device=dev)
-    eng = binding.Engine(local_rank)
-    stream = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream shared by torch events and the engine
-    eng.set_stream(stream.cuda_stream)
+    # S independent handles, each with its own HIP stream and its own output buffers (inputs are shared, read-only)
+    S = max(1, min(args.streams, max(args.steps, 1)))
+    engs, streams, dbs = [], [], []
+    for i in range(S):
+        e = binding.Engine(local_rank)
+        st = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream shared by torch events and the engine
+        e.set_stream(st.cuda_stream)
+        engs.append(e); streams.append(st)
+        dbs.append(dbatch if i == 0 else dbatch.clone_outputs())
 
     def barrier():
         torch.cuda.synchronize()
@@ -77,40 +94,51 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        eng.solve_batch_device(dbatch)
-    barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for e0, e1 in evs:
-        e0.record(stream)
-        eng.solve_batch_device(dbatch)
-        e1.record(stream)
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+    def run(steps, n_streams):
+        """`steps` complete solves of the batch, step k on handle k % n_streams; returns (wall seconds, per-launch ms)."""
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for k, (e0, e1) in enumerate(evs):
+            i = k % n_streams
+            e0.record(streams[i])
+            engs[i].solve_batch_device(dbs[i])
+            e1.record(streams[i])
+        barrier()
+        t1 = time.perf_counter()
+        return t1 - t0, float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    for k in range(max(args.warmup, 0)):
+        engs[k % S].solve_batch_device(dbs[k % S])
+    elapsed, kernel_ms = run(args.steps, S)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    # the same K steps strictly one after the other on one stream (reported beside the headline, not as `value`)
+    serial_elapsed, serial_kernel_ms = run(args.steps, 1) if S > 1 else (elapsed, kernel_ms)
+    if world > 1:
+        t = torch.tensor([serial_elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        serial_elapsed = float(t.item())
     info = dbatch.info_numpy()
-    stats = torch.tensor([float(info["iters"].sum()), float((info["status"] != 1).sum()), float(info["iters"].max())],
-                         dtype=torch.float64, device=dev)
+    stats = torch.tensor([float(info["iters"].sum()), float((info["status"] != 1).sum()), float(info["iters"].max()),
+                          float(info["n_refactor"].sum())], dtype=torch.float64, device=dev)
     if world > 1:
         tot = stats.clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        iters_sum_all, unsolved_all, iters_max = float(tot[0]), float(tot[1]), float(mx[2])
+        iters_sum_all, unsolved_all, iters_max, refac_all = float(tot[0]), float(tot[1]), float(mx[2]), float(tot[3])
     else:
-        iters_sum_all, unsolved_all, iters_max = float(stats[0]), float(stats[1]), float(stats[2])
+        iters_sum_all, unsolved_all, iters_max, refac_all = float(stats[0]), float(stats[1]), float(stats[2]), float(stats[3])
 
     if rank == 0:
         N, keep, form = batch.N, batch.keep, batch.formulation
         paths_per_s = world * B * args.steps / elapsed
         abytes, b_iter = algorithmic_bytes(form, N, keep, float(info["iters"].sum()), B)
-        achieved = abytes / (kernel_ms * 1e-3) / 1e9  # GB/s, this rank's kernel
+        achieved = abytes / (kernel_ms * 1e-3) / 1e9  # GB/s, this rank's kernel (per-launch duration: launches of different streams overlap)
+        serial_achieved = abytes / (serial_kernel_ms * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tfile):
@@ -133,17 +161,28 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"BASELINE config {cfg}: KP, B={B} paths/GPU x {world} GPU, N={N} points, "
                                    "per-path random obstacle clearances, OSQP defaults (scaling 10, adaptive rho every 100 it) at eps_abs=eps_rel=1e-4",
-                       "batch_per_gpu": B, "points": N, "formulation": "KP", "parallelism": f"batch-split x{world}"},
+                       "batch_per_gpu": B, "points": N, "formulation": "KP", "parallelism": f"batch-split x{world}",
+                       "streams_per_gpu": S},
+            # the same K steps issued strictly serially on one stream (every step waits for the previous step's last straggler)
+            "serial": {"value": world * B * args.steps / serial_elapsed, "ms_per_step": serial_elapsed / args.steps * 1e3,
+                       "kernel_ms": serial_kernel_ms, "roofline_achieved": serial_achieved, "roofline_frac": serial_achieved / 8000.0},
             "admm": {"iters_mean": iters_sum_all / (world * B), "iters_max": iters_max, "unsolved": int(unsolved_all),
-                     "path_iters_per_s": iters_sum_all * args.steps / elapsed},
+                     "refactorisations": int(refac_all), "path_iters_per_s": iters_sum_all * args.steps / elapsed,
+                     # distribution on rank 0's shard
+                     "iters_min": int(info["iters"].min()), "iters_median": float(np.median(info["iters"])),
+                     "iters_p95": float(np.percentile(info["iters"], 95)),
+                     "schedule": "termination check every 25 it, adaptive rho every 100 it (by iteration count), max_iter 4000"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "frac_of_measured_copy_ceiling": achieved / 6290.0,  # MI355X_MICROARCH.md: 6.29 TB/s measured copy
                          "traffic": traffic, "kernel": "po::solve_kernel_fast<KP,SPL=4,NT=64,two-level>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_path_iter": b_iter,
-                         "note": "algorithmic bytes / kernel time; state is LDS-resident so this is not HBM traffic",
+                         "note": "algorithmic bytes of one launch / that launch's duration (hipEvents on its stream); launches of the "
+                                 f"{S} streams overlap, so one launch's duration is longer than ms_per_step; the state is LDS-resident, so this is not HBM traffic",
+                         "aggregate_achieved": abytes * args.steps / elapsed / 1e9, "aggregate_frac": abytes * args.steps / elapsed / 1e9 / 8000.0,
                          # the bound that actually limits the kernel: fp64 VALU issue, v_fma_f64 = 8 cycles per
                          # wave-instruction measured (tools/ubench) -> 1024 SIMDs x 2.4 GHz x 64 lanes x 2 / 8 = 39.3 TFLOP/s
                          "secondary": {"bound": "fp64_valu", "unit": "TFLOP/s", "peak": 39.3,
-                                       "achieved": float(info["iters"].sum()) * 1.0e5 / (kernel_ms * 1e-3) / 1e12,
+                                       "achieved": float(info["iters"].sum()) * 1.0e5 * args.steps / elapsed / 1e12,
                                        "note": "0.1 MFLOP per path-iteration (SURVEY.md §8a10)"}},
         }
         if world == 1 and args.cpu_sample > 0:
@@ -159,6 +198,26 @@ def main():
                                    "sample": f"first {ns} paths of the same batch, oracle/libpo_oracle.so (OSQP-style ADMM, "
                                              f"sparse LDL', gcc -O3), {c1 - c0:.1f} s, mean iters {float(oinfo['iters'].mean()):.1f}",
                                    "host_cpus": os.cpu_count()}
+            # the same sample on every host core, one path slice per process (the reference itself is single-threaded)
+            try:
+                import multiprocessing as mp
+
+                nproc = max(1, min(os.cpu_count() or 1, 64))
+                nmt = min(B, 48 * nproc)  # ~48 paths per core
+                sample = batch.slice(0, nmt)
+                ns = nmt
+                parts = [(lo_, min(ns, lo_ + -(-ns // nproc))) for lo_ in range(0, ns, -(-ns // nproc))]
+                # spawn (not fork): the parent holds a live HIP context; workers import numpy + the oracle only
+                with mp.get_context("spawn").Pool(len(parts)) as pool:
+                    pool.map_async(_cpu_slice, [(sample.slice(a, a + 2), None) for a, _ in parts], chunksize=1).get(timeout=180)  # warm
+                    m0 = time.perf_counter()
+                    pool.map_async(_cpu_slice, [(sample.slice(a, b_), None) for a, b_ in parts], chunksize=1).get(timeout=180)
+                    m1 = time.perf_counter()
+                out["cpu_baseline_all_cores"] = {"value": ns / (m1 - m0), "unit": "paths/s", "cores": len(parts), "kind": "port",
+                                                 "sample": f"first {ns} paths of the batch split over {len(parts)} processes "
+                                                           f"(one oracle instance per host core, capped at 64), {m1 - m0:.2f} s"}
+            except Exception as e:  # never let the optional leg break the bench line
+                out["cpu_baseline_all_cores"] = {"error": repr(e)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -176,5 +176,17 @@ class DeviceBatch:
         self.out_info = torch.zeros((batch.B, 48), dtype=torch.uint8, device=device)  # sizeof(po_info) == 48
         self.out_x = torch.zeros((batch.B, n), dtype=torch.float64, device=device) if want_x else None
 
+    def clone_outputs(self):
+        """Same (shared, read-only) inputs, fresh output buffers: lets several handles solve the batch concurrently."""
+        import copy
+
+        import torch
+
+        d = copy.copy(self)
+        d.out_states = torch.zeros_like(self.out_states)
+        d.out_info = torch.zeros_like(self.out_info)
+        d.out_x = None if self.out_x is None else torch.zeros_like(self.out_x)
+        return d
+
     def info_numpy(self):
         return self.out_info.cpu().numpy().view(INFO_DTYPE).reshape(-1)

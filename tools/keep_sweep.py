@@ -1,0 +1,34 @@
+"""Throughput of the KP solve for every keep_control_steps value (arc-length spacing 1.2/keep), N=200 (keep=1: also N=100).  Dev tool (GPU box)."""
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+import np_twin as T
+from path_optimizer_amd import binding, synth
+
+eng = binding.Engine(0)
+s = torch.cuda.Stream(); eng.set_stream(s.cuda_stream)
+def rand_batch(B, N, ds, seed):
+    rng = np.random.default_rng(seed)
+    insts = [T.random_instance(rng, N, ds=ds) for _ in range(B)]
+    st = lambda k: np.ascontiguousarray(np.stack([i[k] for i in insts]))
+    return synth.Batch(0, B, N, 4, st("ref_x"), st("ref_y"), st("ref_z"), st("ref_k"), st("ref_s"), st("bounds"), st("x0"), np.array([i["goal_z"] for i in insts]))
+out = []
+for keep, N in [(1, 100), (1, 200), (2, 200), (3, 200), (4, 200), (5, 200), (6, 200), (7, 200), (8, 200), (9, 200), (12, 200)]:
+    b = rand_batch(256, N, 1.2 / keep * 0.999, keep)
+    b.keep = keep
+    b = synth.replicate(b, 4096)
+    db = binding.DeviceBatch(b)
+    eng.solve_batch_device(db); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3): eng.solve_batch_device(db)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    info = db.info_numpy()
+    it = info["iters"]
+    r = {"keep": keep, "N": N, "ms": dt * 1e3, "paths_per_s": 4096 / dt, "iters_mean": float(it.mean()), "iters_max": int(it.max()),
+         "unsolved": int((info["status"] != 1).sum()), "path_iters_per_s": float(it.sum()) / dt}
+    out.append(r)
+    print(f"keep={keep:2d} N={N}: {dt*1e3:8.2f} ms {4096/dt:9.0f} paths/s  iters mean {it.mean():.0f} max {it.max()}  unsolved {r['unsolved']}  {r['path_iters_per_s']:.3e} path-iters/s", flush=True)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/keep_sweep.json", "w"), indent=1)
