@@ -292,3 +292,22 @@ def test_ragged_batch(binding, oracle, form, name):
     bad.n_points = np.array([20, 21], dtype=np.int32)
     with pytest.raises(binding.PoError):
         binding.Engine(0).solve_batch(bad)
+
+
+@pytest.mark.parametrize("form,name", FORMS)
+def test_frozen_tight_optima_on_device(binding, oracle, form, name):
+    """The device ADMM driven to eps 1e-9 lands on the frozen KKT-certified optima (tests/golden/tight_*.npz) — a check that
+    does not go through the oracle's ADMM at all — and at eps 1e-4 its gap to them equals the oracle's."""
+    from test_oracle import _tight_batch
+
+    b, xg, ey = _tight_batch(form)
+    p = binding.default_params(); p.eps_abs = p.eps_rel = 1e-9; p.max_iter = 200000
+    st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
+    assert (info["status"] == 1).all(), info
+    assert np.abs(xs - xg).max() < 1e-6, np.abs(xs - xg).max()
+    st, info, xs = binding.Engine(0).solve_batch(b, want_x=True)
+    ost, oinfo, oxs = oracle.solve_batch(b, oracle.device_equivalent_params())
+    assert np.array_equal(info["iters"], oinfo["iters"]) and (info["status"] == 1).all()
+    rms = np.sqrt((((xs - xg)[:, ey]) ** 2).mean(axis=1))
+    orms = np.sqrt((((oxs - xg)[:, ey]) ** 2).mean(axis=1))
+    assert rms.max() < 2e-3 and np.abs(rms - orms).max() < 1e-7
