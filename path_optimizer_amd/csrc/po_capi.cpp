@@ -232,8 +232,8 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
         long long c4[16];
         HIP_TRY(hipStreamSynchronize(h->stream));
         HIP_TRY(hipMemcpy(c4, D.dbg_cycles, sizeof(c4), hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "[po] path0 cycles: rhs %lld solve %lld update %lld over %lld iterations | solve phases F1 %lld F2 %lld F3B1 %lld B2 %lld B3 %lld\n",
-                     c4[0], c4[1], c4[2], c4[3], c4[4], c4[5], c4[6], c4[7], c4[8]);
+        std::fprintf(stderr, "[po] path0 cycles: rhs %lld solve %lld update %lld over %lld iterations | solve phases F1 %lld F2 %lld F3B1 %lld B2 %lld B3 %lld | uniform row classes %lld\n",
+                     c4[0], c4[1], c4[2], c4[3], c4[4], c4[5], c4[6], c4[7], c4[8], c4[10]);
     }
     return PO_OK;
 }

@@ -333,6 +333,47 @@ struct RhsFn {
     }
 };
 
+// Specialised rhs functor of the two-level hot loop.  UNI: every lane's rows have the same class pattern, so the per-row
+// step rho~_r = W_r * {rho, rho_eq, rho_min}[class_r] is a wave-uniform number prepared once per pass (rr[]), instead of a
+// 2-bit decode + two selects per row and stage.  FIRST: compile-time version of the cold-start special case (z^0 = 0).
+template <bool UNI, bool FIRST, int NR> struct RhsFnX {
+    double g[5];
+    const double *v;
+    int stride;
+    double rho, rho_eq;
+    const double *W;
+    unsigned cls;
+    double rr[NR];
+    __device__ __forceinline__ void prepare(unsigned pat, int nrows) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) rr[r] = r < nrows ? class_rho(pat, r, W[r], rho, rho_eq) : 0.0;
+    }
+    template <int MASK> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, double l, double u) {
+        const double rw = UNI ? rr[r] : class_rho(cls, r, W[r], rho, rho_eq);
+        const double vv = v[r * stride];
+        const double t = FIRST ? -(rw * vv) : rw * (2.0 * clipd(vv, l, u) - vv);
+        const double c[5] = {c0, c1, c2, c3, c4};
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+            if (MASK >> a & 1) g[a] += t * c[a];
+    }
+};
+template <bool FIRST> struct UpdFnX {
+    double xt[5];
+    double *v;
+    int stride;
+    double alpha;
+    template <int MASK> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, double l, double u) {
+        const double c[5] = {c0, c1, c2, c3, c4};
+        double zt = 0;
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+            if (MASK >> a & 1) zt += c[a] * xt[a];
+        const double vv = v[r * stride];
+        v[r * stride] = vv + alpha * (FIRST ? zt : zt - clipd(vv, l, u));
+    }
+};
+
 // update pass: ztilde = a . xtilde ; v += alpha (ztilde - zc)
 struct UpdFn {
     double xt[5];
