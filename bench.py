@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--config", type=int, default=0, help="BASELINE config id (default: 3 at N=1, 4 at N>1)")
     ap.add_argument("--streams", type=int, default=3, help="handles/HIP streams the consecutive steps are issued on round-robin "
                     "(independent batches: the stragglers of step k drain while step k+1 fills the CUs); 1 = strictly serial steps")
+    ap.add_argument("--serial-leg", action="store_true", help="additionally time the same K steps strictly serially on one stream "
+                    "and report them under \"serial\" (off by default so that a profile of the default command sees only the timed pattern)")
     ap.add_argument("--cpu-sample", type=int, default=768, help="paths timed on the CPU oracle (rank 0, N=1 only)")
     args = ap.parse_args()
 
@@ -116,8 +118,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # the same K steps strictly one after the other on one stream (reported beside the headline, not as `value`)
-    serial_elapsed, serial_kernel_ms = run(args.steps, 1) if S > 1 else (elapsed, kernel_ms)
-    if world > 1:
+    serial_elapsed, serial_kernel_ms = run(args.steps, 1) if (S > 1 and args.serial_leg) else ((elapsed, kernel_ms) if S == 1 else (None, None))
+    if world > 1 and serial_elapsed is not None:
         t = torch.tensor([serial_elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         serial_elapsed = float(t.item())
@@ -138,7 +140,7 @@ def main():
         paths_per_s = world * B * args.steps / elapsed
         abytes, b_iter = algorithmic_bytes(form, N, keep, float(info["iters"].sum()), B)
         achieved = abytes / (kernel_ms * 1e-3) / 1e9  # GB/s, this rank's kernel (per-launch duration: launches of different streams overlap)
-        serial_achieved = abytes / (serial_kernel_ms * 1e-3) / 1e9
+        serial_achieved = None if serial_kernel_ms is None else abytes / (serial_kernel_ms * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tfile):
@@ -164,8 +166,9 @@ def main():
                        "batch_per_gpu": B, "points": N, "formulation": "KP", "parallelism": f"batch-split x{world}",
                        "streams_per_gpu": S},
             # the same K steps issued strictly serially on one stream (every step waits for the previous step's last straggler)
-            "serial": {"value": world * B * args.steps / serial_elapsed, "ms_per_step": serial_elapsed / args.steps * 1e3,
-                       "kernel_ms": serial_kernel_ms, "roofline_achieved": serial_achieved, "roofline_frac": serial_achieved / 8000.0},
+            "serial": None if serial_elapsed is None else {
+                "value": world * B * args.steps / serial_elapsed, "ms_per_step": serial_elapsed / args.steps * 1e3,
+                "kernel_ms": serial_kernel_ms, "roofline_achieved": serial_achieved, "roofline_frac": serial_achieved / 8000.0},
             "admm": {"iters_mean": iters_sum_all / (world * B), "iters_max": iters_max, "unsolved": int(unsolved_all),
                      "refactorisations": int(refac_all), "path_iters_per_s": iters_sum_all * args.steps / elapsed,
                      # distribution on rank 0's shard

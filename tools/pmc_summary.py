@@ -1,0 +1,35 @@
+"""Condense a tools/profile.sh output directory into profiles/<tag>/{kernel_stats.csv,pmc_summary.json,bench_under_rocprof.json}
+and refresh profiles/traffic_latest.json (HBM bytes per launch of the solve kernel = 2*FETCH_SIZE + WRITE_SIZE, KB units,
+gfx950 FETCH_SIZE correction per MI355X_MICROARCH.md).  Usage: python tools/pmc_summary.py gpurun_out/prof_<tag> profiles/<tag>"""
+import collections, csv, glob, json, os, shutil, sys
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+for f in glob.glob(os.path.join(src, "trace", "*kernel_stats.csv")):
+    shutil.copy(f, os.path.join(dst, "kernel_stats.csv"))
+if os.path.exists(os.path.join(src, "bench_trace.json")):
+    shutil.copy(os.path.join(src, "bench_trace.json"), os.path.join(dst, "bench_under_rocprof.json"))
+agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, set()]))
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for f in glob.glob(os.path.join(src, sub, "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0][:60]
+            a = agg[k][r["Counter_Name"]]
+            a[0] += float(r["Counter_Value"]); a[1].add(r["Dispatch_Id"])
+out = {k: {c: {"sum": v[0], "dispatches": len(v[1]), "per_dispatch": v[0] / max(len(v[1]), 1)} for c, v in d.items()} for k, d in agg.items()}
+json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+solve = next((v for k, v in out.items() if "solve_kernel" in k), None)
+if solve and "FETCH_SIZE" in solve and "WRITE_SIZE" in solve:
+    fetch = solve["FETCH_SIZE"]["per_dispatch"] * 1024.0
+    write = solve["WRITE_SIZE"]["per_dispatch"] * 1024.0
+    t = {"hbm_bytes_per_launch": 2 * fetch + write, "fetch_bytes_raw": fetch,
+         "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM section)",
+         "write_bytes": write, "write_note": "32.8 MB of outputs + register-spill scratch write-backs",
+         "source": f"{dst}/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)",
+         "compulsory_io_bytes": 4096 * 8 * (18 * 200 + 8)}
+    json.dump(t, open(os.path.join(os.path.dirname(dst.rstrip("/")), "traffic_latest.json"), "w"), indent=1)
+    print(t)
+for k, d in out.items():
+    if "solve_kernel" in k and "SQ_INSTS_VALU" in d:
+        print("VALU wave-instr per launch", d["SQ_INSTS_VALU"]["per_dispatch"], "LDS instr", d["SQ_INSTS_LDS"]["per_dispatch"],
+              "bank-conflict cycles", d["SQ_LDS_BANK_CONFLICT"]["per_dispatch"], "busy", d["SQ_BUSY_CYCLES"]["per_dispatch"])
