@@ -76,7 +76,12 @@ typedef struct po_params {
     int    check_every;                 /* check_termination 25                                    */
     int    adapt_every;                 /* adaptive-rho interval in iterations (100 = OSQP's
                                            non-profiling default 4*check_termination); 0 = off     */
-    int    reserved;
+    int    enable_collision_check;      /* FLAGS_enable_collision_check (true), post-solve step only */
+    /* vehicle footprint, read by the post-solve collision check (planning_flags.cpp:18-29) */
+    double car_width;           /* FLAGS_car_width           (2.0)  */
+    double car_length;          /* FLAGS_car_length          (4.9)  */
+    double rear_axle_to_center; /* FLAGS_rear_axle_to_center (1.45) */
+    double safety_margin;       /* FLAGS_safety_margin       (0.0): circle_radius = sqrt((L/8)^2+(W/2)^2) + safety_margin */
 } po_params;
 
 typedef struct po_info {
@@ -115,6 +120,20 @@ typedef struct po_batch_out {
     double  *x;      /* optional [B][n]: raw QP solution in the REFERENCE variable order, or NULL   */
 } po_batch_out;
 
+/* Obstacle-distance map: what the reference reads through PathOptimizationNS::Map::getObstacleDistance / isInside
+ * (src/tools/Map.cpp:16-26), i.e. layer "distance" of a grid_map::GridMap sampled with
+ * atPosition(INTER_LINEAR).  grid_map is a third-party dependency that is NOT in /root/reference (ROS package
+ * grid_map_core, un-pinned): its geometry conventions are restated in csrc/po_map.hpp / oracle/po_oracle.c:
+ * `distance` is the layer's Eigen::MatrixXf, column-major, size_x rows (along x) by size_y columns (along y);
+ * cell (0,0) is the corner of LARGEST x and y; cell (i,j) is centred at
+ *   pos + 0.5*len - (idx + 0.5)*resolution,  len = size*resolution;  the circular-buffer start index is (0,0). */
+typedef struct po_map {
+    const float *distance;  /* [size_y][size_x] in memory (column-major), metres to the nearest obstacle */
+    int    size_x, size_y;
+    double resolution;      /* metres per cell */
+    double pos_x, pos_y;    /* position of the map centre in the world frame */
+} po_map;
+
 typedef struct po_handle_s *po_handle;
 
 /* Fill `p` with the reference defaults (planning_flags.cpp) and the project's ADMM settings. */
@@ -138,6 +157,24 @@ int po_set_stream(po_handle h, void *hip_stream);
 int po_solve_batch(po_handle h, const po_batch_in *in, const po_batch_out *out);
 /* Device-pointer entry: all pointers in `in`/`out` are device pointers; asynchronous on the stream. */
 int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out *out);
+
+/* ---- post-solve step: PathOptimizer::optimizePath, src/path_optimizer/path_optimizer.cpp:183-200 ----
+ * Upload the obstacle-distance layer (host pointer in `map->distance`) to the handle's device; kept until replaced. */
+int po_set_map(po_handle h, const po_map *map);
+/* For every path: walk the optimised states in order and stop at the first state that fails
+ * CollisionChecker::isSingleStateCollisionFreeImproved (src/tools/collision_checker.cpp:42-59: bounding circle, then the
+ * six footprint circles of src/tools/car_geometry.cpp:38-72; outside the map = collision).
+ *   n_valid[b] = number of states kept (the reference erases from the colliding state on);
+ *   ok[b]      = what optimizePath returns: 0 if the QP was not solved (info[b].status != PO_STATUS_SOLVED),
+ *                1 if no state collides, else (s of the last kept state >= 20 m); 0 if the first state collides.
+ * `states`/`info` are the outputs of po_solve_batch* ([B][N][5], [B]); n_points as in po_batch_in (or NULL).
+ * With params.enable_collision_check == 0 every solved path is kept whole.  Host-pointer and device-pointer entries. */
+int po_postcheck_batch(po_handle h, int B, int N, const int *n_points, const double *states, const po_info *info,
+                       int *n_valid, int *ok);
+int po_postcheck_batch_device(po_handle h, int B, int N, const int *n_points, const double *states, const po_info *info,
+                              int *n_valid, int *ok);
+/* Test/diagnostic entry: Map::getObstacleDistance at `n` world positions xy[n][2] (host pointers); inside[n] = Map::isInside. */
+int po_map_sample(po_handle h, int n, const double *xy, double *dist, int *inside);
 
 /* Test/diagnostic entry: run only the device assembly and return the QP data in the REFERENCE
  * row order: l,u [B][m]; dyn [B][N-1][3] = per-transition data-dependent A entries

@@ -10,7 +10,7 @@ import subprocess
 
 import numpy as np
 
-from path_optimizer_amd.abi import INFO_DTYPE, PoBatchIn, PoBatchOut, PoInfo, PoParams
+from path_optimizer_amd.abi import INFO_DTYPE, PoBatchIn, PoBatchOut, PoInfo, PoMap, PoParams
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -166,3 +166,44 @@ def output_map(form, N, xsol, ref_x, ref_y, ref_z):
     xsol, ref_x, ref_y, ref_z = map(f, (xsol, ref_x, ref_y, ref_z))
     lib().po_oracle_output(form, N, _p(xsol), _p(ref_x), _p(ref_y), _p(ref_z), _p(out))
     return out
+
+
+# ---- post-solve step ----
+def make_map(dist, resolution, pos_x, pos_y) -> PoMap:
+    """po_map over a float32 array dist[size_x, size_y] (index (i, j): i along x, j along y; stored column-major like
+    grid_map's Eigen::MatrixXf, i.e. the numpy array is kept Fortran-ordered)."""
+    d = np.asfortranarray(dist, dtype=np.float32)
+    m = PoMap(d.ctypes.data_as(C.c_void_p), d.shape[0], d.shape[1], float(resolution), float(pos_x), float(pos_y))
+    m._keep = d
+    return m
+
+
+def map_distance(m: PoMap, xy):
+    L = lib()
+    L.po_oracle_map_distance.restype = C.c_double
+    L.po_oracle_map_distance.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    L.po_oracle_map_inside.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    xy = np.asarray(xy, dtype=np.float64).reshape(-1, 2)
+    d = np.array([L.po_oracle_map_distance(C.byref(m), x, y) for x, y in xy])
+    ins = np.array([L.po_oracle_map_inside(C.byref(m), x, y) for x, y in xy], dtype=np.int32)
+    return d, ins
+
+
+def collision_free(params, m: PoMap, x, y, z) -> int:
+    L = lib()
+    L.po_oracle_collision_free.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double]
+    return L.po_oracle_collision_free(C.byref(params), C.byref(m), x, y, z)
+
+
+def postcheck_batch(params, m: PoMap, states, info, n_points=None):
+    """po_oracle_postcheck per path. states [B,N,5], info structured. Returns n_valid [B], ok [B]."""
+    B, N = states.shape[0], states.shape[1]
+    nv = np.zeros(B, dtype=np.int32); ok = np.zeros(B, dtype=np.int32)
+    L = lib()
+    for b in range(B):
+        n = N if n_points is None else int(n_points[b])
+        s = np.ascontiguousarray(states[b], dtype=np.float64)
+        k = C.c_int(0)
+        ok[b] = L.po_oracle_postcheck(C.byref(params), C.byref(m), n, _p(s), int(info["status"][b]), C.byref(k))
+        nv[b] = k.value
+    return nv, ok

@@ -56,6 +56,8 @@ void po_oracle_default_params(po_params *p) {
     p->margin = 1.3; /* :116 */
     p->max_steer = 30.0 * M_PI / 180.0;
     p->wheel_base = 2.85;
+    p->enable_collision_check = 1;
+    p->car_width = 2.0; p->car_length = 4.9; p->rear_axle_to_center = 1.45; p->safety_margin = 0.0;  /* planning_flags.cpp:18-29 */
     p->constraint_end_heading = 1;
     p->scaling = 10; /* OSQP default; > 0: true Ruiz passes, < 0: class-level form (what the device runs) */
     p->eps_abs = 1e-4;
@@ -1490,4 +1492,97 @@ int po_oracle_kkt_check(int n, int m, const int *Pp, const int *Pi, const double
     res[3] = obj;
     free(t); free(t2); free(ax);
     return PO_OK;
+}
+
+
+/* =====================================================================================================
+ * Post-solve step.  In-tree logic: Map.cpp:16-26, collision_checker.cpp:17-59, car_geometry.cpp:38-72,
+ * tools.cpp:50-55, path_optimizer.cpp:183-200 — pinned against those files compiled through oracle/ref_shim
+ * (tests/test_oracle_vs_reference.py).  grid_map_core (GridMap::isInside / atPosition(INTER_LINEAR), GridMapMath.cpp) is a
+ * third-party dependency absent from /root/reference: restated from its published sources, "parity unpinned".
+ * ===================================================================================================== */
+int po_oracle_map_inside(const po_map *m, double x, double y) {
+    const double lx = m->size_x * m->resolution, ly = m->size_y * m->resolution;
+    const double tx = -((x - m->pos_x) - 0.5 * lx), ty = -((y - m->pos_y) - 0.5 * ly);
+    return tx >= 0.0 && ty >= 0.0 && tx < lx && ty < ly;
+}
+static void map_index(const po_map *m, double x, double y, int *ix, int *iy) {
+    const double lx = m->size_x * m->resolution, ly = m->size_y * m->resolution;
+    *ix = (int)(-(((x - 0.5 * lx) - m->pos_x) / m->resolution));
+    *iy = (int)(-(((y - 0.5 * ly) - m->pos_y) / m->resolution));
+}
+static int map_index_ok(const po_map *m, int ix, int iy) { return ix >= 0 && iy >= 0 && ix < m->size_x && iy < m->size_y; }
+static void map_position(const po_map *m, int ix, int iy, double *x, double *y) {
+    if (!map_index_ok(m, ix, iy)) return; /* getPositionFromIndex returns false and leaves the output untouched */
+    const double lx = m->size_x * m->resolution, ly = m->size_y * m->resolution;
+    *x = (m->pos_x + (0.5 * lx - 0.5 * m->resolution)) + m->resolution * (double)(-ix);
+    *y = (m->pos_y + (0.5 * ly - 0.5 * m->resolution)) + m->resolution * (double)(-iy);
+}
+float po_oracle_map_at_linear(const po_map *m, double x, double y) {
+    int i0x, i0y, ix[4], iy[4], sh[4], up;
+    double ptx = 0, pty = 0;
+    map_index(m, x, y, &i0x, &i0y);
+    map_position(m, i0x, i0y, &ptx, &pty);
+    ix[0] = i0x; iy[0] = i0y;
+    if (x >= ptx) { ix[1] = i0x - 1; iy[1] = i0y; up = 1; } else { ix[1] = i0x + 1; iy[1] = i0y; up = 0; }
+    if (y >= pty) {
+        ix[2] = i0x; iy[2] = i0y - 1;
+        if (up) { sh[0] = 0; sh[1] = 1; sh[2] = 2; sh[3] = 3; } else { sh[0] = 1; sh[1] = 0; sh[2] = 3; sh[3] = 2; }
+    } else {
+        ix[2] = i0x; iy[2] = i0y + 1;
+        if (up) { sh[0] = 2; sh[1] = 3; sh[2] = 0; sh[3] = 1; } else { sh[0] = 3; sh[1] = 2; sh[2] = 1; sh[3] = 0; }
+    }
+    ix[3] = ix[1]; iy[3] = iy[2];
+    const long long nbuf = (long long)m->size_x * m->size_y;
+    float f[4];
+    int ok = 1;
+    for (int i = 0; i < 4; ++i) {
+        const long long lin = (long long)iy[sh[i]] * m->size_x + ix[sh[i]];
+        if (lin < 0 || lin > nbuf) ok = 0;
+        f[i] = (lin >= 0 && lin < nbuf) ? m->distance[lin] : 0.0f;
+    }
+    if (ok) {
+        map_position(m, ix[sh[0]], iy[sh[0]], &ptx, &pty);
+        const double rx = (x - ptx) / m->resolution, ry = (y - pty) / m->resolution;
+        const double fx = 1.0 - rx, fy = 1.0 - ry;
+        const double v = f[0] * fx * fy + f[1] * rx * fy + f[2] * fx * ry + f[3] * rx * ry;
+        return (float)v;
+    }
+    return map_index_ok(m, i0x, i0y) ? m->distance[(long long)i0y * m->size_x + i0x] : 0.0f;
+}
+double po_oracle_map_distance(const po_map *m, double x, double y) {
+    return po_oracle_map_inside(m, x, y) ? (double)po_oracle_map_at_linear(m, x, y) : 0.0;
+}
+int po_oracle_collision_free(const po_params *p, const po_map *m, double x, double y, double z) {
+    /* CollisionChecker ctor (collision_checker.cpp:9-15) + CarGeometry::setCircles (car_geometry.cpp:38-56) */
+    const double width = p->car_width, back = p->car_length / 2.0 - p->rear_axle_to_center, front = p->car_length / 2.0 + p->rear_axle_to_center;
+    const double length = front + back;
+    const double bcx = (front - back) / 2.0, bcr = sqrt((length / 2) * (length / 2) + (width / 2) * (width / 2));
+    const double shift = width / 4.0, small_r = sqrt(2 * (shift * shift));
+    const double large_r = sqrt(width * width + ((length - width) / 2.0) * ((length - width) / 2.0)) / 2;
+    const double cx[6] = {-back + shift, -back + shift, front - shift, front - shift, bcx + (length - width) / 4, bcx - (length - width) / 4};
+    const double cy[6] = {-width / 2.0 + shift, width / 2.0 - shift, -width / 2.0 + shift, width / 2.0 - shift, 0, 0};
+    const double cr[6] = {small_r, small_r, small_r, small_r, large_r, large_r};
+    const double cz = cos(z), sz = sin(z);
+    const double bx = bcx * cz - 0.0 * sz + x, by = bcx * sz + 0.0 * cz + y; /* local2Global, tools.cpp:50-55 */
+    if (!po_oracle_map_inside(m, bx, by)) return 0;
+    if (!(po_oracle_map_distance(m, bx, by) < bcr)) return 1;
+    for (int k = 0; k < 6; ++k) {
+        const double gx = cx[k] * cz - cy[k] * sz + x, gy = cx[k] * sz + cy[k] * cz + y;
+        if (!po_oracle_map_inside(m, gx, gy)) return 0;
+        if (po_oracle_map_distance(m, gx, gy) < cr[k]) return 0;
+    }
+    return 1;
+}
+int po_oracle_postcheck(const po_params *p, const po_map *m, int n, const double *states, int status, int *n_valid) {
+    if (status != PO_STATUS_SOLVED) { *n_valid = 0; return 0; }          /* "QP failed." -> false (path_optimizer.cpp:183-186) */
+    for (int i = 0; i < n; ++i) {
+        /* s is the running length the output map already wrote (same recurrence, :193-195) */
+        if (p->enable_collision_check && !po_oracle_collision_free(p, m, states[5 * i], states[5 * i + 1], states[5 * i + 2])) {
+            *n_valid = i;
+            return i > 0 && states[5 * (i - 1) + 4] >= 20.0;          /* (the reference calls back() on an empty vector when i == 0) */
+        }
+    }
+    *n_valid = n;
+    return 1;
 }

@@ -92,6 +92,19 @@ int po_oracle_kkt_check(int n, int m, const int *Pp, const int *Pi, const double
                         const int *Ap, const int *Ai, const double *Ax, const double *l, const double *u,
                         const double *x, const double *y, double *res);
 
+/* ---- post-solve step ----
+ * Map::isInside / Map::getObstacleDistance (src/tools/Map.cpp:16-26) over the grid_map conventions restated in
+ * include/po_hip.h (grid_map_core itself is absent from /root/reference: that part is "parity unpinned"). */
+int    po_oracle_map_inside(const po_map *m, double x, double y);
+double po_oracle_map_distance(const po_map *m, double x, double y);
+/* grid_map::GridMap::atPosition("distance", p, INTER_LINEAR) for a position inside the map (float result) */
+float  po_oracle_map_at_linear(const po_map *m, double x, double y);
+/* CollisionChecker::isSingleStateCollisionFreeImproved (src/tools/collision_checker.cpp:42-59) */
+int    po_oracle_collision_free(const po_params *p, const po_map *m, double x, double y, double heading);
+/* the output loop of PathOptimizer::optimizePath (src/path_optimizer/path_optimizer.cpp:183-200), raw-output branch:
+ * returns ok, writes the number of states kept.  states [n][5] = x,y,heading,k,s as produced by the solve. */
+int    po_oracle_postcheck(const po_params *p, const po_map *m, int n, const double *states, int status, int *n_valid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,3 +69,27 @@ def solve(type_name: str, inst: dict, params: PoParams):
     lib().po_ref_get_qp(_p(Pp), _p(Pi), _p(Px), _p(Ap), _p(Ai), _p(Ax), _p(q), _p(l), _p(u), _p(x))
     return dict(rc=rc, states=states[:ns.value], P=sp.csc_matrix((Px, Pi, Pp), shape=(n, n)), A=sp.csc_matrix((Ax, Ai, Ap), shape=(m, n)),
                 q=q, l=l, u=u, x=x, n=n, m=m)
+
+
+# ---- post-solve step: the reference's own CollisionChecker / CarGeometry / Map / tools (ref_shim/ref_glue_post.cpp) ----
+def collision_free(m, x, y, z) -> int:
+    L = lib()
+    L.po_ref_collision_free.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+    return L.po_ref_collision_free(C.byref(m), x, y, z)
+
+
+def map_distance(m, x, y) -> float:
+    L = lib()
+    L.po_ref_map_distance.restype = C.c_double
+    L.po_ref_map_distance.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    return L.po_ref_map_distance(C.byref(m), x, y)
+
+
+def postcheck(m, states):
+    """optimizePath's raw-output tail on one solved path: returns ok, n_valid, s [n]."""
+    s = np.ascontiguousarray(states, dtype=np.float64)
+    n = s.shape[0]
+    nv = C.c_int(0)
+    so = np.zeros(n)
+    ok = lib().po_ref_postcheck(C.byref(m), n, _p(s), C.byref(nv), _p(so))
+    return ok, nv.value, so

@@ -20,8 +20,14 @@ class PoParams(C.Structure):
         ("constraint_end_heading", C.c_int), ("scaling", C.c_int),
         ("eps_abs", C.c_double), ("eps_rel", C.c_double), ("eps_prim_inf", C.c_double), ("eps_dual_inf", C.c_double),
         ("rho0", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double), ("adapt_tol", C.c_double),
-        ("max_iter", C.c_int), ("check_every", C.c_int), ("adapt_every", C.c_int), ("reserved", C.c_int),
+        ("max_iter", C.c_int), ("check_every", C.c_int), ("adapt_every", C.c_int), ("enable_collision_check", C.c_int),
+        ("car_width", C.c_double), ("car_length", C.c_double), ("rear_axle_to_center", C.c_double), ("safety_margin", C.c_double),
     ]
+
+
+class PoMap(C.Structure):
+    _fields_ = [("distance", C.c_void_p), ("size_x", C.c_int), ("size_y", C.c_int), ("resolution", C.c_double),
+                ("pos_x", C.c_double), ("pos_y", C.c_double)]
 
 
 class PoInfo(C.Structure):

@@ -153,6 +153,36 @@ class Engine:
         bo = PoBatchOut(dev.out_states.data_ptr(), dev.out_info.data_ptr(), None if dev.out_x is None else dev.out_x.data_ptr())
         _check(lib().po_solve_batch_device(self._h, C.byref(bi), C.byref(bo)))
 
+    # ---- post-solve step ----
+    def set_map(self, dist, resolution, pos_x, pos_y):
+        """Upload the obstacle-distance layer dist[size_x, size_y] (float32; kept column-major like grid_map's MatrixXf)."""
+        from .abi import PoMap
+
+        d = np.asfortranarray(dist, dtype=np.float32)
+        m = PoMap(d.ctypes.data_as(C.c_void_p), d.shape[0], d.shape[1], float(resolution), float(pos_x), float(pos_y))
+        _check(lib().po_set_map(self._h, C.byref(m)))
+
+    def postcheck_batch(self, states, info, n_points=None):
+        """Host-pointer entry: states [B,N,5], info structured array -> n_valid [B], ok [B]."""
+        states = np.ascontiguousarray(states, dtype=np.float64)
+        info = np.ascontiguousarray(info)
+        B, N = states.shape[0], states.shape[1]
+        nv = np.zeros(B, dtype=np.int32); ok = np.zeros(B, dtype=np.int32)
+        _check(lib().po_postcheck_batch(self._h, B, N, _np(_i32(n_points)), _np(states), _np(info), _np(nv), _np(ok)))
+        return nv, ok
+
+    def postcheck_batch_device(self, dev: "DeviceBatch", n_valid, ok):
+        """Device-pointer entry on the outputs of solve_batch_device; n_valid / ok are int32 torch tensors [B]."""
+        _check(lib().po_postcheck_batch_device(self._h, dev.B, dev.N, None if dev.n_points is None else C.c_void_p(dev.n_points.data_ptr()),
+                                               C.c_void_p(dev.out_states.data_ptr()), C.c_void_p(dev.out_info.data_ptr()),
+                                               C.c_void_p(n_valid.data_ptr()), C.c_void_p(ok.data_ptr())))
+
+    def map_sample(self, xy):
+        xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+        d = np.zeros(len(xy)); ins = np.zeros(len(xy), dtype=np.int32)
+        _check(lib().po_map_sample(self._h, len(xy), _np(xy), _np(d), _np(ins)))
+        return d, ins
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float()
         _check(lib().po_last_kernel_ms(self._h, C.byref(ms)))

@@ -13,11 +13,15 @@
 
 #include "../../include/po_hip.h"
 #include "po_device.hpp"
+#include "po_map.hpp"
 
 extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out);
 extern "C" hipError_t po_launch_scale(int form, const po::DevBatch *in, const po::DevParams *P, int passes, double *sc, hipStream_t st);
 extern "C" hipError_t po_launch_assemble(int form, const po::DevBatch *in, const po::DevParams *P, double *l, double *u, double *dyn, hipStream_t st);
 extern "C" size_t po_lds_bytes(int form, int N, int C, int keep);
+extern "C" hipError_t po_launch_postcheck(const po::DevMap *m, const po::DevCar *c, int B, int N, const int *n_points, const double *states,
+                                          const po_info *info, int *n_valid, int *ok, hipStream_t st);
+extern "C" hipError_t po_launch_map_sample(const po::DevMap *m, int n, const double *xy, double *dist, int *inside, hipStream_t st);
 
 namespace {
 thread_local std::string g_hip_err;
@@ -57,7 +61,8 @@ struct po_handle_s {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    DevBuf in_buf, out_buf, asm_buf, scale_buf, dbg_buf;
+    DevBuf in_buf, out_buf, asm_buf, scale_buf, dbg_buf, map_buf, post_buf;
+    po::DevMap map{};  // obstacle-distance layer (po_set_map); map.d == nullptr until set
     std::mutex mu;
 };
 
@@ -78,6 +83,8 @@ void po_default_params(po_params *p) {
     p->margin = 1.3;
     p->max_steer = 30.0 * M_PI / 180.0;
     p->wheel_base = 2.85;
+    p->enable_collision_check = 1;
+    p->car_width = 2.0; p->car_length = 4.9; p->rear_axle_to_center = 1.45; p->safety_margin = 0.0;  /* planning_flags.cpp:18-29 */
     p->constraint_end_heading = 1;
     p->scaling = 10;  // OSQP default (the reference leaves it untouched)
     p->eps_abs = 1e-4; p->eps_rel = 1e-4; p->eps_prim_inf = 1e-4; p->eps_dual_inf = 1e-4;
@@ -142,7 +149,7 @@ int po_destroy(po_handle h) {
     if (!h) return PO_ERR_INVALID;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    h->in_buf.release(); h->out_buf.release(); h->asm_buf.release(); h->scale_buf.release(); h->dbg_buf.release();
+    h->in_buf.release(); h->out_buf.release(); h->asm_buf.release(); h->scale_buf.release(); h->dbg_buf.release(); h->map_buf.release(); h->post_buf.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -366,6 +373,91 @@ int po_last_kernel_ms(po_handle h, float *ms) {
     if (!h || !ms || !h->timed) return PO_ERR_INVALID;
     HIP_TRY(hipEventSynchronize(h->ev1));
     HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return PO_OK;
+}
+
+// ---- post-solve step -------------------------------------------------------------------------------------------
+static po::DevCar make_car(const po_params &p) {
+    // CollisionChecker ctor (collision_checker.cpp:9-15) + CarGeometry::setCircles (car_geometry.cpp:38-56)
+    po::DevCar c{};
+    const double width = p.car_width, back = p.car_length / 2.0 - p.rear_axle_to_center, front = p.car_length / 2.0 + p.rear_axle_to_center;
+    const double length = front + back;
+    c.bx = (front - back) / 2.0;
+    c.br = std::sqrt((length / 2) * (length / 2) + (width / 2) * (width / 2));
+    const double shift = width / 4.0, small_r = std::sqrt(2 * (shift * shift));
+    const double large_r = std::sqrt(width * width + ((length - width) / 2.0) * ((length - width) / 2.0)) / 2;
+    const double px[4] = {-back + shift, -back + shift, front - shift, front - shift};          // rr, rl, fr, fl
+    const double py[4] = {-width / 2.0 + shift, width / 2.0 - shift, -width / 2.0 + shift, width / 2.0 - shift};
+    for (int i = 0; i < 4; ++i) { c.cx[i] = px[i]; c.cy[i] = py[i]; c.cr[i] = small_r; }
+    c.cx[4] = c.bx + (length - width) / 4; c.cy[4] = 0; c.cr[4] = large_r;  // fm
+    c.cx[5] = c.bx - (length - width) / 4; c.cy[5] = 0; c.cr[5] = large_r;  // rm
+    c.enable = p.enable_collision_check;
+    return c;
+}
+
+int po_set_map(po_handle h, const po_map *map) {
+    if (!h || !map || !map->distance || map->size_x < 1 || map->size_y < 1 || !(map->resolution > 0)) return PO_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t bytes = sizeof(float) * (size_t)map->size_x * map->size_y;
+    if (int rc = h->map_buf.ensure(bytes)) return rc;
+    HIP_TRY(hipMemcpyAsync(h->map_buf.p, map->distance, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->map = po::DevMap{static_cast<const float *>(h->map_buf.p), map->size_x, map->size_y, map->resolution, map->pos_x, map->pos_y};
+    return PO_OK;
+}
+
+int po_postcheck_batch_device(po_handle h, int B, int N, const int *n_points, const double *states, const po_info *info, int *n_valid, int *ok) {
+    if (!h || B < 0 || N < 1 || (B > 0 && (!states || !info || !n_valid || !ok))) return PO_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->map.d && h->params.enable_collision_check) return PO_ERR_INVALID;  // no map set
+    if (B == 0) return PO_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const po::DevCar car = make_car(h->params);
+    HIP_TRY(po_launch_postcheck(&h->map, &car, B, N, n_points, states, info, n_valid, ok, h->stream));
+    return PO_OK;
+}
+
+int po_postcheck_batch(po_handle h, int B, int N, const int *n_points, const double *states, const po_info *info, int *n_valid, int *ok) {
+    if (!h || B < 0 || N < 1 || (B > 0 && (!states || !info || !n_valid || !ok))) return PO_ERR_INVALID;
+    if (B == 0) return PO_OK;
+    const size_t bs = sizeof(double) * 5 * (size_t)B * N, bi = sizeof(po_info) * (size_t)B, bn = sizeof(int) * (size_t)B;
+    char *base = nullptr;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        HIP_TRY(hipSetDevice(h->device));
+        if (int rc = h->post_buf.ensure(bs + bi + 3 * bn + 64)) return rc;
+        base = static_cast<char *>(h->post_buf.p);
+        HIP_TRY(hipMemcpyAsync(base, states, bs, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(base + bs, info, bi, hipMemcpyHostToDevice, h->stream));
+        if (n_points) HIP_TRY(hipMemcpyAsync(base + bs + bi, n_points, bn, hipMemcpyHostToDevice, h->stream));
+    }
+    int *dn = reinterpret_cast<int *>(base + bs + bi);
+    const int rc = po_postcheck_batch_device(h, B, N, n_points ? dn : nullptr, reinterpret_cast<const double *>(base),
+                                             reinterpret_cast<const po_info *>(base + bs), dn + B, dn + 2 * B);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIP_TRY(hipMemcpyAsync(n_valid, dn + B, bn, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(ok, dn + 2 * B, bn, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PO_OK;
+}
+
+int po_map_sample(po_handle h, int n, const double *xy, double *dist, int *inside) {
+    if (!h || n < 0 || (n > 0 && (!xy || !dist || !inside))) return PO_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->map.d) return PO_ERR_INVALID;
+    if (n == 0) return PO_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t bx = sizeof(double) * 2 * (size_t)n, bd = sizeof(double) * (size_t)n, bi = sizeof(int) * (size_t)n;
+    if (int rc = h->post_buf.ensure(bx + bd + bi)) return rc;
+    char *base = static_cast<char *>(h->post_buf.p);
+    HIP_TRY(hipMemcpyAsync(base, xy, bx, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(po_launch_map_sample(&h->map, n, reinterpret_cast<const double *>(base), reinterpret_cast<double *>(base + bx),
+                                 reinterpret_cast<int *>(base + bx + bd), h->stream));
+    HIP_TRY(hipMemcpyAsync(dist, base + bx, bd, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(inside, base + bx + bd, bi, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     return PO_OK;
 }
 

@@ -1,0 +1,148 @@
+// po_map.hpp — obstacle-distance map sampling and the post-solve collision check, gfx950.
+//
+// Reference: PathOptimizationNS::Map::{getObstacleDistance,isInside} (src/tools/Map.cpp:16-26),
+// CollisionChecker::isSingleStateCollisionFree{,Improved} (src/tools/collision_checker.cpp:17-59),
+// CarGeometry (src/tools/car_geometry.cpp:38-72), the output loop of PathOptimizer::optimizePath
+// (src/path_optimizer/path_optimizer.cpp:183-200).
+// grid_map (ROS package grid_map_core, NOT in /root/reference, un-pinned) is restated from its published sources:
+// GridMap::isInside -> checkIfPositionWithinMap, GridMap::atPosition(INTER_LINEAR) -> atPositionLinearInterpolated with the
+// nearest-cell fallback, index/position conversions of GridMapMath.cpp.  "parity unpinned" for that part.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace po {
+
+struct DevMap {
+    const float *d;  // column-major [sy][sx]
+    int sx, sy;
+    double res, px, py;
+};
+struct DevCar {  // CollisionChecker's CarGeometry, built on the host exactly like car_geometry.cpp:38-56
+    double bx, br;            // bounding circle (local x, radius); local y = 0
+    double cx[6], cy[6], cr[6];
+    int enable;
+};
+
+#ifdef PO_MAP_DEVICE_CODE  // kernels and device functions: po_kernels.hip only (po_capi.cpp needs just the structs)
+// checkIfPositionWithinMap (GridMapMath.cpp): t = -(p - mapPos - 0.5*len); 0 <= t < len on both axes
+__device__ __forceinline__ bool map_inside(const DevMap &m, double x, double y) {
+    const double lx = m.sx * m.res, ly = m.sy * m.res;
+    const double tx = -(__dsub_rn(__dsub_rn(x, m.px), __dmul_rn(0.5, lx)));
+    const double ty = -(__dsub_rn(__dsub_rn(y, m.py), __dmul_rn(0.5, ly)));
+    return tx >= 0.0 && ty >= 0.0 && tx < lx && ty < ly;
+}
+// getIndexFromPosition: idx = (int)( -((p - 0.5*len - mapPos) / res) )   (C++ double->int conversion truncates)
+__device__ __forceinline__ void map_index(const DevMap &m, double x, double y, int &ix, int &iy) {
+    const double lx = m.sx * m.res, ly = m.sy * m.res;
+    ix = (int)(-(__dsub_rn(__dsub_rn(x, __dmul_rn(0.5, lx)), m.px) / m.res));
+    iy = (int)(-(__dsub_rn(__dsub_rn(y, __dmul_rn(0.5, ly)), m.py) / m.res));
+}
+__device__ __forceinline__ bool map_index_ok(const DevMap &m, int ix, int iy) { return ix >= 0 && iy >= 0 && ix < m.sx && iy < m.sy; }
+// getPositionFromIndex: p = (mapPos + (0.5*len - 0.5*res)) + res * (-idx); leaves p untouched when idx is out of range
+__device__ __forceinline__ void map_position(const DevMap &m, int ix, int iy, double &x, double &y) {
+    if (!map_index_ok(m, ix, iy)) return;
+    const double lx = m.sx * m.res, ly = m.sy * m.res;
+    x = __dadd_rn(__dadd_rn(m.px, __dsub_rn(__dmul_rn(0.5, lx), __dmul_rn(0.5, m.res))), __dmul_rn(m.res, (double)(-ix)));
+    y = __dadd_rn(__dadd_rn(m.py, __dsub_rn(__dmul_rn(0.5, ly), __dmul_rn(0.5, m.res))), __dmul_rn(m.res, (double)(-iy)));
+}
+// GridMap::atPosition(layer, p, INTER_LINEAR) for a position that isInside (the only way the reference calls it)
+__device__ __forceinline__ double map_at_linear(const DevMap &m, double x, double y) {
+    int i0x, i0y;
+    map_index(m, x, y, i0x, i0y);
+    double ptx = 0, pty = 0;
+    map_position(m, i0x, i0y, ptx, pty);
+    int ix[4], iy[4], sh[4];
+    ix[0] = i0x; iy[0] = i0y;
+    bool up;
+    if (x >= ptx) { ix[1] = i0x - 1; iy[1] = i0y; up = true; } else { ix[1] = i0x + 1; iy[1] = i0y; up = false; }
+    if (y >= pty) {
+        ix[2] = i0x; iy[2] = i0y - 1;
+        if (up) { sh[0] = 0; sh[1] = 1; sh[2] = 2; sh[3] = 3; } else { sh[0] = 1; sh[1] = 0; sh[2] = 3; sh[3] = 2; }
+    } else {
+        ix[2] = i0x; iy[2] = i0y + 1;
+        if (up) { sh[0] = 2; sh[1] = 3; sh[2] = 0; sh[3] = 1; } else { sh[0] = 3; sh[1] = 2; sh[2] = 1; sh[3] = 0; }
+    }
+    ix[3] = ix[1]; iy[3] = iy[2];
+    const long long nbuf = (long long)m.sx * m.sy;
+    float f[4];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int jx = 0, jy = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (sh[i] == k) { jx = ix[k]; jy = iy[k]; }
+        // the library tests the LINEAR index (size_t) against [0, size]: a row index of -1 wraps into the previous column
+        const long long lin = (long long)jy * m.sx + jx;
+        if (lin < 0 || lin > nbuf) ok = false;
+        f[i] = (lin >= 0 && lin < nbuf) ? m.d[lin] : 0.0f;  // (lin == size would read one past the buffer in the library)
+    }
+    if (ok) {
+        int jx = 0, jy = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (sh[0] == k) { jx = ix[k]; jy = iy[k]; }
+        map_position(m, jx, jy, ptx, pty);
+        const double rx = __dsub_rn(x, ptx) / m.res, ry = __dsub_rn(y, pty) / m.res;
+        const double fx = __dsub_rn(1.0, rx), fy = __dsub_rn(1.0, ry);
+        double v = __dmul_rn(__dmul_rn((double)f[0], fx), fy);
+        v = __dadd_rn(v, __dmul_rn(__dmul_rn((double)f[1], rx), fy));
+        v = __dadd_rn(v, __dmul_rn(__dmul_rn((double)f[2], fx), ry));
+        v = __dadd_rn(v, __dmul_rn(__dmul_rn((double)f[3], rx), ry));
+        return (double)(float)v;  // the library returns float
+    }
+    // INTER_NEAREST fallback
+    return map_index_ok(m, i0x, i0y) ? (double)m.d[(long long)i0y * m.sx + i0x] : 0.0;
+}
+// Map::getObstacleDistance (Map.cpp:16-22)
+__device__ __forceinline__ double map_distance(const DevMap &m, double x, double y) { return map_inside(m, x, y) ? map_at_linear(m, x, y) : 0.0; }
+
+// CollisionChecker::isSingleStateCollisionFreeImproved (collision_checker.cpp:42-59)
+__device__ __forceinline__ bool collision_free(const DevMap &m, const DevCar &c, double x, double y, double z) {
+    const double cz = cos(z), sz = sin(z);
+    // local2Global (tools.cpp:50-55): x = tx cos - ty sin + rx ; y = tx sin + ty cos + ry
+    const double bx = __dadd_rn(__dsub_rn(__dmul_rn(c.bx, cz), __dmul_rn(0.0, sz)), x);
+    const double by = __dadd_rn(__dadd_rn(__dmul_rn(c.bx, sz), __dmul_rn(0.0, cz)), y);
+    if (!map_inside(m, bx, by)) return false;
+    if (!(map_at_linear(m, bx, by) < c.br)) return true;
+#pragma unroll 1
+    for (int k = 0; k < 6; ++k) {
+        const double gx = __dadd_rn(__dsub_rn(__dmul_rn(c.cx[k], cz), __dmul_rn(c.cy[k], sz)), x);
+        const double gy = __dadd_rn(__dadd_rn(__dmul_rn(c.cx[k], sz), __dmul_rn(c.cy[k], cz)), y);
+        if (!map_inside(m, gx, gy)) return false;
+        if (map_at_linear(m, gx, gy) < c.cr[k]) return false;
+    }
+    return true;
+}
+
+// One block per path: first colliding state, then optimizePath's return value (path_optimizer.cpp:183-200).
+__global__ __launch_bounds__(128) void postcheck_kernel(DevMap m, DevCar c, int B, int N, const int *n_points, const double *states,
+                                                        const po_info *info, int *n_valid, int *ok) {
+    const int b = blockIdx.x;
+    __shared__ int first;
+    int n = n_points ? n_points[b] : N;
+    n = n < 0 ? 0 : (n > N ? N : n);
+    if (threadIdx.x == 0) first = n;
+    __syncthreads();
+    const bool solved = info[b].status == PO_STATUS_SOLVED;
+    if (solved && c.enable) {
+        const double *s = states + (size_t)b * N * 5;
+        for (int i = threadIdx.x; i < n; i += blockDim.x)
+            if (!collision_free(m, c, s[5 * i], s[5 * i + 1], s[5 * i + 2])) atomicMin(&first, i);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (!solved) { n_valid[b] = 0; ok[b] = 0; }
+        else if (first >= n) { n_valid[b] = n; ok[b] = 1; }
+        else { n_valid[b] = first; ok[b] = (first > 0 && states[((size_t)b * N + first - 1) * 5 + 4] >= 20.0) ? 1 : 0; }
+    }
+}
+
+__global__ void map_sample_kernel(DevMap m, int n, const double *xy, double *dist, int *inside) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    dist[i] = map_distance(m, xy[2 * i], xy[2 * i + 1]);
+    inside[i] = map_inside(m, xy[2 * i], xy[2 * i + 1]) ? 1 : 0;
+}
+
+#endif  // PO_MAP_DEVICE_CODE
+
+}  // namespace po

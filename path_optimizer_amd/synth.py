@@ -146,3 +146,22 @@ def replicate(batch: Batch, B: int) -> Batch:
     f = lambda a: None if a is None else np.ascontiguousarray(np.concatenate([a] * reps, axis=0)[:B])
     return Batch(batch.formulation, B, batch.N, batch.keep, f(batch.ref_x), f(batch.ref_y), f(batch.ref_z), f(batch.ref_k),
                  f(batch.ref_s), f(batch.bounds), f(batch.x0), f(batch.goal_z), f(batch.max_k), f(batch.max_kp))
+
+
+def make_distance_map(seed: int, size_x: int = 400, size_y: int = 300, resolution: float = 0.2, pos=(10.0, -5.0), n_obstacles: int = 25,
+                      r_range=(0.5, 2.5)):
+    """Synthetic obstacle-distance layer (stand-in for cv::distanceTransform * resolution of the benchmark's PNG,
+    /root/reference/src/test/path_optimizer_benchmark.cpp:28-44): distance from each cell centre to the nearest of
+    `n_obstacles` random discs (0 inside a disc), float32 [size_x, size_y] in grid_map's index convention
+    (cell (0,0) at the largest x and y).  Returns dist, resolution, pos_x, pos_y, discs [n,3] (x, y, r)."""
+    rng = np.random.default_rng(np.random.SeedSequence([SEED0, 77, seed]))
+    lx, ly = size_x * resolution, size_y * resolution
+    cx = pos[0] + 0.5 * lx - (np.arange(size_x) + 0.5) * resolution
+    cy = pos[1] + 0.5 * ly - (np.arange(size_y) + 0.5) * resolution
+    discs = np.stack([rng.uniform(pos[0] - 0.5 * lx, pos[0] + 0.5 * lx, n_obstacles), rng.uniform(pos[1] - 0.5 * ly, pos[1] + 0.5 * ly, n_obstacles),
+                      rng.uniform(r_range[0], r_range[1], n_obstacles)], axis=1)
+    X, Y = np.meshgrid(cx, cy, indexing="ij")
+    d = np.full((size_x, size_y), np.inf)
+    for ox, oy, r in discs:
+        d = np.minimum(d, np.hypot(X - ox, Y - oy) - r)
+    return np.maximum(d, 0.0).astype(np.float32), resolution, pos[0], pos[1], discs
