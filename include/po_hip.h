@@ -173,6 +173,24 @@ int po_postcheck_batch(po_handle h, int B, int N, const int *n_points, const dou
                        int *n_valid, int *ok);
 int po_postcheck_batch_device(po_handle h, int B, int N, const int *n_points, const double *states, const po_info *info,
                               int *n_valid, int *ok);
+/* ---- corridor-bounds producer: ReferencePath::updateBounds -> ReferencePathImpl::updateBoundsImproved,
+ * src/data_struct/reference_path_impl.cpp:142-201 (+ getApproxState :121-140, getClearanceWithDirectionStrict :283-472 with
+ * FLAGS_enable_simple_boundary_decision = true as shipped, tk::spline src/tools/spline.cpp).  Needs po_set_map.
+ * Inputs per path: the N reference states (x, y, heading, s) and the K knots (s, x, y) the path's x(s) / y(s) splines were set
+ * from (tk::spline::set_points, natural boundary conditions — what ReferencePath::setSpline receives).
+ * Outputs: bounds [B][N][4][2] = (lb, ub) of the four covering circles, directly consumable as po_batch_in.bounds, and
+ * n_valid[b] = number of states kept (the reference stops at the first blocked state and truncates the reference there);
+ * rows >= n_valid[b] are zero.  n_valid is directly consumable as po_batch_in.n_points (when >= 2). */
+typedef struct po_bounds_in {
+    int B, N, K;                                   /* paths, reference states per path (stride), knots per path (stride) */
+    const double *ref_x, *ref_y, *ref_z, *ref_s;   /* [B][N] */
+    const int    *n_points;                        /* optional [B]: states of each path (<= N) */
+    const double *knot_s, *knot_x, *knot_y;        /* [B][K], knot_s strictly increasing */
+    const int    *n_knots;                         /* optional [B]: knots of each path (3 <= n_knots[b] <= K) */
+} po_bounds_in;
+int po_bounds_batch(po_handle h, const po_bounds_in *in, double *bounds, int *n_valid);        /* host pointers, synchronous  */
+int po_bounds_batch_device(po_handle h, const po_bounds_in *in, double *bounds, int *n_valid); /* device pointers, on the stream */
+
 /* Test/diagnostic entry: Map::getObstacleDistance at `n` world positions xy[n][2] (host pointers); inside[n] = Map::isInside. */
 int po_map_sample(po_handle h, int n, const double *xy, double *dist, int *inside);
 

@@ -207,3 +207,24 @@ def postcheck_batch(params, m: PoMap, states, info, n_points=None):
         ok[b] = L.po_oracle_postcheck(C.byref(params), C.byref(m), n, _p(s), int(info["status"][b]), C.byref(k))
         nv[b] = k.value
     return nv, ok
+
+
+# ---- corridor-bounds producer ----
+def spline_eval(ks, kv, at):
+    L = lib()
+    L.po_oracle_spline_eval.restype = C.c_double
+    ks = np.ascontiguousarray(ks, np.float64); kv = np.ascontiguousarray(kv, np.float64)
+    K = len(ks)
+    a = np.zeros(K); b = np.zeros(K); c = np.zeros(K)
+    L.po_oracle_spline_fit(K, _p(ks), _p(kv), _p(a), _p(b), _p(c))
+    return np.array([L.po_oracle_spline_eval(K, _p(ks), _p(kv), _p(a), _p(b), _p(c), C.c_double(float(t))) for t in np.atleast_1d(at)])
+
+
+def bounds_path(params, m: PoMap, ref_x, ref_y, ref_z, ref_s, ks, kx, ky):
+    """updateBoundsImproved for one path. Returns bounds [N,4,2] (lb, ub; rows >= n_valid are zero), n_valid."""
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    ref_x, ref_y, ref_z, ref_s, ks, kx, ky = map(f, (ref_x, ref_y, ref_z, ref_s, ks, kx, ky))
+    N = len(ref_x)
+    out = np.zeros((N, 4, 2))
+    n = lib().po_oracle_bounds_path(C.byref(params), C.byref(m), N, _p(ref_x), _p(ref_y), _p(ref_z), _p(ref_s), len(ks), _p(ks), _p(kx), _p(ky), _p(out))
+    return out, n

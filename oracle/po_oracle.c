@@ -1586,3 +1586,132 @@ int po_oracle_postcheck(const po_params *p, const po_map *m, int n, const double
     *n_valid = n;
     return 1;
 }
+
+
+/* =====================================================================================================
+ * Corridor-bounds producer.  In-tree logic pinned against reference_path_impl.cpp / spline.cpp / tools.cpp
+ * compiled through oracle/ref_shim (oracle/_ref/libpo_ref_bounds.so, tests/test_bounds.py).
+ * ===================================================================================================== */
+void po_oracle_spline_fit(int K, const double *x, const double *y, double *a, double *b, double *c) {
+    /* set_points (spline.cpp:168-250): tridiagonal system for b[], rows normalised to a unit diagonal, LU without pivoting
+     * (band_matrix::lu_decompose, :70-101), then l_solve / r_solve (:103-130).  Scratch: lo, di, up, sd, rhs in the outputs. */
+    double *lo = a, *up = c; /* reuse: a <- lower band, c <- upper band until the solve is done */
+    double *di = (double *)malloc(sizeof(double) * (size_t)K * 3), *sd = di + K, *rh = di + 2 * K;
+    for (int i = 1; i < K - 1; ++i) {
+        lo[i] = 1.0 / 3.0 * (x[i] - x[i - 1]);
+        di[i] = 2.0 / 3.0 * (x[i + 1] - x[i - 1]);
+        up[i] = 1.0 / 3.0 * (x[i + 1] - x[i]);
+        rh[i] = (y[i + 1] - y[i]) / (x[i + 1] - x[i]) - (y[i] - y[i - 1]) / (x[i] - x[i - 1]);
+    }
+    di[0] = 2.0; up[0] = 0.0; rh[0] = 0.0; lo[0] = 0.0;
+    di[K - 1] = 2.0; lo[K - 1] = 0.0; rh[K - 1] = 0.0; up[K - 1] = 0.0;
+    for (int i = 0; i < K; ++i) { /* preconditioning */
+        sd[i] = 1.0 / di[i];
+        if (i > 0) lo[i] *= sd[i];
+        if (i < K - 1) up[i] *= sd[i];
+        di[i] = 1.0;
+    }
+    for (int k = 0; k + 1 < K; ++k) { /* Gauss */
+        const double xx = -lo[k + 1] / di[k];
+        lo[k + 1] = -xx;
+        di[k + 1] = di[k + 1] + xx * up[k];
+    }
+    for (int i = 0; i < K; ++i) rh[i] = (rh[i] * sd[i]) - (i > 0 ? lo[i] * rh[i - 1] : 0.0);           /* l_solve (in place) */
+    for (int i = K - 1; i >= 0; --i) b[i] = (rh[i] - (i < K - 1 ? up[i] * b[i + 1] : 0.0)) / di[i];  /* r_solve */
+    for (int i = 0; i < K - 1; ++i) {
+        a[i] = 1.0 / 3.0 * (b[i + 1] - b[i]) / (x[i + 1] - x[i]);
+        c[i] = (y[i + 1] - y[i]) / (x[i + 1] - x[i]) - 1.0 / 3.0 * (2.0 * b[i] + b[i + 1]) * (x[i + 1] - x[i]);
+    }
+    const double h = x[K - 1] - x[K - 2];
+    a[K - 1] = 0.0;
+    c[K - 1] = 3.0 * a[K - 2] * h * h + 2.0 * b[K - 2] * h + c[K - 2];
+    free(di);
+}
+double po_oracle_spline_eval(int K, const double *x, const double *y, const double *a, const double *b, const double *c, double at) {
+    /* operator() (spline.cpp:251-271): idx = max(lower_bound(x, at) - 1, 0) */
+    int lo = 0, hi = K;
+    while (lo < hi) { const int mid = (lo + hi) / 2; if (x[mid] < at) lo = mid + 1; else hi = mid; }
+    const int idx = lo - 1 > 0 ? lo - 1 : 0;
+    const double h = at - x[idx];
+    if (at < x[0]) return (b[0] * h + c[0]) * h + y[0];
+    if (at > x[K - 1]) return (b[K - 1] * h + c[K - 1]) * h + y[K - 1];
+    return ((a[idx] * h + b[idx]) * h + c[idx]) * h + y[idx];
+}
+/* getClearanceWithDirectionStrict (reference_path_impl.cpp:283-472), out[0] = left bound, out[1] = right bound */
+static void clearance_strict(const po_map *m, double radius, double sx, double sy, double sz, double out[2]) {
+    double left_bound = 0, right_bound = 0;
+    const double delta_s = 0.5;
+    const double la = po_oracle_wrap_angle(sz + M_PI_2), ra = po_oracle_wrap_angle(sz - M_PI_2);
+    const int n = (int)(5.0 / delta_s);
+    const double cl = cos(la), sl = sin(la), cr = cos(ra), sr = sin(ra);
+    if (po_oracle_map_distance(m, sx, sy) > radius) { /* normal case */
+        double right_s = 0, left_s = 0;
+        for (int j = 0; j != n; ++j) { right_s += delta_s; if (po_oracle_map_distance(m, sx + right_s * cr, sy + right_s * sr) < radius) break; }
+        for (int j = 0; j != n; ++j) { left_s += delta_s; if (po_oracle_map_distance(m, sx + left_s * cl, sy + left_s * sl) < radius) break; }
+        right_bound = -(right_s - delta_s);
+        left_bound = left_s - delta_s;
+    } else { /* in collision already: expand both ways until free, pick the nearer side (:383-440) */
+        double right_s = 0, left_s = 0;
+        for (int j = 0; j != n; ++j) { right_s += delta_s; if (po_oracle_map_distance(m, sx + right_s * cr, sy + right_s * sr) > radius) break; }
+        for (int j = 0; j != n; ++j) { left_s += delta_s; if (po_oracle_map_distance(m, sx + left_s * cl, sy + left_s * sl) > radius) break; }
+        if (left_s < right_s) {
+            right_bound = left_s;
+            for (int j = 0; j != n; ++j) { left_s += delta_s; if (po_oracle_map_distance(m, sx + left_s * cl, sy + left_s * sl) < radius) break; }
+            left_bound = left_s - delta_s;
+        } else {
+            left_bound = -right_s;
+            for (int j = 0; j != n; ++j) { right_s += delta_s; if (po_oracle_map_distance(m, sx + right_s * cr, sy + right_s * sr) < radius) break; }
+            right_bound = -(right_s - delta_s);
+        }
+    }
+    const double smaller_ds = 0.1;
+    const int nf = (int)(delta_s / smaller_ds);
+    for (int i = 1; i != nf; ++i) {
+        left_bound += smaller_ds;
+        if (po_oracle_map_distance(m, sx + left_bound * cl, sy + left_bound * sl) < radius) { left_bound -= smaller_ds; break; }
+    }
+    for (int i = 1; i != nf; ++i) {
+        right_bound -= smaller_ds;
+        if (po_oracle_map_distance(m, sx + right_bound * cr, sy + right_bound * sr) < radius) { right_bound += smaller_ds; break; }
+    }
+    out[0] = left_bound; out[1] = right_bound;
+}
+int po_oracle_bounds_path(const po_params *p, const po_map *m, int N, const double *ref_x, const double *ref_y, const double *ref_z,
+                          const double *ref_s, int K, const double *ks, const double *kx, const double *ky, double *bounds) {
+    double *co = (double *)malloc(sizeof(double) * (size_t)K * 6);
+    double *xa = co, *xb = co + K, *xc = co + 2 * K, *ya = co + 3 * K, *yb = co + 4 * K, *yc = co + 5 * K;
+    po_oracle_spline_fit(K, ks, kx, xa, xb, xc);
+    po_oracle_spline_fit(K, ks, ky, ya, yb, yc);
+    /* FLAGS_circle_radius as updateConfig() computes it (planning_flags.cpp:9) */
+    const double radius = sqrt((p->car_length / 8) * (p->car_length / 8) + (p->car_width / 2) * (p->car_width / 2)) + p->safety_margin;
+    int kept = 0;
+    for (int i = 0; i < N; ++i) {
+        const double cz = cos(ref_z[i]), sz = sin(ref_z[i]);
+        double cl[4][2];
+        int blocked = 0;
+        for (int j = 0; j < 4; ++j) {
+            const double len = p->d[j];
+            const double cx = ref_x[i] + len * cz, cy = ref_y[i] + len * sz;            /* circle centre on the tangent (:150-161) */
+            /* getApproxState (:121-140) */
+            const double px = po_oracle_spline_eval(K, ks, kx, xa, xb, xc, ref_s[i] + len), py = po_oracle_spline_eval(K, ks, ky, ya, yb, yc, ref_s[i] + len);
+            const double v1x = cx - ref_x[i], v1y = cy - ref_y[i], v2x = px - ref_x[i], v2y = py - ref_y[i];
+            const double nrm = sqrt(v1x * v1x + v1y * v1y);
+            const double proj = (v1x * v2x + v1y * v2y) / (0.001 > nrm ? 0.001 : nrm);
+            const double move = fabs(len) - proj;
+            const int sign = len >= 0 ? 1 : -1;
+            const double ax = px + sign * move * cz, ay = py + sign * move * sz;
+            double c2[2];
+            clearance_strict(m, radius, ax, ay, ref_z[i], c2);
+            /* offset = global2Local(c_j, c_jj).y (tools.cpp:57-64) */
+            const double dx = ax - cx, dy = ay - cy;
+            const double off = -dx * sz + dy * cz;
+            cl[j][0] = c2[0] + off; cl[j][1] = c2[1] + off;
+            if (fabs(cl[j][0] - cl[j][1]) < 1e-6) blocked = 1;                        /* isEqual, FLAGS_epsilon (tools.cpp:28-30) */
+        }
+        if (blocked) break;
+        for (int j = 0; j < 4; ++j) { bounds[(i * 4 + j) * 2] = cl[j][1]; bounds[(i * 4 + j) * 2 + 1] = cl[j][0]; }
+        ++kept;
+    }
+    free(co);
+    return kept;
+}

@@ -105,6 +105,16 @@ int    po_oracle_collision_free(const po_params *p, const po_map *m, double x, d
  * returns ok, writes the number of states kept.  states [n][5] = x,y,heading,k,s as produced by the solve. */
 int    po_oracle_postcheck(const po_params *p, const po_map *m, int n, const double *states, int status, int *n_valid);
 
+/* ---- corridor-bounds producer ----
+ * tk::spline (src/tools/spline.cpp:154-271, natural boundary conditions): coefficients a,b,c [K] from knots (ks, kv). */
+void   po_oracle_spline_fit(int K, const double *ks, const double *kv, double *a, double *b, double *c);
+double po_oracle_spline_eval(int K, const double *ks, const double *kv, const double *a, const double *b, const double *c, double at);
+/* ReferencePathImpl::updateBoundsImproved (src/data_struct/reference_path_impl.cpp:142-201) with getApproxState (:121-140) and
+ * getClearanceWithDirectionStrict (:283-472, FLAGS_enable_simple_boundary_decision = true as shipped) for one path.
+ * bounds [N][4][2] = (lb, ub) of circles c0..c3; returns the number of states kept (the loop stops at the first blocked one). */
+int    po_oracle_bounds_path(const po_params *p, const po_map *m, int N, const double *ref_x, const double *ref_y, const double *ref_z,
+                             const double *ref_s, int K, const double *ks, const double *kx, const double *ky, double *bounds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,7 @@ from path_optimizer_amd.abi import PoParams
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_ref", "libpo_ref.so")
 _LIB = None
+_LIBB = None
 NAMES = {0: "KP", 1: "KPC", 2: "K"}
 
 
@@ -93,3 +94,28 @@ def postcheck(m, states):
     so = np.zeros(n)
     ok = lib().po_ref_postcheck(C.byref(m), n, _p(s), C.byref(nv), _p(so))
     return ok, nv.value, so
+
+
+# ---- corridor-bounds producer: the reference's real ReferencePathImpl (ref_shim/ref_glue_bounds.cpp, own library) ----
+def lib_bounds():
+    global _LIBB
+    if _LIBB is None:
+        lib()
+        _LIBB = C.CDLL(os.path.join(_HERE, "_ref", "libpo_ref_bounds.so"))
+    return _LIBB
+
+
+def spline_eval(ks, kv, at):
+    ks = np.ascontiguousarray(ks, np.float64); kv = np.ascontiguousarray(kv, np.float64); at = np.ascontiguousarray(np.atleast_1d(at), np.float64)
+    out = np.zeros(len(at))
+    lib_bounds().po_ref_spline_eval(len(ks), _p(ks), _p(kv), len(at), _p(at), _p(out))
+    return out
+
+
+def bounds_path(m, ref_x, ref_y, ref_z, ref_s, ks, kx, ky):
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    ref_x, ref_y, ref_z, ref_s, ks, kx, ky = map(f, (ref_x, ref_y, ref_z, ref_s, ks, kx, ky))
+    N = len(ref_x)
+    out = np.zeros((N, 4, 2))
+    n = lib_bounds().po_ref_bounds_path(C.byref(m), N, _p(ref_x), _p(ref_y), _p(ref_z), _p(ref_s), len(ks), _p(ks), _p(kx), _p(ky), _p(out))
+    return out, n

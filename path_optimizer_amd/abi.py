@@ -48,3 +48,9 @@ class PoBatchOut(C.Structure):
 
 INFO_DTYPE = [("status", "<i4"), ("iters", "<i4"), ("n_refactor", "<i4"), ("reserved", "<i4"),
               ("r_prim", "<f8"), ("r_dual", "<f8"), ("rho", "<f8"), ("obj", "<f8")]
+
+
+class PoBoundsIn(C.Structure):
+    _fields_ = [("B", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("ref_x", C.c_void_p), ("ref_y", C.c_void_p), ("ref_z", C.c_void_p), ("ref_s", C.c_void_p), ("n_points", C.c_void_p),
+                ("knot_s", C.c_void_p), ("knot_x", C.c_void_p), ("knot_y", C.c_void_p), ("n_knots", C.c_void_p)]

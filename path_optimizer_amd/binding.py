@@ -177,6 +177,32 @@ class Engine:
                                                C.c_void_p(dev.out_states.data_ptr()), C.c_void_p(dev.out_info.data_ptr()),
                                                C.c_void_p(n_valid.data_ptr()), C.c_void_p(ok.data_ptr())))
 
+    # ---- corridor-bounds producer ----
+    def bounds_batch(self, paths: dict, n_points=None, n_knots=None):
+        """Host-pointer entry. paths: dict of [B,N] ref_x/ref_y/ref_z/ref_s and [B,K] knot_s/knot_x/knot_y (synth.make_spline_paths).
+        Returns bounds [B,N,4,2] (lb, ub), n_valid [B]."""
+        from .abi import PoBoundsIn
+
+        f = lambda k: np.ascontiguousarray(paths[k], dtype=np.float64)
+        arr = {k: f(k) for k in ("ref_x", "ref_y", "ref_z", "ref_s", "knot_s", "knot_x", "knot_y")}
+        B, N = arr["ref_x"].shape
+        K = arr["knot_s"].shape[1]
+        bi = PoBoundsIn(B, N, K, _np(arr["ref_x"]), _np(arr["ref_y"]), _np(arr["ref_z"]), _np(arr["ref_s"]), _np(_i32(n_points)),
+                        _np(arr["knot_s"]), _np(arr["knot_x"]), _np(arr["knot_y"]), _np(_i32(n_knots)))
+        bounds = np.zeros((B, N, 4, 2)); nv = np.zeros(B, dtype=np.int32)
+        _check(lib().po_bounds_batch(self._h, C.byref(bi), _np(bounds), _np(nv)))
+        return bounds, nv
+
+    def bounds_batch_device(self, t: dict, bounds, n_valid):
+        """Device-pointer entry: t holds torch tensors (same keys as bounds_batch), bounds [B,N,4,2] f64 and n_valid [B] i32 are outputs."""
+        from .abi import PoBoundsIn
+
+        B, N = t["ref_x"].shape
+        K = t["knot_s"].shape[1]
+        p = lambda k: None if t.get(k) is None else C.c_void_p(t[k].data_ptr())
+        bi = PoBoundsIn(B, N, K, p("ref_x"), p("ref_y"), p("ref_z"), p("ref_s"), p("n_points"), p("knot_s"), p("knot_x"), p("knot_y"), p("n_knots"))
+        _check(lib().po_bounds_batch_device(self._h, C.byref(bi), C.c_void_p(bounds.data_ptr()), C.c_void_p(n_valid.data_ptr())))
+
     def map_sample(self, xy):
         xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
         d = np.zeros(len(xy)); ins = np.zeros(len(xy), dtype=np.int32)

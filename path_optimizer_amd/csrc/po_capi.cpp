@@ -21,6 +21,7 @@ extern "C" hipError_t po_launch_assemble(int form, const po::DevBatch *in, const
 extern "C" size_t po_lds_bytes(int form, int N, int C, int keep);
 extern "C" hipError_t po_launch_postcheck(const po::DevMap *m, const po::DevCar *c, int B, int N, const int *n_points, const double *states,
                                           const po_info *info, int *n_valid, int *ok, hipStream_t st);
+extern "C" hipError_t po_launch_bounds(const po::DevMap *m, const po::DevBounds *in, double *bounds, int *n_valid, hipStream_t st);
 extern "C" hipError_t po_launch_map_sample(const po::DevMap *m, int n, const double *xy, double *dist, int *inside, hipStream_t st);
 
 namespace {
@@ -61,7 +62,7 @@ struct po_handle_s {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    DevBuf in_buf, out_buf, asm_buf, scale_buf, dbg_buf, map_buf, post_buf;
+    DevBuf in_buf, out_buf, asm_buf, scale_buf, dbg_buf, map_buf, post_buf, coef_buf, bnd_buf;
     po::DevMap map{};  // obstacle-distance layer (po_set_map); map.d == nullptr until set
     std::mutex mu;
 };
@@ -149,7 +150,7 @@ int po_destroy(po_handle h) {
     if (!h) return PO_ERR_INVALID;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    h->in_buf.release(); h->out_buf.release(); h->asm_buf.release(); h->scale_buf.release(); h->dbg_buf.release(); h->map_buf.release(); h->post_buf.release();
+    h->in_buf.release(); h->out_buf.release(); h->asm_buf.release(); h->scale_buf.release(); h->dbg_buf.release(); h->map_buf.release(); h->post_buf.release(); h->coef_buf.release(); h->bnd_buf.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -439,6 +440,63 @@ int po_postcheck_batch(po_handle h, int B, int N, const int *n_points, const dou
     std::lock_guard<std::mutex> g(h->mu);
     HIP_TRY(hipMemcpyAsync(n_valid, dn + B, bn, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(ok, dn + 2 * B, bn, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PO_OK;
+}
+
+// ---- corridor-bounds producer ------------------------------------------------------------------------------------
+int po_bounds_batch_device(po_handle h, const po_bounds_in *in, double *bounds, int *n_valid) {
+    if (!h || !in || in->B < 0 || in->N < 1 || in->K < 3) return PO_ERR_INVALID;
+    if (in->B > 0 && (!in->ref_x || !in->ref_y || !in->ref_z || !in->ref_s || !in->knot_s || !in->knot_x || !in->knot_y || !bounds || !n_valid)) return PO_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->map.d) return PO_ERR_INVALID;  // po_set_map first
+    if (in->B == 0) return PO_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    if (int rc = h->coef_buf.ensure(sizeof(double) * (size_t)in->B * 2 * 6 * in->K)) return rc;
+    po::DevBounds D{};
+    D.B = in->B; D.N = in->N; D.K = in->K;
+    D.ref_x = in->ref_x; D.ref_y = in->ref_y; D.ref_z = in->ref_z; D.ref_s = in->ref_s; D.n_points = in->n_points;
+    D.knot_s = in->knot_s; D.knot_x = in->knot_x; D.knot_y = in->knot_y; D.n_knots = in->n_knots;
+    const po_params &p = h->params;
+    for (int j = 0; j < 4; ++j) D.d[j] = p.d[j];
+    D.radius = std::sqrt((p.car_length / 8) * (p.car_length / 8) + (p.car_width / 2) * (p.car_width / 2)) + p.safety_margin;  // planning_flags.cpp:9
+    D.coef = static_cast<double *>(h->coef_buf.p);
+    HIP_TRY(po_launch_bounds(&h->map, &D, bounds, n_valid, h->stream));
+    return PO_OK;
+}
+
+int po_bounds_batch(po_handle h, const po_bounds_in *in, double *bounds, int *n_valid) {
+    if (!h || !in || in->B < 0 || in->N < 1 || in->K < 3) return PO_ERR_INVALID;
+    if (in->B > 0 && (!in->ref_x || !in->ref_y || !in->ref_z || !in->ref_s || !in->knot_s || !in->knot_x || !in->knot_y || !bounds || !n_valid)) return PO_ERR_INVALID;
+    if (in->B == 0) return PO_OK;
+    const size_t bn = sizeof(double) * (size_t)in->B * in->N, bk = sizeof(double) * (size_t)in->B * in->K, bi = sizeof(int) * (size_t)in->B;
+    const size_t bo = sizeof(double) * (size_t)in->B * in->N * 8;
+    char *base = nullptr;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        HIP_TRY(hipSetDevice(h->device));
+        if (int rc = h->bnd_buf.ensure(4 * bn + 3 * bk + 3 * bi + bo + 64)) return rc;
+        base = static_cast<char *>(h->bnd_buf.p);
+        const void *src[7] = {in->ref_x, in->ref_y, in->ref_z, in->ref_s, in->knot_s, in->knot_x, in->knot_y};
+        size_t off = 0;
+        for (int i = 0; i < 7; ++i) { const size_t sz = i < 4 ? bn : bk; HIP_TRY(hipMemcpyAsync(base + off, src[i], sz, hipMemcpyHostToDevice, h->stream)); off += sz; }
+        if (in->n_points) HIP_TRY(hipMemcpyAsync(base + off, in->n_points, bi, hipMemcpyHostToDevice, h->stream));
+        if (in->n_knots) HIP_TRY(hipMemcpyAsync(base + off + bi, in->n_knots, bi, hipMemcpyHostToDevice, h->stream));
+    }
+    po_bounds_in d = *in;
+    const double *pd = reinterpret_cast<const double *>(base);
+    d.ref_x = pd; d.ref_y = pd + (size_t)in->B * in->N; d.ref_z = pd + 2 * (size_t)in->B * in->N; d.ref_s = pd + 3 * (size_t)in->B * in->N;
+    const double *pk = pd + 4 * (size_t)in->B * in->N;
+    d.knot_s = pk; d.knot_x = pk + (size_t)in->B * in->K; d.knot_y = pk + 2 * (size_t)in->B * in->K;
+    int *pi = reinterpret_cast<int *>(base + 4 * bn + 3 * bk);
+    d.n_points = in->n_points ? pi : nullptr;
+    d.n_knots = in->n_knots ? pi + in->B : nullptr;
+    double *dout = reinterpret_cast<double *>(base + 4 * bn + 3 * bk + 3 * bi + (8 - (3 * bi) % 8) % 8);
+    const int rc = po_bounds_batch_device(h, &d, dout, pi + 2 * in->B);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIP_TRY(hipMemcpyAsync(bounds, dout, bo, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(n_valid, pi + 2 * in->B, bi, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return PO_OK;
 }

@@ -15,8 +15,6 @@
 #include "../../include/po_hip.h"
 #include "po_device.hpp"
 #include "po_scale.hpp"
-#define PO_MAP_DEVICE_CODE
-#include "po_map.hpp"
 
 namespace po {
 
@@ -237,12 +235,3 @@ extern "C" size_t po_lds_bytes(int form, int N, int C, int keep) {
     return lds_of(form, N, C, s);
 }
 
-extern "C" hipError_t po_launch_postcheck(const po::DevMap *m, const po::DevCar *c, int B, int N, const int *n_points, const double *states,
-                                          const po_info *info, int *n_valid, int *ok, hipStream_t st) {
-    hipLaunchKernelGGL(po::postcheck_kernel, dim3(B), dim3(128), 0, st, *m, *c, B, N, n_points, states, info, n_valid, ok);
-    return hipGetLastError();
-}
-extern "C" hipError_t po_launch_map_sample(const po::DevMap *m, int n, const double *xy, double *dist, int *inside, hipStream_t st) {
-    hipLaunchKernelGGL(po::map_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *m, n, xy, dist, inside);
-    return hipGetLastError();
-}

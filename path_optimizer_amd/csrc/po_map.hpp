@@ -23,6 +23,17 @@ struct DevCar {  // CollisionChecker's CarGeometry, built on the host exactly li
     int enable;
 };
 
+// corridor-bounds producer launch arguments (po_post.hip)
+struct DevBounds {
+    int B, N, K;
+    const double *ref_x, *ref_y, *ref_z, *ref_s;
+    const int *n_points;
+    const double *knot_s, *knot_x, *knot_y;
+    const int *n_knots;
+    double d[4], radius;
+    double *coef;  // [B][2][6][K]: per spline a, b, c + 3K scratch
+};
+
 #ifdef PO_MAP_DEVICE_CODE  // kernels and device functions: po_kernels.hip only (po_capi.cpp needs just the structs)
 // checkIfPositionWithinMap (GridMapMath.cpp): t = -(p - mapPos - 0.5*len); 0 <= t < len on both axes
 __device__ __forceinline__ bool map_inside(const DevMap &m, double x, double y) {
@@ -111,36 +122,6 @@ __device__ __forceinline__ bool collision_free(const DevMap &m, const DevCar &c,
         if (map_at_linear(m, gx, gy) < c.cr[k]) return false;
     }
     return true;
-}
-
-// One block per path: first colliding state, then optimizePath's return value (path_optimizer.cpp:183-200).
-__global__ __launch_bounds__(128) void postcheck_kernel(DevMap m, DevCar c, int B, int N, const int *n_points, const double *states,
-                                                        const po_info *info, int *n_valid, int *ok) {
-    const int b = blockIdx.x;
-    __shared__ int first;
-    int n = n_points ? n_points[b] : N;
-    n = n < 0 ? 0 : (n > N ? N : n);
-    if (threadIdx.x == 0) first = n;
-    __syncthreads();
-    const bool solved = info[b].status == PO_STATUS_SOLVED;
-    if (solved && c.enable) {
-        const double *s = states + (size_t)b * N * 5;
-        for (int i = threadIdx.x; i < n; i += blockDim.x)
-            if (!collision_free(m, c, s[5 * i], s[5 * i + 1], s[5 * i + 2])) atomicMin(&first, i);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (!solved) { n_valid[b] = 0; ok[b] = 0; }
-        else if (first >= n) { n_valid[b] = n; ok[b] = 1; }
-        else { n_valid[b] = first; ok[b] = (first > 0 && states[((size_t)b * N + first - 1) * 5 + 4] >= 20.0) ? 1 : 0; }
-    }
-}
-
-__global__ void map_sample_kernel(DevMap m, int n, const double *xy, double *dist, int *inside) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    dist[i] = map_distance(m, xy[2 * i], xy[2 * i + 1]);
-    inside[i] = map_inside(m, xy[2 * i], xy[2 * i + 1]) ? 1 : 0;
 }
 
 #endif  // PO_MAP_DEVICE_CODE

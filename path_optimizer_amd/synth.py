@@ -165,3 +165,25 @@ def make_distance_map(seed: int, size_x: int = 400, size_y: int = 300, resolutio
     for ox, oy, r in discs:
         d = np.minimum(d, np.hypot(X - ox, Y - oy) - r)
     return np.maximum(d, 0.0).astype(np.float32), resolution, pos[0], pos[1], discs
+
+
+def make_spline_paths(seed: int, B: int, N: int = 200, ds: float = 0.3, knot_ds: float = 1.5, start_box: float = 8.0):
+    """Reference paths for the corridor-bounds producer: smooth planar curves given as spline knots (s_k, x_k, y_k) every
+    `knot_ds` metres (what ReferencePath::setSpline is built from) plus N reference states sampled every `ds` metres
+    (x, y, heading, s) as buildReferenceFromSpline would hand them over.  Returns dict of arrays [B, ...]."""
+    rng = np.random.default_rng(np.random.SeedSequence([SEED0, 78, seed]))
+    length = (N - 1) * ds
+    K = int(math.ceil(length / knot_ds)) + 4
+    ks = knot_ds * np.arange(K)
+    out = dict(ref_x=np.zeros((B, N)), ref_y=np.zeros((B, N)), ref_z=np.zeros((B, N)), ref_s=np.tile(ds * np.arange(N), (B, 1)),
+               knot_s=np.tile(ks, (B, 1)), knot_x=np.zeros((B, K)), knot_y=np.zeros((B, K)))
+    fine = np.linspace(0, ks[-1], 8 * K)
+    for b in range(B):
+        k = rng.uniform(0, 0.05) * np.sin(2 * math.pi * fine / rng.uniform(25, 70) + rng.uniform(0, 6.28)) + rng.uniform(-0.01, 0.01)
+        z = rng.uniform(-math.pi, math.pi) + np.concatenate(([0.0], np.cumsum(0.5 * (k[1:] + k[:-1]) * np.diff(fine))))
+        x = rng.uniform(-start_box, start_box) + np.concatenate(([0.0], np.cumsum(np.cos(0.5 * (z[1:] + z[:-1])) * np.diff(fine))))
+        y = rng.uniform(-start_box, start_box) + np.concatenate(([0.0], np.cumsum(np.sin(0.5 * (z[1:] + z[:-1])) * np.diff(fine))))
+        out["knot_x"][b] = np.interp(ks, fine, x); out["knot_y"][b] = np.interp(ks, fine, y)
+        s = out["ref_s"][b]
+        out["ref_x"][b] = np.interp(s, fine, x); out["ref_y"][b] = np.interp(s, fine, y); out["ref_z"][b] = np.interp(s, fine, z)
+    return out
