@@ -33,6 +33,51 @@ def algorithmic_bytes(form, N, keep, iters_sum, B):
     return 8.0 * vals * iters_sum + 8.0 * (18 * N + 8) * B, 8.0 * vals
 
 
+def stage_legs(torch, binding, synth, eng, stream, dbatch, B, with_cpu):
+    """Stages immediately before / after the QP on the same device (reported beside the headline, never part of `value`):
+    corridor-bounds producer over a synthetic obstacle-distance map and the post-solve collision check of the solved batch."""
+    d, res, px, py, _ = synth.make_distance_map(seed=3, size_x=600, size_y=600, resolution=0.2, pos=(1.0, -2.0), n_obstacles=60, r_range=(0.5, 3.0))
+    eng.set_map(d, res, px, py)
+    nb = 256
+    P = synth.make_spline_paths(1, nb, 200)
+    keys = ("ref_x", "ref_y", "ref_z", "ref_s", "knot_s", "knot_x", "knot_y")
+    reps = -(-B // nb)
+    t = {k: torch.from_numpy(np.ascontiguousarray(np.concatenate([P[k]] * reps, axis=0)[:B])).cuda() for k in keys}
+    bounds = torch.zeros((B, 200, 4, 2), dtype=torch.float64, device="cuda"); nvalid = torch.zeros(B, dtype=torch.int32, device="cuda")
+    nkeep = torch.zeros(B, dtype=torch.int32, device="cuda"); ok = torch.zeros_like(nkeep)
+
+    def timed(fn, n=3):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(n):
+            fn()
+        e1.record(stream); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    ms_b = timed(lambda: eng.bounds_batch_device(t, bounds, nvalid))
+    ms_c = timed(lambda: eng.postcheck_batch_device(dbatch, nkeep, ok))
+    st = {"map": "600 x 600 cells at 0.2 m (1.44 MB float32), 60 random discs",
+          "bounds_producer": {"ms": ms_b, "paths_per_s": B / (ms_b * 1e-3), "circle_clearances_per_s": B * 200 * 4 / (ms_b * 1e-3),
+                              "kept_states_mean": float(nvalid.float().mean().item()),
+                              "workload": f"{B} spline reference paths x 200 states x 4 circles, <= 28 bilinear samples each"},
+          "post_check": {"ms": ms_c, "paths_per_s": B / (ms_c * 1e-3), "states_per_s": B * 200 / (ms_c * 1e-3),
+                         "ok_frac": float(ok.float().mean().item())}}
+    if with_cpu:
+        from oracle import oracle_py
+
+        m = oracle_py.make_map(d, res, px, py); p = oracle_py.default_params()
+        c0 = time.perf_counter()
+        for b in range(64):
+            oracle_py.bounds_path(p, m, *[P[k][b] for k in keys])
+        c1 = time.perf_counter()
+        states = dbatch.out_states[:64].cpu().numpy(); info = dbatch.info_numpy()[:64]
+        oracle_py.postcheck_batch(p, m, states, info)
+        c2 = time.perf_counter()
+        st["cpu_port"] = {"bounds_paths_per_s": 64 / (c1 - c0), "post_check_paths_per_s": 64 / (c2 - c1), "cores": 1, "sample": "64 paths each, oracle (C)"}
+    return st
+
+
 def _cpu_slice(arg):
     """Worker of the all-cores CPU baseline leg (oracle, test infrastructure)."""
     from oracle import oracle_py
@@ -53,6 +98,8 @@ def main():
                     "(independent batches: the stragglers of step k drain while step k+1 fills the CUs); 1 = strictly serial steps")
     ap.add_argument("--serial-leg", action="store_true", help="additionally time the same K steps strictly serially on one stream "
                     "and report them under \"serial\" (off by default so that a profile of the default command sees only the timed pattern)")
+    ap.add_argument("--no-stages", action="store_true", help="skip the (untimed) legs for the stages around the QP: corridor-bounds producer "
+                    "and post-solve collision check (SURVEY.md §8f-1/2)")
     ap.add_argument("--cpu-sample", type=int, default=768, help="paths timed on the CPU oracle (rank 0, N=1 only)")
     args = ap.parse_args()
 
@@ -188,6 +235,8 @@ def main():
                                        "achieved": float(info["iters"].sum()) * 1.0e5 * args.steps / elapsed / 1e12,
                                        "note": "0.1 MFLOP per path-iteration (SURVEY.md §8a10)"}},
         }
+        if world == 1 and not args.no_stages:
+            out["stages"] = stage_legs(torch, binding, synth, engs[0], streams[0], dbatch, B, args.cpu_sample > 0)
         if world == 1 and args.cpu_sample > 0:
             from oracle import oracle_py  # CPU baseline leg only
 
