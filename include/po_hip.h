@@ -82,6 +82,13 @@ typedef struct po_params {
     double car_length;          /* FLAGS_car_length          (4.9)  */
     double rear_axle_to_center; /* FLAGS_rear_axle_to_center (1.45) */
     double safety_margin;       /* FLAGS_safety_margin       (0.0): circle_radius = sqrt((L/8)^2+(W/2)^2) + safety_margin */
+    /* reference-smoothing QPs, planning_flags.cpp:76-86 */
+    double t2_w_dev;            /* FLAGS_tension_2_deviation_weight       (0.005) */
+    double t2_w_curv;           /* FLAGS_tension_2_curvature_weight       (1)     */
+    double t2_w_curv_rate;      /* FLAGS_tension_2_curvature_rate_weight  (10)    */
+    double cart_w_curv;         /* FLAGS_cartesian_curvature_weight       (1)     */
+    double cart_w_curv_rate;    /* FLAGS_cartesian_curvature_rate_weight  (50)    */
+    double cart_w_dev;          /* FLAGS_cartesian_deviation_weight       (0)     */
 } po_params;
 
 typedef struct po_info {
@@ -190,6 +197,41 @@ typedef struct po_bounds_in {
 } po_bounds_in;
 int po_bounds_batch(po_handle h, const po_bounds_in *in, double *bounds, int *n_valid);        /* host pointers, synchronous  */
 int po_bounds_batch_device(po_handle h, const po_bounds_in *in, double *bounds, int *n_valid); /* device pointers, on the stream */
+
+/* ---- reference-smoothing QPs: the three other places where the reference hands a chain-structured QP to
+ * OsqpEigen with the same call pattern as the hot path (setHessianMatrix ... initSolver, solve):
+ *   PO_SMOOTH_TENSION2  TensionSmoother2::osqpSmooth       src/reference_path_smoother/tension_smoother_2.cpp:163-301
+ *                       (FLAGS_smoothing_method = "TENSION2", FLAGS_tension_solver = "OSQP": the shipped defaults)
+ *   PO_SMOOTH_TENSION   TensionSmoother::osqpSmooth        src/reference_path_smoother/tension_smoother.cpp:186-314  (needs po_set_map)
+ *   PO_SMOOTH_POST      ReferencePathSmoother::postSmooth  src/reference_path_smoother/reference_path_smoother.cpp:534-644 (the QP; the
+ *                       re-projection onto the spline that follows it stays with the caller)
+ * One batch = B independent instances with up to P points each (arrays [B][P], ragged through n_points).
+ *   TENSION2 / TENSION inputs: x, y, angle, k, s = the five lists segmentRawReference produces (reference_path_smoother.cpp:50-91);
+ *       outputs: out_x, out_y, out_s = result_x_list, result_y_list, result_s_list (s = running chord length of the result).
+ *   POST inputs: s = layers_s_list_, lb / ub = layers_bounds_ (.first / .second), l0[b] = vehicle_l_wrt_smoothed_ref_;
+ *       x, y, angle, k unused (may be NULL); output: out_x[b][i] = QPSolution(i), the lateral offset of layer i; out_y / out_s unused.
+ * info[b].status == PO_STATUS_SOLVED <=> the reference's `solver.solve()` returned true; raw (optional) = the whole QP solution in
+ * the REFERENCE variable order, [B][n_max] with n_max = po_smooth_dims(kind, P).  OSQP settings come from the handle's po_params
+ * (the reference runs the smoothers at OSQP's default eps_abs = eps_rel = 1e-3; create the handle accordingly to mirror that).
+ * Fewer points than the reference accepts (TENSION*: 3, POST: 4, reference_path_smoother.cpp:536) -> PO_ERR_INVALID. */
+enum { PO_SMOOTH_TENSION2 = 0, PO_SMOOTH_TENSION = 1, PO_SMOOTH_POST = 2 };
+typedef struct po_smooth_in {
+    int kind, B, P;
+    const int    *n_points;            /* optional [B] */
+    const double *x, *y, *angle, *k;   /* [B][P] */
+    const double *s;                   /* [B][P] */
+    const double *lb, *ub;             /* [B][P]  POST only */
+    const double *l0;                  /* [B]     POST only */
+} po_smooth_in;
+typedef struct po_smooth_out {
+    double  *x, *y, *s;   /* [B][P] (y, s may be NULL for POST) */
+    po_info *info;        /* [B] */
+    double  *raw;         /* optional [B][n_max] */
+} po_smooth_out;
+/* QP dimensions as the reference sets them (tension_smoother_2.cpp:177-178, tension_smoother.cpp:201-202, reference_path_smoother.cpp:544-545) */
+int po_smooth_dims(int kind, int P, int *n, int *m);
+int po_smooth_batch(po_handle h, const po_smooth_in *in, const po_smooth_out *out);        /* host pointers, synchronous  */
+int po_smooth_batch_device(po_handle h, const po_smooth_in *in, const po_smooth_out *out); /* device pointers, on the stream */
 
 /* Test/diagnostic entry: Map::getObstacleDistance at `n` world positions xy[n][2] (host pointers); inside[n] = Map::isInside. */
 int po_map_sample(po_handle h, int n, const double *xy, double *dist, int *inside);

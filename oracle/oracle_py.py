@@ -228,3 +228,64 @@ def bounds_path(params, m: PoMap, ref_x, ref_y, ref_z, ref_s, ks, kx, ky):
     out = np.zeros((N, 4, 2))
     n = lib().po_oracle_bounds_path(C.byref(params), C.byref(m), N, _p(ref_x), _p(ref_y), _p(ref_z), _p(ref_s), len(ks), _p(ks), _p(kx), _p(ky), _p(out))
     return out, n
+
+
+# ---- reference-smoothing QPs ----
+def smooth_dims(kind, P):
+    n, m = C.c_int(), C.c_int()
+    rc = lib().po_oracle_smooth_dims(kind, P, C.byref(n), C.byref(m))
+    if rc:
+        raise ValueError(f"po_oracle_smooth_dims rc={rc}")
+    return n.value, m.value
+
+
+def _smooth_args(inp, b, n):
+    f = lambda key: None if inp.get(key) is None else np.ascontiguousarray(inp[key][b, :n], dtype=np.float64)
+    return [f(k) for k in ("x", "y", "angle", "k", "s", "lb", "ub")], float(inp["l0"][b]) if inp.get("l0") is not None else 0.0
+
+
+def smooth_assemble(kind, params, inp, b=0, m_map=None):
+    """(P upper CSC, q, A CSC, l, u) of instance b in the reference's variable / row order."""
+    import scipy.sparse as sp
+
+    n_pts = int(inp["n_points"][b]) if inp.get("n_points") is not None else inp["s"].shape[1]
+    n, m = smooth_dims(kind, n_pts)
+    arrs, l0 = _smooth_args(inp, b, n_pts)
+    Pp = np.zeros(n + 1, np.int32); Pi = np.zeros(16 * n_pts + 16, np.int32); Px = np.zeros(16 * n_pts + 16)
+    Ap = np.zeros(n + 1, np.int32); Ai = np.zeros(4 * m + 16, np.int32); Ax = np.zeros(4 * m + 16)
+    q = np.zeros(n); l = np.zeros(m); u = np.zeros(m)
+    L = lib()
+    L.po_oracle_smooth_assemble.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_double] + [C.c_void_p] * 9
+    rc = L.po_oracle_smooth_assemble(kind, C.byref(params), None if m_map is None else C.byref(m_map), n_pts, *[_p(a) for a in arrs], l0,
+                                     _p(Pp), _p(Pi), _p(Px), _p(q), _p(Ap), _p(Ai), _p(Ax), _p(l), _p(u))
+    if rc:
+        raise ValueError(f"po_oracle_smooth_assemble rc={rc}")
+    Pm = sp.csc_matrix((Px[:Pp[n]], Pi[:Pp[n]], Pp), shape=(n, n))
+    Am = sp.csc_matrix((Ax[:Ap[n]], Ai[:Ap[n]], Ap), shape=(m, n))
+    return Pm, q, Am, l, u
+
+
+def smooth_batch(kind, params, inp, m_map=None, want_raw=False):
+    """po_oracle_smooth_solve over a batch: out_x, out_y, out_s [B,P], info [B] (+ raw [B,n_max])."""
+    B, P = inp["s"].shape
+    ox = np.zeros((B, P)); oy = np.zeros((B, P)); os_ = np.zeros((B, P))
+    info = np.zeros(B, dtype=INFO_DTYPE)
+    nmax, _ = smooth_dims(kind, P)
+    raw = np.zeros((B, nmax)) if want_raw else None
+    L = lib()
+    L.po_oracle_smooth_solve.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_double] + [C.c_void_p] * 5
+    for b in range(B):
+        n_pts = int(inp["n_points"][b]) if inp.get("n_points") is not None else P
+        arrs, l0 = _smooth_args(inp, b, n_pts)
+        one = PoInfo()
+        tx = np.zeros(n_pts); ty = np.zeros(n_pts); ts = np.zeros(n_pts); tr = np.zeros(nmax)
+        rc = L.po_oracle_smooth_solve(kind, C.byref(params), None if m_map is None else C.byref(m_map), n_pts, *[_p(a) for a in arrs], l0,
+                                      _p(tx), _p(ty), _p(ts), _p(tr), C.byref(one))
+        if rc < 0:
+            raise ValueError(f"po_oracle_smooth_solve rc={rc}")
+        ox[b, :n_pts], oy[b, :n_pts], os_[b, :n_pts] = tx, ty, ts
+        for name, _ in INFO_DTYPE:
+            info[b][name] = getattr(one, name)
+        if want_raw:
+            raw[b] = tr
+    return ox, oy, os_, info, raw

@@ -71,6 +71,9 @@ void po_oracle_default_params(po_params *p) {
     p->max_iter = 4000;
     p->check_every = 25;
     p->adapt_every = 100;
+    /* planning_flags.cpp:76-86 (reference-smoothing QPs) */
+    p->t2_w_dev = 0.005; p->t2_w_curv = 1; p->t2_w_curv_rate = 10;
+    p->cart_w_curv = 1; p->cart_w_curv_rate = 50; p->cart_w_dev = 0.0;
 }
 
 /* tools.hpp:24-35 — recursive in the reference; same fixed point as this loop */
@@ -1714,4 +1717,161 @@ int po_oracle_bounds_path(const po_params *p, const po_map *m, int N, const doub
     }
     free(co);
     return kept;
+}
+
+
+/* ------------------------------------------------------------------------------------------ */
+/* Part 6: the reference-smoothing QPs.  Same OsqpEigen call pattern as the   */
+/* hot path; assembly restated in the reference's variable / row order with its dense-scratch   */
+/* + sparseView() semantics, solved by po_oracle_qp_solve (true Ruiz passes, scaling = 10).     */
+/*   TENSION2 : src/reference_path_smoother/tension_smoother_2.cpp:163-301                      */
+/*   TENSION  : src/reference_path_smoother/tension_smoother.cpp:186-314                        */
+/*   POST     : src/reference_path_smoother/reference_path_smoother.cpp:534-644                 */
+/* ------------------------------------------------------------------------------------------ */
+int po_oracle_smooth_dims(int kind, int P, int *n, int *m) {
+    int nn, mm;
+    if (kind == PO_SMOOTH_TENSION2) { if (P < 3) return PO_ERR_INVALID; nn = 4 * P - 1; mm = 3 * (P - 1) + 2; }   /* tension_smoother_2.cpp:177-178 */
+    else if (kind == PO_SMOOTH_TENSION) { if (P < 3) return PO_ERR_INVALID; nn = 3 * P; mm = 3 * P; }             /* tension_smoother.cpp:201-202 */
+    else if (kind == PO_SMOOTH_POST) { if (P < 4) return PO_ERR_INVALID; nn = 3 * P; mm = 3 * P - 2; }            /* reference_path_smoother.cpp:536,544-545 */
+    else return PO_ERR_INVALID;
+    if (n) *n = nn;
+    if (m) *m = mm;
+    return PO_OK;
+}
+
+int po_oracle_smooth_assemble(int kind, const po_params *p, const po_map *map, int P, const double *x, const double *y,
+                              const double *angle, const double *k, const double *s, const double *lb, const double *ub, double l0,
+                              int *Pp, int *Pi, double *Px, double *q, int *Ap, int *Ai, double *Ax, double *l, double *u) {
+    int n, m;
+    if (po_oracle_smooth_dims(kind, P, &n, &m)) return PO_ERR_INVALID;
+    tripbuf H = {0, 0, 0}, A = {0, 0, 0};
+    int rc = PO_OK;
+    for (int i = 0; i < n; ++i) q[i] = 0;
+    for (int i = 0; i < m; ++i) l[i] = u[i] = 0;
+    if (kind == PO_SMOOTH_TENSION2) {
+        const int xs = 0, ys = P, ts = 2 * P, ks = 3 * P;
+        /* setHessianMatrix, tension_smoother_2.cpp:220-241 */
+        for (int i = 0; i < P; ++i) {
+            TSET(&H, xs + i, xs + i, p->t2_w_dev * 2);
+            TSET(&H, ys + i, ys + i, p->t2_w_dev * 2);
+            if (i != P - 1) TSET(&H, ks + i, ks + i, p->t2_w_curv * 2);
+        }
+        for (int i = 0; i < P - 2; ++i) { /* hessian.block(k+i, k+i, 2, 2) += 2 * w * [1 -1; -1 1] */
+            const double w2 = 2 * p->t2_w_curv_rate;
+            TADD(&H, ks + i, ks + i, w2 * 1.0);
+            TADD(&H, ks + i + 1, ks + i, w2 * -1.0);
+            TADD(&H, ks + i, ks + i + 1, w2 * -1.0);
+            TADD(&H, ks + i + 1, ks + i + 1, w2 * 1.0);
+        }
+        /* setGradient, :288-299 */
+        for (int i = 0; i < P; ++i) {
+            q[xs + i] = -2 * p->t2_w_dev * x[i];
+            q[ys + i] = -2 * p->t2_w_dev * y[i];
+        }
+        /* setConstraintMatrix, :243-286 */
+        const int cx = 0, cy = P - 1, ct = 2 * (P - 1), c0x = 3 * (P - 1), c0y = 3 * (P - 1) + 1;
+        for (int i = 0; i < P - 1; ++i) {
+            const double ds = s[i + 1] - s[i];
+            TSET(&A, cx + i, xs + i + 1, 1.0); TSET(&A, cy + i, ys + i + 1, 1.0); TSET(&A, ct + i, ts + i + 1, 1.0);
+            TSET(&A, cx + i, xs + i, -1.0); TSET(&A, cy + i, ys + i, -1.0); TSET(&A, ct + i, ts + i, -1.0);
+            TSET(&A, cx + i, ts + i, ds * sin(angle[i]));
+            TSET(&A, cy + i, ts + i, -ds * cos(angle[i]));
+            TSET(&A, ct + i, ks + i, -ds);
+            l[cx + i] = u[cx + i] = ds * cos(angle[i]);
+            l[cy + i] = u[cy + i] = ds * sin(angle[i]);
+            l[ct + i] = u[ct + i] = -ds * k[i];
+        }
+        TSET(&A, c0x, xs, 1.0); TSET(&A, c0y, ys, 1.0);
+        l[c0x] = u[c0x] = x[0];
+        l[c0y] = u[c0y] = y[0];
+    } else if (kind == PO_SMOOTH_TENSION) {
+        const int xs = 0, ys = P, dsi = 2 * P;
+        /* setHessianMatrix, tension_smoother.cpp:238-261: dds = [1 -2 1]'[1 -2 1] * w_c, ddds = [-1 3 -3 1]'[-1 3 -3 1] * w_cr */
+        static const double v3[3] = {1, -2, 1}, v4[4] = {-1, 3, -3, 1};
+        for (int i = 0; i < P - 2; ++i) {
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    TADD(&H, xs + i + a, xs + i + b, v3[a] * v3[b] * p->cart_w_curv);
+                    TADD(&H, ys + i + a, ys + i + b, v3[a] * v3[b] * p->cart_w_curv);
+                }
+            if (i != P - 3)
+                for (int a = 0; a < 4; ++a)
+                    for (int b = 0; b < 4; ++b) {
+                        TADD(&H, xs + i + a, xs + i + b, v4[a] * v4[b] * p->cart_w_curv_rate);
+                        TADD(&H, ys + i + a, ys + i + b, v4[a] * v4[b] * p->cart_w_curv_rate);
+                    }
+        }
+        for (int i = 0; i < P; ++i) TSET(&H, dsi + i, dsi + i, p->cart_w_dev);
+        /* setConstraintMatrix, :263-314 */
+        for (int i = 0; i < P; ++i) {
+            TSET(&A, xs + i, xs + i, 1.0); TSET(&A, ys + i, ys + i, 1.0);
+            const double theta = angle[i] + M_PI_2;
+            TSET(&A, xs + i, dsi + i, -cos(theta));
+            TSET(&A, ys + i, dsi + i, -sin(theta));
+            TSET(&A, dsi + i, dsi + i, 1.0);
+            l[xs + i] = u[xs + i] = x[i];
+            l[ys + i] = u[ys + i] = y[i];
+        }
+        l[dsi] = u[dsi] = 0;
+        l[dsi + P - 1] = -0.5; u[dsi + P - 1] = 0.5;
+        for (int i = 1; i < P - 1; ++i) {
+            double clearance = map ? po_oracle_map_distance(map, x[i], y[i]) : 2.0;
+            clearance = clearance < 2.0 ? clearance : 2.0; /* std::min(clearance, default_clearance) */
+            l[dsi + i] = -clearance; u[dsi + i] = clearance;
+        }
+    } else { /* POST: setPostHessianMatrix :598-612, setPostConstraintMatrix :614-650 */
+        const int L = P, xi = 0, dxi = L, ddxi = 2 * L, cdx = L, cddx = 2 * L - 1;
+        for (int i = 0; i < L; ++i) { TSET(&H, i, i, 1.0); TSET(&H, L + i, L + i, 100.0); TSET(&H, 2 * L + i, 2 * L + i, 1000.0); }
+        for (int i = 0; i < L; ++i) TSET(&A, i, i, 1.0);
+        for (int i = 0; i < L - 1; ++i) {
+            TSET(&A, cdx + i, xi + i + 1, 1.0); TSET(&A, cdx + i, xi + i, -1.0); TSET(&A, cdx + i, dxi + i, -(s[i + 1] - s[i]));
+        }
+        for (int i = 0; i < L - 1; ++i) {
+            TSET(&A, cddx + i, dxi + i + 1, 1.0); TSET(&A, cddx + i, dxi + i, -1.0); TSET(&A, cddx + i, ddxi + i, -(s[i + 1] - s[i]));
+        }
+        l[0] = u[0] = l0;
+        for (int i = 1; i < L; ++i) { l[i] = lb[i]; u[i] = ub[i]; }
+    }
+    if (!H.t || !A.t) rc = PO_ERR_NOMEM;
+    if (!rc) { tb_compress(&H, n, 1, Pp, Pi, Px); tb_compress(&A, n, 0, Ap, Ai, Ax); }
+    free(H.t); free(A.t);
+    return rc;
+}
+
+/* osqpSmooth / postSmooth for one instance: assemble, OSQP-style solve, and the output loop
+ * (tension_smoother_2.cpp:204-217 == tension_smoother.cpp:222-235: result lists + running chord length). Returns 1 iff "solved". */
+int po_oracle_smooth_solve(int kind, const po_params *p, const po_map *map, int P, const double *x, const double *y, const double *angle,
+                           const double *k, const double *s, const double *lb, const double *ub, double l0,
+                           double *out_x, double *out_y, double *out_s, double *raw, po_info *info) {
+    int n, m;
+    if (po_oracle_smooth_dims(kind, P, &n, &m)) return PO_ERR_INVALID;
+    const int pcap = 16 * P + 16, acap = 4 * m + 16;
+    int *Pp = (int *)malloc(sizeof(int) * (size_t)(n + 1)), *Pi = (int *)malloc(sizeof(int) * (size_t)pcap);
+    int *Ap = (int *)malloc(sizeof(int) * (size_t)(n + 1)), *Ai = (int *)malloc(sizeof(int) * (size_t)acap);
+    double *Px = (double *)malloc(sizeof(double) * (size_t)pcap), *Ax = (double *)malloc(sizeof(double) * (size_t)acap);
+    double *q = (double *)malloc(sizeof(double) * (size_t)n), *l = (double *)malloc(sizeof(double) * (size_t)m), *u = (double *)malloc(sizeof(double) * (size_t)m);
+    double *xs = (double *)malloc(sizeof(double) * (size_t)n), *ys = (double *)malloc(sizeof(double) * (size_t)m), *zs = (double *)malloc(sizeof(double) * (size_t)m);
+    int rc = po_oracle_smooth_assemble(kind, p, map, P, x, y, angle, k, s, lb, ub, l0, Pp, Pi, Px, q, Ap, Ai, Ax, l, u);
+    if (!rc) rc = po_oracle_qp_solve(n, m, Pp, Pi, Px, q, Ap, Ai, Ax, l, u, p, NULL, xs, ys, zs, info);
+    int ok = 0;
+    if (!rc) {
+        ok = info->status == PO_STATUS_SOLVED;
+        if (raw) memcpy(raw, xs, sizeof(double) * (size_t)n);
+        if (kind == PO_SMOOTH_POST) {
+            for (int i = 0; i < P; ++i) out_x[i] = xs[i];
+        } else {
+            double tmp_s = 0;
+            for (int i = 0; i < P; ++i) {
+                out_x[i] = xs[i];
+                out_y[i] = xs[P + i];
+                if (i != 0) {
+                    const double ddx = out_x[i] - out_x[i - 1], ddy = out_y[i] - out_y[i - 1];
+                    tmp_s += sqrt(ddx * ddx + ddy * ddy);
+                }
+                out_s[i] = tmp_s;
+            }
+        }
+    }
+    free(Pp); free(Pi); free(Ap); free(Ai); free(Px); free(Ax); free(q); free(l); free(u); free(xs); free(ys); free(zs);
+    return rc ? rc : ok;
 }

@@ -115,6 +115,18 @@ double po_oracle_spline_eval(int K, const double *ks, const double *kv, const do
 int    po_oracle_bounds_path(const po_params *p, const po_map *m, int N, const double *ref_x, const double *ref_y, const double *ref_z,
                              const double *ref_s, int K, const double *ks, const double *kx, const double *ky, double *bounds);
 
+/* ---- reference-smoothing QPs (kinds PO_SMOOTH_* of include/po_hip.h) ----
+ * TensionSmoother2::osqpSmooth (tension_smoother_2.cpp:163-301), TensionSmoother::osqpSmooth (tension_smoother.cpp:186-314),
+ * ReferencePathSmoother::postSmooth's QP (reference_path_smoother.cpp:534-650): assembly in the reference's variable/row order. */
+int po_oracle_smooth_dims(int kind, int P, int *n, int *m);
+int po_oracle_smooth_assemble(int kind, const po_params *p, const po_map *map, int P, const double *x, const double *y,
+                              const double *angle, const double *k, const double *s, const double *lb, const double *ub, double l0,
+                              int *Pp, int *Pi, double *Px, double *q, int *Ap, int *Ai, double *Ax, double *l, double *u);
+/* one instance end to end (assemble, po_oracle_qp_solve, output lists); returns 1 iff solved, 0 otherwise, < 0 on misuse */
+int po_oracle_smooth_solve(int kind, const po_params *p, const po_map *map, int P, const double *x, const double *y, const double *angle,
+                           const double *k, const double *s, const double *lb, const double *ub, double l0,
+                           double *out_x, double *out_y, double *out_s, double *raw, po_info *info);
+
 #ifdef __cplusplus
 }
 #endif

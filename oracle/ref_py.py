@@ -119,3 +119,64 @@ def bounds_path(m, ref_x, ref_y, ref_z, ref_s, ks, kx, ky):
     out = np.zeros((N, 4, 2))
     n = lib_bounds().po_ref_bounds_path(C.byref(m), N, _p(ref_x), _p(ref_y), _p(ref_z), _p(ref_s), len(ks), _p(ks), _p(kx), _p(ky), _p(out))
     return out, n
+
+
+# ---- reference-smoothing QPs: the reference's real smoother classes (ref_shim/ref_glue_smooth.cpp, own library) ----
+_LIBS = None
+
+
+def lib_smooth():
+    global _LIBS
+    if _LIBS is None:
+        lib()
+        _LIBS = C.CDLL(os.path.join(_HERE, "_ref", "libpo_ref_smooth.so"))
+    return _LIBS
+
+
+def smooth_flags():
+    out = np.zeros(6)
+    lib_smooth().po_ref_smooth_flags(_p(out))
+    return out
+
+
+def _captured_smooth():
+    import scipy.sparse as sp
+
+    L = lib_smooth()
+    n, m, pnz, anz = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    L.po_ref_smooth_get_dims(C.byref(n), C.byref(m), C.byref(pnz), C.byref(anz))
+    n, m, pnz, anz = n.value, m.value, pnz.value, anz.value
+    Pp = np.zeros(n + 1, np.int32); Pi = np.zeros(pnz, np.int32); Px = np.zeros(pnz)
+    Ap = np.zeros(n + 1, np.int32); Ai = np.zeros(anz, np.int32); Ax = np.zeros(anz)
+    q = np.zeros(n); l = np.zeros(m); u = np.zeros(m); x = np.zeros(n)
+    L.po_ref_smooth_get_qp(_p(Pp), _p(Pi), _p(Px), _p(Ap), _p(Ai), _p(Ax), _p(q), _p(l), _p(u), _p(x))
+    return dict(P=sp.csc_matrix((Px, Pi, Pp), shape=(n, n)), A=sp.csc_matrix((Ax, Ai, Ap), shape=(m, n)), q=q, l=l, u=u, x=x, n=n, m=m)
+
+
+def osqp_smooth(kind, params, x, y, angle, k, s, m_map=None):
+    """TensionSmoother2::osqpSmooth (kind 0) / TensionSmoother::osqpSmooth (kind 1) of the reference on one instance."""
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    x, y, angle, k, s = map(f, (x, y, angle, k, s))
+    P = len(x)
+    rx = np.zeros(P); ry = np.zeros(P); rs = np.zeros(P)
+    L = lib_smooth()
+    L.po_ref_osqp_smooth.argtypes = [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 9
+    rc = L.po_ref_osqp_smooth(kind, None if m_map is None else C.byref(m_map), P, _p(x), _p(y), _p(angle), _p(k), _p(s), C.byref(params), _p(rx), _p(ry), _p(rs))
+    out = _captured_smooth()
+    out.update(rc=rc, out_x=rx, out_y=ry, out_s=rs)
+    return out
+
+
+def post_smooth(params, layer_s, lb, ub, l0, ks, kx, ky):
+    """ReferencePathSmoother::postSmooth of the reference: captured QP + samples of the re-fitted spline."""
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    layer_s, lb, ub, ks, kx, ky = map(f, (layer_s, lb, ub, ks, kx, ky))
+    Lr = len(layer_s)
+    send = C.c_double(0)
+    nx = np.zeros(Lr); ny = np.zeros(Lr)
+    L = lib_smooth()
+    L.po_ref_post_smooth.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int] + [C.c_void_p] * 7
+    rc = L.po_ref_post_smooth(Lr, _p(layer_s), _p(lb), _p(ub), float(l0), len(ks), _p(ks), _p(kx), _p(ky), C.byref(params), C.byref(send), _p(nx), _p(ny))
+    out = _captured_smooth()
+    out.update(rc=rc, s_end=send.value, new_x=nx, new_y=ny)
+    return out

@@ -1,0 +1,109 @@
+// ref_glue_smooth.cpp — drives the REFERENCE's own reference-smoothing QP code, compiled from
+// /root/reference/src/reference_path_smoother/{reference_path_smoother,tension_smoother,tension_smoother_2,angle_diff_smoother}.cpp,
+// src/data_struct/{reference_path,reference_path_impl}.cpp, src/tools/{Map,tools,spline}.cpp and src/config/planning_flags.cpp,
+// unmodified, against the stand-in headers in this directory.  TEST INFRASTRUCTURE ONLY; built into oracle/_ref/libpo_ref_smooth.so.
+//
+// Pins: TensionSmoother2::{setHessianMatrix,setGradient,setConstraintMatrix,osqpSmooth's output loop},
+// TensionSmoother::{setHessianMatrix,setConstraintMatrix,osqpSmooth} (incl. the map clearance of every point),
+// ReferencePathSmoother::{setPostHessianMatrix,setPostConstraintMatrix,postSmooth} and the flag defaults they read.
+// Does NOT pin OSQP (absent): OsqpEigen::Solver::solve() forwards to the oracle's ADMM.
+#include <cstring>
+#include <vector>
+
+#define private public      // the entry points are private members of the reference's classes; access only, no layout change
+#define protected public
+#include "path_optimizer/reference_path_smoother/tension_smoother_2.hpp"
+#undef private
+#undef protected
+#include "OsqpEigen/OsqpEigen.h"
+#include "path_optimizer/config/planning_flags.hpp"
+#include "path_optimizer/data_struct/reference_path.hpp"
+#include "path_optimizer/tools/Map.hpp"
+#include "path_optimizer/tools/spline.h"
+
+namespace OsqpEigen {
+static Captured g_cap;
+static po_params g_params;
+Captured &last_captured() { return g_cap; }
+const po_params &shim_params() { return g_params; }
+}  // namespace OsqpEigen
+
+void updateConfig();  // planning_flags.cpp
+
+extern "C" {
+
+void po_ref_smooth_flags(double *out /*[6]*/) {
+    const double v[6] = {FLAGS_tension_2_deviation_weight, FLAGS_tension_2_curvature_weight, FLAGS_tension_2_curvature_rate_weight,
+                         FLAGS_cartesian_curvature_weight, FLAGS_cartesian_curvature_rate_weight, FLAGS_cartesian_deviation_weight};
+    std::memcpy(out, v, sizeof(v));
+}
+
+// kind 0: TensionSmoother2::osqpSmooth, kind 1: TensionSmoother::osqpSmooth (virtual dispatch on the real classes).
+// Returns what osqpSmooth returned (1/0).  The captured QP is read back with po_ref_smooth_get_*.
+int po_ref_osqp_smooth(int kind, const po_map *m, int P, const double *x, const double *y, const double *angle, const double *k,
+                       const double *s, const po_params *admm, double *rx, double *ry, double *rs) {
+    using namespace PathOptimizationNS;
+    updateConfig();
+    OsqpEigen::g_params = *admm;
+    po_map empty{};
+    grid_map::GridMap gm(m ? *m : empty);
+    Map map(gm);
+    std::vector<State> input(4);
+    State start;
+    std::vector<double> vx(x, x + P), vy(y, y + P), va(angle, angle + P), vk(k, k + P), vs(s, s + P), ox, oy, os;
+    bool ok;
+    if (kind == 0) { TensionSmoother2 sm(input, start, map); ok = static_cast<TensionSmoother &>(sm).osqpSmooth(vx, vy, va, vk, vs, &ox, &oy, &os); }
+    else { TensionSmoother sm(input, start, map); ok = sm.osqpSmooth(vx, vy, va, vk, vs, &ox, &oy, &os); }
+    for (size_t i = 0; i < ox.size(); ++i) { rx[i] = ox[i]; ry[i] = oy[i]; rs[i] = os[i]; }
+    return ok ? 1 : 0;
+}
+
+// ReferencePathSmoother::postSmooth on given layers (layers_s_list_, layers_bounds_, vehicle_l_wrt_smoothed_ref_) and a reference
+// spline through (ks, kx, ky).  Outputs: the new spline's knots (s_list, x_list, y_list) re-read from the ReferencePath.
+int po_ref_post_smooth(int L, const double *layer_s, const double *lb, const double *ub, double l0, int K, const double *ks,
+                       const double *kx, const double *ky, const po_params *admm, double *new_s_end, double *new_x_at, double *new_y_at) {
+    using namespace PathOptimizationNS;
+    updateConfig();
+    OsqpEigen::g_params = *admm;
+    po_map empty{};
+    grid_map::GridMap gm(empty);
+    Map map(gm);
+    std::vector<State> input(4);
+    State start;
+    TensionSmoother2 sm(input, start, map);
+    sm.layers_s_list_.assign(layer_s, layer_s + L);
+    sm.layers_bounds_.clear();
+    for (int i = 0; i < L; ++i) sm.layers_bounds_.emplace_back(lb[i], ub[i]);
+    sm.vehicle_l_wrt_smoothed_ref_ = l0;
+    ReferencePath ref;
+    tk::spline xs, ys;
+    xs.set_points(std::vector<double>(ks, ks + K), std::vector<double>(kx, kx + K));
+    ys.set_points(std::vector<double>(ks, ks + K), std::vector<double>(ky, ky + K));
+    ref.setSpline(xs, ys, ks[K - 1]);
+    const bool ok = sm.postSmooth(&ref);
+    if (ok) {  // sample the re-fitted spline at L abscissae spread over its length
+        *new_s_end = ref.getLength();
+        for (int i = 0; i < L; ++i) {
+            const double at = ref.getLength() * i / (L - 1);
+            new_x_at[i] = ref.getXS(at);
+            new_y_at[i] = ref.getYS(at);
+        }
+    }
+    return ok ? 1 : 0;
+}
+
+void po_ref_smooth_get_dims(int *n, int *m, int *pnz, int *anz) {
+    const auto &c = OsqpEigen::g_cap;
+    *n = c.n; *m = c.m; *pnz = (int)c.Px.size(); *anz = (int)c.Ax.size();
+}
+void po_ref_smooth_get_qp(int *Pp, int *Pi, double *Px, int *Ap, int *Ai, double *Ax, double *q, double *l, double *u, double *x) {
+    const auto &c = OsqpEigen::g_cap;
+    std::memcpy(Pp, c.Pp.data(), sizeof(int) * c.Pp.size()); std::memcpy(Pi, c.Pi.data(), sizeof(int) * c.Pi.size());
+    std::memcpy(Px, c.Px.data(), sizeof(double) * c.Px.size());
+    std::memcpy(Ap, c.Ap.data(), sizeof(int) * c.Ap.size()); std::memcpy(Ai, c.Ai.data(), sizeof(int) * c.Ai.size());
+    std::memcpy(Ax, c.Ax.data(), sizeof(double) * c.Ax.size());
+    std::memcpy(q, c.q.data(), sizeof(double) * c.q.size());
+    std::memcpy(l, c.l.data(), sizeof(double) * c.l.size()); std::memcpy(u, c.u.data(), sizeof(double) * c.u.size());
+    if (x && !c.x.empty()) std::memcpy(x, c.x.data(), sizeof(double) * c.x.size());
+}
+}

@@ -22,6 +22,8 @@ class PoParams(C.Structure):
         ("rho0", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double), ("adapt_tol", C.c_double),
         ("max_iter", C.c_int), ("check_every", C.c_int), ("adapt_every", C.c_int), ("enable_collision_check", C.c_int),
         ("car_width", C.c_double), ("car_length", C.c_double), ("rear_axle_to_center", C.c_double), ("safety_margin", C.c_double),
+        ("t2_w_dev", C.c_double), ("t2_w_curv", C.c_double), ("t2_w_curv_rate", C.c_double),
+        ("cart_w_curv", C.c_double), ("cart_w_curv_rate", C.c_double), ("cart_w_dev", C.c_double),
     ]
 
 
@@ -54,3 +56,16 @@ class PoBoundsIn(C.Structure):
     _fields_ = [("B", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("ref_x", C.c_void_p), ("ref_y", C.c_void_p), ("ref_z", C.c_void_p), ("ref_s", C.c_void_p), ("n_points", C.c_void_p),
                 ("knot_s", C.c_void_p), ("knot_x", C.c_void_p), ("knot_y", C.c_void_p), ("n_knots", C.c_void_p)]
+
+
+PO_SMOOTH_TENSION2, PO_SMOOTH_TENSION, PO_SMOOTH_POST = 0, 1, 2
+
+
+class PoSmoothIn(C.Structure):
+    _fields_ = [("kind", C.c_int), ("B", C.c_int), ("P", C.c_int), ("n_points", C.c_void_p),
+                ("x", C.c_void_p), ("y", C.c_void_p), ("angle", C.c_void_p), ("k", C.c_void_p), ("s", C.c_void_p),
+                ("lb", C.c_void_p), ("ub", C.c_void_p), ("l0", C.c_void_p)]
+
+
+class PoSmoothOut(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("s", C.c_void_p), ("info", C.c_void_p), ("raw", C.c_void_p)]

@@ -19,7 +19,8 @@ _LIB = None
 
 EXPORTS = ["po_default_params", "po_problem_dims", "po_keep_control_steps", "po_create", "po_destroy", "po_set_stream",
            "po_solve_batch", "po_solve_batch_device", "po_assemble_batch", "po_scaling_batch", "po_last_kernel_ms", "po_strerror",
-           "po_last_hip_error", "po_version"]
+           "po_last_hip_error", "po_version", "po_set_map", "po_postcheck_batch", "po_postcheck_batch_device", "po_bounds_batch",
+           "po_bounds_batch_device", "po_map_sample", "po_smooth_dims", "po_smooth_batch", "po_smooth_batch_device"]
 
 
 class PoError(RuntimeError):
@@ -71,6 +72,12 @@ def problem_dims(form: int, N: int, keep: int):
     n, m, c = C.c_int(), C.c_int(), C.c_int()
     _check(lib().po_problem_dims(form, N, keep, C.byref(n), C.byref(m), C.byref(c)))
     return n.value, m.value, c.value
+
+
+def smooth_dims(kind: int, P: int):
+    n, m = C.c_int(), C.c_int()
+    _check(lib().po_smooth_dims(kind, P, C.byref(n), C.byref(m)))
+    return n.value, m.value
 
 
 def keep_control_steps(form: int, ref_s) -> int:
@@ -202,6 +209,33 @@ class Engine:
         p = lambda k: None if t.get(k) is None else C.c_void_p(t[k].data_ptr())
         bi = PoBoundsIn(B, N, K, p("ref_x"), p("ref_y"), p("ref_z"), p("ref_s"), p("n_points"), p("knot_s"), p("knot_x"), p("knot_y"), p("n_knots"))
         _check(lib().po_bounds_batch_device(self._h, C.byref(bi), C.c_void_p(bounds.data_ptr()), C.c_void_p(n_valid.data_ptr())))
+
+    # ---- reference-smoothing QPs ----
+    def smooth_batch(self, kind: int, inp: dict, want_raw: bool = False):
+        """Host-pointer entry. inp: dict of [B,P] arrays x, y, angle, k, s (TENSION2 / TENSION) or s, lb, ub + l0 [B] (POST), optional
+        n_points [B] (synth.make_smooth_inputs).  Returns out_x, out_y, out_s [B,P], info [B] (+ raw [B,n_max] in the reference order)."""
+        from .abi import PoSmoothIn, PoSmoothOut
+
+        f = lambda k: None if inp.get(k) is None else np.ascontiguousarray(inp[k], dtype=np.float64)
+        arr = {k: f(k) for k in ("x", "y", "angle", "k", "s", "lb", "ub", "l0")}
+        B, P = arr["s"].shape
+        si = PoSmoothIn(kind, B, P, _np(_i32(inp.get("n_points"))), *[_np(arr[k]) for k in ("x", "y", "angle", "k", "s", "lb", "ub", "l0")])
+        ox = np.zeros((B, P)); oy = np.zeros((B, P)); os_ = np.zeros((B, P))
+        info = np.zeros(B, dtype=INFO_DTYPE)
+        raw = np.zeros((B, smooth_dims(kind, P)[0])) if want_raw else None
+        so = PoSmoothOut(_np(ox), _np(oy), _np(os_), _np(info), _np(raw))
+        _check(lib().po_smooth_batch(self._h, C.byref(si), C.byref(so)))
+        return ox, oy, os_, info, raw
+
+    def smooth_batch_device(self, kind: int, t: dict, out: dict):
+        """Device-pointer entry: t / out hold torch tensors (keys as above; out: x, y, s [B,P] f64, info [B,48] u8, optional raw)."""
+        from .abi import PoSmoothIn, PoSmoothOut
+
+        B, P = t["s"].shape
+        p = lambda d, k: None if d.get(k) is None else C.c_void_p(d[k].data_ptr())
+        si = PoSmoothIn(kind, B, P, p(t, "n_points"), *[p(t, k) for k in ("x", "y", "angle", "k", "s", "lb", "ub", "l0")])
+        so = PoSmoothOut(p(out, "x"), p(out, "y"), p(out, "s"), p(out, "info"), p(out, "raw"))
+        _check(lib().po_smooth_batch_device(self._h, C.byref(si), C.byref(so)))
 
     def map_sample(self, xy):
         xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)

@@ -10,10 +10,12 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/po_hip.h"
 #include "po_device.hpp"
 #include "po_map.hpp"
+#include "po_smooth.hpp"
 
 extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out);
 extern "C" hipError_t po_launch_scale(int form, const po::DevBatch *in, const po::DevParams *P, int passes, double *sc, hipStream_t st);
@@ -22,6 +24,9 @@ extern "C" size_t po_lds_bytes(int form, int N, int C, int keep);
 extern "C" hipError_t po_launch_postcheck(const po::DevMap *m, const po::DevCar *c, int B, int N, const int *n_points, const double *states,
                                           const po_info *info, int *n_valid, int *ok, hipStream_t st);
 extern "C" hipError_t po_launch_bounds(const po::DevMap *m, const po::DevBounds *in, double *bounds, int *n_valid, hipStream_t st);
+extern "C" hipError_t po_launch_smooth(const po::DevSmooth *a, hipStream_t st);
+extern "C" size_t po_smooth_lds_bytes(int kind, int P);
+extern "C" size_t po_smooth_scratch_doubles(int kind, int P);
 extern "C" hipError_t po_launch_map_sample(const po::DevMap *m, int n, const double *xy, double *dist, int *inside, hipStream_t st);
 
 namespace {
@@ -62,7 +67,7 @@ struct po_handle_s {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    DevBuf in_buf, out_buf, asm_buf, scale_buf, dbg_buf, map_buf, post_buf, coef_buf, bnd_buf;
+    DevBuf in_buf, out_buf, asm_buf, scale_buf, dbg_buf, map_buf, post_buf, coef_buf, bnd_buf, smooth_buf, smooth_io;
     po::DevMap map{};  // obstacle-distance layer (po_set_map); map.d == nullptr until set
     std::mutex mu;
 };
@@ -91,6 +96,9 @@ void po_default_params(po_params *p) {
     p->eps_abs = 1e-4; p->eps_rel = 1e-4; p->eps_prim_inf = 1e-4; p->eps_dual_inf = 1e-4;
     p->rho0 = 0.1; p->sigma = 1e-6; p->alpha = 1.6; p->adapt_tol = 5.0;
     p->max_iter = 4000; p->check_every = 25; p->adapt_every = 100;
+    // reference-smoothing QPs, planning_flags.cpp:76-86
+    p->t2_w_dev = 0.005; p->t2_w_curv = 1; p->t2_w_curv_rate = 10;
+    p->cart_w_curv = 1; p->cart_w_curv_rate = 50; p->cart_w_dev = 0.0;
 }
 
 int po_problem_dims(int form, int N, int keep, int *n, int *m, int *C) {
@@ -150,7 +158,7 @@ int po_destroy(po_handle h) {
     if (!h) return PO_ERR_INVALID;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    h->in_buf.release(); h->out_buf.release(); h->asm_buf.release(); h->scale_buf.release(); h->dbg_buf.release(); h->map_buf.release(); h->post_buf.release(); h->coef_buf.release(); h->bnd_buf.release();
+    h->in_buf.release(); h->out_buf.release(); h->asm_buf.release(); h->scale_buf.release(); h->dbg_buf.release(); h->map_buf.release(); h->post_buf.release(); h->coef_buf.release(); h->bnd_buf.release(); h->smooth_buf.release(); h->smooth_io.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -497,6 +505,114 @@ int po_bounds_batch(po_handle h, const po_bounds_in *in, double *bounds, int *n_
     std::lock_guard<std::mutex> g(h->mu);
     HIP_TRY(hipMemcpyAsync(bounds, dout, bo, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(n_valid, pi + 2 * in->B, bi, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PO_OK;
+}
+
+// ---- reference-smoothing QPs -----------------------------------------------------------------------
+int po_smooth_dims(int kind, int P, int *n, int *m) {
+    int nn, mm;
+    if (kind == PO_SMOOTH_TENSION2) { if (P < 3) return PO_ERR_INVALID; nn = 4 * P - 1; mm = 3 * (P - 1) + 2; }  // tension_smoother_2.cpp:177-178
+    else if (kind == PO_SMOOTH_TENSION) { if (P < 3) return PO_ERR_INVALID; nn = 3 * P; mm = 3 * P; }            // tension_smoother.cpp:201-202
+    else if (kind == PO_SMOOTH_POST) { if (P < 4) return PO_ERR_INVALID; nn = 3 * P; mm = 3 * P - 2; }           // reference_path_smoother.cpp:536,544-545
+    else return PO_ERR_INVALID;
+    if (n) *n = nn;
+    if (m) *m = mm;
+    return PO_OK;
+}
+
+static int smooth_args_ok(const po_smooth_in *in, const po_smooth_out *out) {
+    if (!in || !out || in->B < 0) return 0;
+    if (po_smooth_dims(in->kind, in->P, nullptr, nullptr)) return 0;
+    if (in->B == 0) return 1;
+    if (!in->s || !out->x || !out->info) return 0;
+    if (in->kind == PO_SMOOTH_POST) return in->lb && in->ub && in->l0;
+    return in->x && in->y && in->angle && in->k && out->y && out->s;
+}
+
+int po_smooth_batch_device(po_handle h, const po_smooth_in *in, const po_smooth_out *out) {
+    if (!h || !smooth_args_ok(in, out)) return PO_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (in->kind == PO_SMOOTH_TENSION && !h->map.d) return PO_ERR_INVALID;  // po_set_map first (clearance of every point)
+    if (in->B == 0) return PO_OK;
+    if (po_smooth_lds_bytes(in->kind, in->P) > 160 * 1024) return PO_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(h->device));
+    po::DevSmooth D{};
+    D.kind = in->kind; D.B = in->B; D.P = in->P; D.n_points = in->n_points;
+    D.x = in->x; D.y = in->y; D.angle = in->angle; D.k = in->k; D.s = in->s; D.lb = in->lb; D.ub = in->ub; D.l0 = in->l0;
+    D.out_x = out->x; D.out_y = out->y; D.out_s = out->s; D.info = out->info; D.raw = out->raw;
+    int nmax = 0;
+    po_smooth_dims(in->kind, in->P, &nmax, nullptr);
+    D.raw_stride = nmax;
+    const po_params &p = h->params;
+    const double w[6] = {p.t2_w_dev, p.t2_w_curv, p.t2_w_curv_rate, p.cart_w_curv, p.cart_w_curv_rate, p.cart_w_dev};
+    for (int i = 0; i < 6; ++i) D.w[i] = w[i];
+    D.sigma = p.sigma; D.alpha = p.alpha; D.rho0 = p.rho0; D.eps_abs = p.eps_abs; D.eps_rel = p.eps_rel;
+    D.eps_pinf = p.eps_prim_inf; D.eps_dinf = p.eps_dual_inf; D.adapt_tol = p.adapt_tol;
+    D.max_iter = p.max_iter; D.check_every = p.check_every; D.adapt_every = p.adapt_every; D.scaling = p.scaling;
+    D.scratch_stride = po_smooth_scratch_doubles(in->kind, in->P);
+    if (int rc = h->smooth_buf.ensure(sizeof(double) * D.scratch_stride * (size_t)in->B)) return rc;
+    D.scratch = static_cast<double *>(h->smooth_buf.p);
+    D.map = h->map;
+    const bool dbg = std::getenv("PO_SMOOTH_DEBUG") != nullptr;  // dev tool: per-phase cycle totals of instance 0..B-1 printed to stderr
+    if (dbg) {
+        if (int rc = h->dbg_buf.ensure(sizeof(long long) * 8 * (size_t)in->B)) return rc;
+        D.dbg_cycles = static_cast<long long *>(h->dbg_buf.p);
+    }
+    if (h->timed) HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    HIP_TRY(po_launch_smooth(&D, h->stream));
+    if (dbg) {
+        std::vector<long long> hc(8 * (size_t)in->B);
+        HIP_TRY(hipMemcpyAsync(hc.data(), D.dbg_cycles, sizeof(long long) * hc.size(), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        double tot[8] = {0};
+        for (int b = 0; b < in->B; ++b) for (int i = 0; i < 8; ++i) tot[i] += (double)hc[8 * (size_t)b + i];
+        std::fprintf(stderr, "po_smooth kind %d: mean cycles/instance setup %.0f factor %.0f rhs %.0f solve %.0f update %.0f check %.0f out %.0f\n", in->kind,
+                     tot[0] / in->B, tot[1] / in->B, tot[2] / in->B, tot[3] / in->B, tot[4] / in->B, tot[5] / in->B, tot[6] / in->B);
+    }
+    if (h->timed) HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    return PO_OK;
+}
+
+int po_smooth_batch(po_handle h, const po_smooth_in *in, const po_smooth_out *out) {
+    if (!h || !smooth_args_ok(in, out)) return PO_ERR_INVALID;
+    if (in->B == 0) return PO_OK;
+    int nmax = 0;
+    po_smooth_dims(in->kind, in->P, &nmax, nullptr);
+    const size_t bp = sizeof(double) * (size_t)in->B * in->P, bb = sizeof(double) * (size_t)in->B, bi = sizeof(int) * (size_t)in->B;
+    const size_t binfo = sizeof(po_info) * (size_t)in->B, braw = out->raw ? sizeof(double) * (size_t)in->B * nmax : 0;
+    char *base = nullptr;
+    const void *src[7] = {in->x, in->y, in->angle, in->k, in->s, in->lb, in->ub};
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        HIP_TRY(hipSetDevice(h->device));
+        if (int rc = h->smooth_io.ensure(10 * bp + bb + bi + binfo + braw + 64)) return rc;
+        base = static_cast<char *>(h->smooth_io.p);
+        for (int i = 0; i < 7; ++i)
+            if (src[i]) HIP_TRY(hipMemcpyAsync(base + i * bp, src[i], bp, hipMemcpyHostToDevice, h->stream));
+        if (in->l0) HIP_TRY(hipMemcpyAsync(base + 10 * bp, in->l0, bb, hipMemcpyHostToDevice, h->stream));
+        if (in->n_points) HIP_TRY(hipMemcpyAsync(base + 10 * bp + bb + binfo + braw, in->n_points, bi, hipMemcpyHostToDevice, h->stream));
+    }
+    po_smooth_in d = *in;
+    const double *pd = reinterpret_cast<const double *>(base);
+    const size_t np = (size_t)in->B * in->P;
+    d.x = in->x ? pd : nullptr; d.y = in->y ? pd + np : nullptr; d.angle = in->angle ? pd + 2 * np : nullptr; d.k = in->k ? pd + 3 * np : nullptr;
+    d.s = pd + 4 * np; d.lb = in->lb ? pd + 5 * np : nullptr; d.ub = in->ub ? pd + 6 * np : nullptr;
+    d.l0 = in->l0 ? reinterpret_cast<const double *>(base + 10 * bp) : nullptr;
+    d.n_points = in->n_points ? reinterpret_cast<const int *>(base + 10 * bp + bb + binfo + braw) : nullptr;
+    po_smooth_out dout{};
+    double *po_ = reinterpret_cast<double *>(base + 7 * bp);
+    dout.x = po_; dout.y = po_ + np; dout.s = po_ + 2 * np;
+    dout.info = reinterpret_cast<po_info *>(base + 10 * bp + bb);
+    dout.raw = out->raw ? reinterpret_cast<double *>(base + 10 * bp + bb + binfo) : nullptr;
+    const int rc = po_smooth_batch_device(h, &d, &dout);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIP_TRY(hipMemcpyAsync(out->x, dout.x, bp, hipMemcpyDeviceToHost, h->stream));
+    if (out->y) HIP_TRY(hipMemcpyAsync(out->y, dout.y, bp, hipMemcpyDeviceToHost, h->stream));
+    if (out->s) HIP_TRY(hipMemcpyAsync(out->s, dout.s, bp, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(out->info, dout.info, binfo, hipMemcpyDeviceToHost, h->stream));
+    if (out->raw) HIP_TRY(hipMemcpyAsync(out->raw, dout.raw, braw, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return PO_OK;
 }

@@ -1,0 +1,738 @@
+// po_smooth.hip — the reference-smoothing QPs on gfx950: one generic banded-QP ADMM engine, three assemblies.
+//
+// Reference (same OsqpEigen call pattern as the hot path: setHessianMatrix ... initSolver, solve):
+//   TENSION2  TensionSmoother2::osqpSmooth       /root/reference/src/reference_path_smoother/tension_smoother_2.cpp:163-301
+//   TENSION   TensionSmoother::osqpSmooth        /root/reference/src/reference_path_smoother/tension_smoother.cpp:186-314
+//   POST      ReferencePathSmoother::postSmooth  /root/reference/src/reference_path_smoother/reference_path_smoother.cpp:534-650
+//
+// Mapping: one wavefront (one 64-thread block) per QP, whole solve on chip.
+//   * variables are re-ordered point by point (x_i, y_i, theta_i, k_i | x_i, y_i, d_i | x_i, dx_i, ddx_i), so that the reduced
+//     KKT matrix  M = P + sigma I + A' diag(rho) A  is BANDED with half-bandwidth W = 4 / 9 / 3;
+//   * A lives in LDS as a row-wise ELL (<= 3 entries per row) plus a transposed index list per variable (<= 4 rows), built once;
+//   * OSQP's Ruiz equilibration (10 passes over the KKT column norms + cost scaling) runs literally, lanes over columns/rows;
+//   * banded LDL' of M: right-looking, the W(W+1)/2 trailing updates of a column on separate lanes;
+//   * per iteration: rhs (lanes over variables), forward/backward substitution (one lane, register sliding window, factor column
+//     read as 16-byte pairs), relaxation + projection + dual update in the one-number-per-row form v = z + y/rho (lanes over rows);
+//   * termination / infeasibility certificates / adaptive rho exactly as OSQP (unscaled residuals every `check_every` iterations).
+// The scaled P band, D and E (needed only at checks and refactorisations) stay in an HBM scratch block per QP.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/po_hip.h"
+#define PO_MAP_DEVICE_CODE
+#include "po_device.hpp"
+#include "po_map.hpp"
+#include "po_smooth.hpp"
+
+namespace po {
+
+template <int KIND> struct ST;
+template <> struct ST<PO_SMOOTH_TENSION2> {
+    static constexpr int W = 4, WP = 4, KA = 3, MINP = 3;
+    static __host__ __device__ int n(int P) { return 4 * P - 1; }
+    static __host__ __device__ int m(int P) { return 3 * (P - 1) + 2; }
+};
+template <> struct ST<PO_SMOOTH_TENSION> {
+    static constexpr int W = 9, WP = 9, KA = 2, MINP = 3;
+    static __host__ __device__ int n(int P) { return 3 * P; }
+    static __host__ __device__ int m(int P) { return 3 * P; }
+};
+template <> struct ST<PO_SMOOTH_POST> {
+    static constexpr int W = 3, WP = 0, KA = 3, MINP = 4;
+    static __host__ __device__ int n(int P) { return 3 * P; }
+    static __host__ __device__ int m(int P) { return 3 * P - 2; }
+};
+constexpr int kKT = 4;  // a variable appears in at most 4 rows in all three QPs
+
+template <int W> __host__ __device__ constexpr int col_stride() { return (W + 2) & ~1; }  // dinv + W entries, padded to 16 bytes
+template <int W> __host__ __device__ constexpr int col_pad() { return 4 * W; }            // zero columns past n: the sweeps need no guards
+
+// LDS carve-up (doubles first, then 16-bit and 8-bit tables)
+template <int KIND> struct Lds {
+    using T = ST<KIND>;
+    static constexpr int LS = col_stride<T::W>();
+    static __host__ __device__ size_t bytes(int P) {
+        const size_t n = (size_t)T::n(P), m = (size_t)T::m(P), np = n + col_pad<T::W>();
+        size_t d = np * LS + (size_t)T::KA * m + 2 * n + np + 4 * m;  // Lb, Av, x, q, wk, v, l, u, tm
+        size_t b = d * 8 + ((size_t)T::KA * m + (size_t)kKT * n) * 2 + n * 4 + m + 8;
+        return (b + 15) & ~(size_t)15;
+    }
+};
+
+__device__ __forceinline__ double lim_scaling(double v) {  // OSQP limit_scaling: MIN_SCALING 1e-4 -> 1, MAX_SCALING 1e4
+    v = v < 1e-4 ? 1.0 : v;
+    return v > 1e4 ? 1e4 : v;
+}
+
+template <int KIND> struct Prob {  // views into LDS + scratch for one QP
+    using T = ST<KIND>;
+    static constexpr int W = T::W, LS = col_stride<T::W>(), KA = T::KA;
+    int n, m, np;
+    double *Lb, *Av, *x, *q, *wk, *v, *l, *u, *tm;
+    uint16_t *Ac, *Tl;
+    int *Tc;
+    uint8_t *cls;
+    double *Pb, *Dv, *Ev;  // HBM scratch: Pb[d*n + j] = P[j][j+d] (scaled), D[n], E[m]
+    __device__ __forceinline__ void setA(int r, int s, int col, double val) { Av[s * m + r] = val; Ac[s * m + r] = (uint16_t)col; }
+    __device__ __forceinline__ void setRow(int r, double lo, double hi) { l[r] = lo; u[r] = hi; }
+    __device__ __forceinline__ void setP(int j, int d, double val) { Lb[j * LS + d] = val; }  // P band parked in the factor storage during setup
+};
+
+// ---- assemblies: rows in point order; values follow the reference expressions term by term ----------------------------------
+template <int KIND> __device__ void assemble(const DevSmooth &a, Prob<KIND> &pb, int b, int P, int lane) {
+    const size_t o = (size_t)b * a.P;
+    if constexpr (KIND == PO_SMOOTH_TENSION2) {
+        // tension_smoother_2.cpp:220-241 (Hessian), :288-299 (gradient), :243-286 (constraints)
+        const double wd = a.w[0], wc = a.w[1], wr = a.w[2];
+        for (int i = lane; i < P; i += 64) {
+            const double xi = a.x[o + i], yi = a.y[o + i];
+            pb.setP(4 * i, 0, wd * 2); pb.setP(4 * i + 1, 0, wd * 2); pb.setP(4 * i + 2, 0, 0.0);
+            pb.q[4 * i] = -2 * wd * xi; pb.q[4 * i + 1] = -2 * wd * yi; pb.q[4 * i + 2] = 0;
+            if (i < P - 1) {
+                double dk = wc * 2;  // blocks i-1 and i of the curvature-rate term touch k_i (blocks run 0..P-3)
+                if (i - 1 >= 0 && i - 1 <= P - 3) dk += 2 * wr;
+                if (i <= P - 3) dk += 2 * wr;
+                pb.setP(4 * i + 3, 0, dk);
+                pb.setP(4 * i + 3, 4, i <= P - 3 ? -2 * wr : 0.0);
+                pb.q[4 * i + 3] = 0;
+                const double ds = a.s[o + i + 1] - a.s[o + i], ang = a.angle[o + i];
+                const double sn = sin(ang), cs = cos(ang);
+                pb.setA(3 * i, 0, 4 * i + 4, 1.0); pb.setA(3 * i, 1, 4 * i, -1.0); pb.setA(3 * i, 2, 4 * i + 2, ds * sn);
+                pb.setRow(3 * i, ds * cs, ds * cs);
+                pb.setA(3 * i + 1, 0, 4 * i + 5, 1.0); pb.setA(3 * i + 1, 1, 4 * i + 1, -1.0); pb.setA(3 * i + 1, 2, 4 * i + 2, -ds * cs);
+                pb.setRow(3 * i + 1, ds * sn, ds * sn);
+                pb.setA(3 * i + 2, 0, 4 * i + 6, 1.0); pb.setA(3 * i + 2, 1, 4 * i + 2, -1.0); pb.setA(3 * i + 2, 2, 4 * i + 3, -ds);
+                const double bk = -ds * a.k[o + i];
+                pb.setRow(3 * i + 2, bk, bk);
+            }
+        }
+        if (lane == 0) {
+            const int r = 3 * (P - 1);
+            pb.setA(r, 0, 0, 1.0); pb.setA(r, 1, 0, 0.0); pb.setA(r, 2, 0, 0.0); pb.setRow(r, a.x[o], a.x[o]);
+            pb.setA(r + 1, 0, 1, 1.0); pb.setA(r + 1, 1, 1, 0.0); pb.setA(r + 1, 2, 1, 0.0); pb.setRow(r + 1, a.y[o], a.y[o]);
+        }
+    } else if constexpr (KIND == PO_SMOOTH_TENSION) {
+        // tension_smoother.cpp:238-261 (Hessian: [1 -2 1] and [-1 3 -3 1] stencils on x and on y), :263-314 (constraints)
+        const double wc = a.w[3], wcr = a.w[4], wdev = a.w[5];
+        const double v3[3] = {1, -2, 1}, v4[4] = {-1, 3, -3, 1};
+        for (int i = lane; i < P; i += 64) {
+            for (int e = 0; e <= 3; ++e) {  // H[i][i+e], accumulated block by block like the reference's loop
+                double acc = 0;
+                if (i + e < P)
+                    for (int k = (i + e - 3 > 0 ? i + e - 3 : 0); k <= i && k <= P - 3; ++k) {
+                        if (i + e - k <= 2) acc += v3[i - k] * v3[i + e - k] * wc;
+                        if (k != P - 3) acc += v4[i - k] * v4[i + e - k] * wcr;
+                    }
+                pb.setP(3 * i, 3 * e, acc); pb.setP(3 * i + 1, 3 * e, acc);
+            }
+            pb.setP(3 * i + 2, 0, wdev);
+            pb.q[3 * i] = 0; pb.q[3 * i + 1] = 0; pb.q[3 * i + 2] = 0;
+            const double xi = a.x[o + i], yi = a.y[o + i], th = a.angle[o + i] + kPi2;
+            pb.setA(3 * i, 0, 3 * i, 1.0); pb.setA(3 * i, 1, 3 * i + 2, -cos(th)); pb.setRow(3 * i, xi, xi);
+            pb.setA(3 * i + 1, 0, 3 * i + 1, 1.0); pb.setA(3 * i + 1, 1, 3 * i + 2, -sin(th)); pb.setRow(3 * i + 1, yi, yi);
+            pb.setA(3 * i + 2, 0, 3 * i + 2, 1.0); pb.setA(3 * i + 2, 1, 3 * i + 2, 0.0);
+            double lo, hi;
+            if (i == 0) { lo = 0; hi = 0; }
+            else if (i == P - 1) { lo = -0.5; hi = 0.5; }
+            else {
+                double c = map_distance(a.map, xi, yi);  // Map::getObstacleDistance, tension_smoother.cpp:303
+                c = c < 2.0 ? c : 2.0;
+                lo = -c; hi = c;
+            }
+            pb.setRow(3 * i + 2, lo, hi);
+        }
+    } else {
+        // reference_path_smoother.cpp:598-612 (Hessian), :614-650 (constraints)
+        for (int i = lane; i < P; i += 64) {
+            pb.setP(3 * i, 0, 1.0); pb.setP(3 * i + 1, 0, 100.0); pb.setP(3 * i + 2, 0, 1000.0);
+            pb.q[3 * i] = 0; pb.q[3 * i + 1] = 0; pb.q[3 * i + 2] = 0;
+            pb.setA(3 * i, 0, 3 * i, 1.0); pb.setA(3 * i, 1, 3 * i, 0.0); pb.setA(3 * i, 2, 3 * i, 0.0);
+            if (i == 0) pb.setRow(0, a.l0[b], a.l0[b]);
+            else pb.setRow(3 * i, a.lb[o + i], a.ub[o + i]);
+            if (i < P - 1) {
+                const double ds = a.s[o + i + 1] - a.s[o + i];
+                pb.setA(3 * i + 1, 0, 3 * i + 3, 1.0); pb.setA(3 * i + 1, 1, 3 * i, -1.0); pb.setA(3 * i + 1, 2, 3 * i + 1, -ds);
+                pb.setRow(3 * i + 1, 0.0, 0.0);
+                pb.setA(3 * i + 2, 0, 3 * i + 4, 1.0); pb.setA(3 * i + 2, 1, 3 * i + 1, -1.0); pb.setA(3 * i + 2, 2, 3 * i + 2, -ds);
+                pb.setRow(3 * i + 2, 0.0, 0.0);
+            }
+        }
+    }
+}
+
+// device variable index -> reference variable index (raw output)
+template <int KIND> __device__ __forceinline__ int ref_var(int j, int P) {
+    if constexpr (KIND == PO_SMOOTH_TENSION2) return (j & 3) * P + (j >> 2);
+    else return (j % 3) * P + j / 3;
+}
+
+template <int KIND> __device__ __forceinline__ double rho_row(const Prob<KIND> &pb, int r, double rho) {
+    const unsigned c = pb.cls[r];
+    return c == 0u ? rho : (c == 1u ? kRhoEqOverIneq * rho : kRhoMin);
+}
+
+// M = P + sigma I + A' diag(rho) A into the band storage, then right-looking banded LDL' (column j: dinv, L[j+1..j+W][j]).
+template <int KIND> __device__ void factorise(Prob<KIND> &pb, double rho, double sigma, int lane) {
+    using T = ST<KIND>;
+    constexpr int W = T::W, LS = Prob<KIND>::LS, KA = T::KA, WP = T::WP;
+    const int n = pb.n, m = pb.m;
+    for (int j = lane; j < pb.np; j += 64) {
+        double col[W + 1];
+#pragma unroll
+        for (int d = 0; d <= W; ++d) col[d] = 0;
+        if (j < n) {
+#pragma unroll
+            for (int d = 0; d <= WP; ++d) col[d] = (j + d < n) ? pb.Pb[(size_t)d * n + j] : 0.0;
+            col[0] += sigma;
+            const int cnt = pb.Tc[j];
+            for (int t = 0; t < cnt; ++t) {
+                const int code = pb.Tl[j * kKT + t], r = code >> 2, s = code & 3;
+                const double ra = rho_row(pb, r, rho) * pb.Av[s * m + r];
+#pragma unroll
+                for (int s2 = 0; s2 < KA; ++s2) {
+                    const int c2 = pb.Ac[s2 * m + r];
+                    const double a2 = pb.Av[s2 * m + r];
+                    const int d = c2 - j;
+                    if (d >= 0 && a2 != 0.0) {
+#pragma unroll
+                        for (int dd = 0; dd <= W; ++dd)
+                            if (dd == d) col[dd] += ra * a2;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d <= W; ++d) pb.Lb[j * LS + d] = col[d];
+    }
+    __syncthreads();
+    // lane -> (a, b), 1 <= a <= b <= W
+    constexpr int NPAIR = W * (W + 1) / 2;
+    int pa = 0, pbb = 0;
+    {
+        int t = lane;
+        for (int a = 1; a <= W; ++a) {
+            const int len = W - a + 1;
+            if (t >= 0 && t < len) { pa = a; pbb = a + t; }
+            t -= len;
+        }
+    }
+    for (int j = 0; j < n; ++j) {
+        const double d = pb.Lb[j * LS];
+        const double dinv = 1.0 / d;
+        double mine = 0;
+        if (lane >= 1 && lane <= W) mine = pb.Lb[j * LS + lane];
+        if (lane < NPAIR) {
+            const double ca = pb.Lb[j * LS + pa], cb = pb.Lb[j * LS + pbb];
+            pb.Lb[(j + pa) * LS + (pbb - pa)] -= ca * dinv * cb;
+        }
+        __syncthreads();
+        if (lane == 0) pb.Lb[j * LS] = dinv;
+        else if (lane <= W) pb.Lb[j * LS + lane] = mine * dinv;
+        __syncthreads();
+    }
+    for (int j = n + lane; j < pb.np; j += 64) {  // padding columns: the trailing updates of the last columns spilled into them
+#pragma unroll
+        for (int d = 0; d <= W; ++d) pb.Lb[j * LS + d] = 0;
+    }
+    __syncthreads();
+}
+
+// L D L' x = wk, in place, one lane.  Forward: column sweep with the W pending right-hand sides in registers; backward: row sweep.
+// Both sweeps run block-wise over W columns with the NEXT block's factor columns (and pending right-hand sides) already in flight:
+// a single wave per SIMD has nothing else to hide the LDS latency behind, so the loads are software-pipelined by hand (two register
+// sets, ping-pong, no branch between issue and use so that the compiler's s_waitcnt can count instead of draining the queue).
+template <int W, int LS> struct BandBlock {
+    double c[W][W + 1];
+    double b[W];
+    __device__ __forceinline__ void load(const double *__restrict__ Lb, const double *__restrict__ wk, int jcol, int jb) {
+#pragma unroll
+        for (int uu = 0; uu < W; ++uu) {
+            b[uu] = wk[jb + uu];
+#pragma unroll
+            for (int d = 0; d <= W; ++d) c[uu][d] = Lb[(jcol + uu) * LS + d];
+        }
+    }
+};
+template <int W, int LS> __device__ __forceinline__ void fwd_block(const BandBlock<W, LS> &k, double (&w)[W], double *__restrict__ wk, int j0) {
+#pragma unroll
+    for (int uu = 0; uu < W; ++uu) {
+        const double yj = w[uu % W];
+        wk[j0 + uu] = yj * k.c[uu][0];
+#pragma unroll
+        for (int d = 1; d < W; ++d) w[(uu + d) % W] -= k.c[uu][d] * yj;
+        w[uu % W] = k.b[uu] - k.c[uu][W] * yj;
+    }
+}
+template <int W, int LS> __device__ __forceinline__ void bwd_block(const BandBlock<W, LS> &k, double (&w)[W], double *__restrict__ wk, int j0) {
+#pragma unroll
+    for (int uu = W - 1; uu >= 0; --uu) {  // w[(j + d) % W] holds x_{j+d}, d = 1..W (slot j % W is the one being produced)
+        double acc = k.b[uu];
+#pragma unroll
+        for (int d = W; d >= 2; --d) acc -= k.c[uu][d] * w[(uu + d) % W];
+        acc -= k.c[uu][1] * w[(uu + 1) % W];
+        wk[j0 + uu] = acc;
+        w[uu % W] = acc;
+    }
+}
+template <int KIND> __device__ __forceinline__ void band_solve(Prob<KIND> &pb) {
+    using T = ST<KIND>;
+    constexpr int W = T::W, LS = Prob<KIND>::LS;
+    const int nsteps = (pb.n + 2 * W - 1) / (2 * W) * (2 * W);  // an even number of W-blocks; the zero padding (col_pad) covers the over-run
+    const double *__restrict__ Lb = pb.Lb;
+    double *__restrict__ wk = pb.wk;
+    double w[W];
+    BandBlock<W, LS> A, B;
+#pragma unroll
+    for (int d = 0; d < W; ++d) w[d] = wk[d];
+    A.load(Lb, wk, 0, W);
+    for (int j0 = 0; j0 < nsteps; j0 += 2 * W) {
+        B.load(Lb, wk, j0 + W, j0 + 2 * W);
+        fwd_block<W, LS>(A, w, wk, j0);
+        A.load(Lb, wk, j0 + 2 * W, j0 + 3 * W);
+        fwd_block<W, LS>(B, w, wk, j0 + W);
+    }
+#pragma unroll
+    for (int d = 0; d < W; ++d) w[d] = 0;
+    A.load(Lb, wk, nsteps - W, nsteps - W);
+    for (int j0 = nsteps - W; j0 >= 0; j0 -= 2 * W) {
+        B.load(Lb, wk, j0 - W, j0 - W);  // j0 - W >= 0: the block count is even
+        bwd_block<W, LS>(A, w, wk, j0);
+        const int jn = j0 - 2 * W > 0 ? j0 - 2 * W : 0;
+        A.load(Lb, wk, jn, jn);
+        bwd_block<W, LS>(B, w, wk, j0 - W);
+    }
+}
+
+#define PO_TICK(slot)                                                   \
+    do {                                                                \
+        if (a.dbg_cycles) { const long long t_ = clock64(); acc_[slot] += t_ - tprev_; tprev_ = t_; } \
+    } while (0)
+template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmooth a) {
+    long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = a.dbg_cycles ? clock64() : 0;
+    using T = ST<KIND>;
+    constexpr int W = T::W, LS = Prob<KIND>::LS, KA = T::KA, WP = T::WP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int P = a.n_points ? a.n_points[b] : a.P;
+    const size_t o = (size_t)b * a.P;
+    po_info info{};
+    info.status = PO_STATUS_UNSOLVED;
+    if (P < T::MINP || P > a.P) {  // misuse inside a device-pointer batch: no abort, flagged per instance
+        for (int i = lane; i < a.P; i += 64) {
+            a.out_x[o + i] = 0;
+            if (a.out_y) a.out_y[o + i] = 0;
+            if (a.out_s) a.out_s[o + i] = 0;
+        }
+        if (lane == 0) a.info[b] = info;
+        return;
+    }
+    Prob<KIND> pb;
+    const int n = pb.n = T::n(P), m = pb.m = T::m(P), np = pb.np = n + col_pad<W>();
+    {
+        double *dp = reinterpret_cast<double *>(smem_raw);
+        pb.Lb = dp; dp += (size_t)np * LS;
+        pb.Av = dp; dp += KA * m;
+        pb.x = dp; dp += n;
+        pb.q = dp; dp += n;
+        pb.wk = dp; dp += np;
+        pb.v = dp; dp += m;
+        pb.l = dp; dp += m;
+        pb.u = dp; dp += m;
+        pb.tm = dp; dp += m;
+        uint16_t *hp = reinterpret_cast<uint16_t *>(dp);
+        pb.Ac = hp; hp += KA * m;
+        pb.Tl = hp; hp += kKT * n;
+        pb.Tc = reinterpret_cast<int *>(reinterpret_cast<uintptr_t>(hp + 1) & ~(uintptr_t)3);
+        pb.cls = reinterpret_cast<uint8_t *>(pb.Tc + n);
+        double *sc = a.scratch + (size_t)b * a.scratch_stride;
+        pb.Pb = sc; pb.Dv = sc + (size_t)(WP + 1) * T::n(a.P); pb.Ev = pb.Dv + T::n(a.P);
+    }
+    for (int i = lane; i < np * LS; i += 64) pb.Lb[i] = 0;
+    for (int i = lane; i < np; i += 64) pb.wk[i] = 0;
+    for (int i = lane; i < n; i += 64) { pb.x[i] = 0; pb.Tc[i] = 0; }
+    for (int i = lane; i < m; i += 64) pb.v[i] = 0;
+    __syncthreads();
+    assemble<KIND>(a, pb, b, P, lane);
+    __syncthreads();
+
+    // ---- transposed index lists (variable -> rows), deterministic: count with LDS atomics, then sort each short list ----
+    for (int e = lane; e < KA * m; e += 64) {
+        const int s = e / m, r = e - s * m;
+        if (pb.Av[e] != 0.0) {
+            const int c = pb.Ac[e];
+            const int pos = atomicAdd(&pb.Tc[c], 1);
+            if (pos < kKT) pb.Tl[c * kKT + pos] = (uint16_t)(r * 4 + s);
+        }
+    }
+    __syncthreads();
+    for (int j = lane; j < n; j += 64) {
+        const int cnt = pb.Tc[j] < kKT ? pb.Tc[j] : kKT;
+        pb.Tc[j] = cnt;
+        for (int i = 1; i < cnt; ++i) {
+            const uint16_t key = pb.Tl[j * kKT + i];
+            int k = i - 1;
+            while (k >= 0 && pb.Tl[j * kKT + k] > key) { pb.Tl[j * kKT + k + 1] = pb.Tl[j * kKT + k]; --k; }
+            pb.Tl[j * kKT + k + 1] = key;
+        }
+    }
+    __syncthreads();
+
+    // ---- data validation (OSQP validate_data: l <= u, else setup fails and the reference's initSolver() returns false) ----
+    {
+        double bad = 0;
+        for (int r = lane; r < m; r += 64) bad = fmax(bad, pb.l[r] > pb.u[r] ? 1.0 : 0.0);
+        bad = wave_max(bad);
+        if (bad > 0) {
+            for (int i = lane; i < a.P; i += 64) {
+                a.out_x[o + i] = 0;
+                if (a.out_y) a.out_y[o + i] = 0;
+                if (a.out_s) a.out_s[o + i] = 0;
+            }
+            if (a.raw) for (int j = lane; j < a.raw_stride; j += 64) a.raw[(size_t)b * a.raw_stride + j] = 0;
+            info.status = PO_STATUS_PRIMAL_INFEASIBLE;
+            info.rho = a.rho0;
+            if (lane == 0) a.info[b] = info;
+            return;
+        }
+    }
+
+    // ---- Ruiz equilibration (OSQP scale_data), P band parked in Lb, D in wk-free storage: Dv/Ev in scratch ----
+    double cscale = 1.0;
+    for (int j = lane; j < n; j += 64) pb.Dv[j] = 1.0;
+    for (int r = lane; r < m; r += 64) pb.Ev[r] = 1.0;
+    for (int pass = 0; pass < a.scaling; ++pass) {
+        for (int j = lane; j < n; j += 64) {  // column inf-norm of [P; A]
+            double cn = 0;
+#pragma unroll
+            for (int d = 0; d <= WP; ++d) {
+                cn = fmax(cn, fabs(pb.Lb[j * LS + d]));
+                if (d > 0 && j - d >= 0) cn = fmax(cn, fabs(pb.Lb[(j - d) * LS + d]));
+            }
+            const int cnt = pb.Tc[j];
+            for (int t = 0; t < cnt; ++t) {
+                const int code = pb.Tl[j * kKT + t];
+                cn = fmax(cn, fabs(pb.Av[(code & 3) * m + (code >> 2)]));
+            }
+            pb.wk[j] = 1.0 / sqrt(lim_scaling(cn));
+        }
+        for (int r = lane; r < m; r += 64) {
+            double rn = 0;
+#pragma unroll
+            for (int s = 0; s < KA; ++s) rn = fmax(rn, fabs(pb.Av[s * m + r]));
+            pb.tm[r] = 1.0 / sqrt(lim_scaling(rn));
+        }
+        __syncthreads();
+        for (int j = lane; j < n; j += 64) {
+            const double dj = pb.wk[j];
+#pragma unroll
+            for (int d = 0; d <= WP; ++d)
+                if (j + d < n) pb.Lb[j * LS + d] *= dj * pb.wk[j + d];
+            pb.q[j] *= dj;
+            pb.Dv[j] *= dj;
+        }
+        for (int r = lane; r < m; r += 64) {
+            const double er = pb.tm[r];
+#pragma unroll
+            for (int s = 0; s < KA; ++s) pb.Av[s * m + r] *= pb.wk[pb.Ac[s * m + r]] * er;
+            pb.Ev[r] *= er;
+        }
+        __syncthreads();
+        double csum = 0, qn = 0;  // cost scaling: mean column norm of P vs ||q||_inf
+        for (int j = lane; j < n; j += 64) {
+            double cn = 0;
+#pragma unroll
+            for (int d = 0; d <= WP; ++d) {
+                cn = fmax(cn, fabs(pb.Lb[j * LS + d]));
+                if (d > 0 && j - d >= 0) cn = fmax(cn, fabs(pb.Lb[(j - d) * LS + d]));
+            }
+            csum += cn;
+            qn = fmax(qn, fabs(pb.q[j]));
+        }
+        csum = wave_sum(csum) / n;
+        qn = lim_scaling(wave_max(qn));
+        double ct = csum > qn ? csum : qn;
+        ct = 1.0 / lim_scaling(ct);
+        __syncthreads();
+        for (int j = lane; j < n; j += 64) {
+#pragma unroll
+            for (int d = 0; d <= WP; ++d) pb.Lb[j * LS + d] *= ct;
+            pb.q[j] *= ct;
+        }
+        cscale *= ct;
+        __syncthreads();
+    }
+    const double cinv = 1.0 / cscale;
+    for (int j = lane; j < n; j += 64) {  // park the scaled P band in HBM; the band storage becomes the factor
+#pragma unroll
+        for (int d = 0; d <= WP; ++d) pb.Pb[(size_t)d * n + j] = pb.Lb[j * LS + d];
+    }
+    for (int r = lane; r < m; r += 64) {
+        const double e = pb.Ev[r];
+        const double lo = pb.l[r] * e, hi = pb.u[r] * e;
+        pb.l[r] = lo; pb.u[r] = hi;
+        pb.cls[r] = (uint8_t)((lo < -kInfThresh && hi > kInfThresh) ? 2u : ((hi - lo < kRhoTol) ? 1u : 0u));  // set_rho_vec
+    }
+    for (int i = lane; i < np; i += 64) pb.wk[i] = 0;
+    __threadfence_block();
+    __syncthreads();
+
+    PO_TICK(0);
+    double rho = fmin(fmax(a.rho0, kRhoMin), kRhoMax);
+    factorise<KIND>(pb, rho, a.sigma, lane);
+    PO_TICK(1);
+
+    // ---- ADMM (OSQP osqp_solve, cold start) ----
+    int iter = 0, n_refactor = 0, status = PO_STATUS_UNSOLVED;
+    double pri_res = 0, dua_res = 0;
+    const double alpha = a.alpha, sigma = a.sigma;
+    for (iter = 1; iter <= a.max_iter; ++iter) {
+        const bool first = iter == 1;
+        const bool can_check = a.check_every > 0 && (iter % a.check_every == 0);
+        const bool can_adapt = a.adapt_every > 0 && (iter % a.adapt_every == 0);
+        const bool last = iter == a.max_iter;
+        const bool term = can_check || last;
+        for (int j = lane; j < n; j += 64) {  // rhs = sigma x - q + A' rho (2 z - v)
+            double acc = sigma * pb.x[j] - pb.q[j];
+            const int cnt = pb.Tc[j];
+            for (int t = 0; t < cnt; ++t) {
+                const int code = pb.Tl[j * kKT + t], r = code >> 2, s = code & 3;
+                const double vv = pb.v[r];
+                const double z = first ? 0.0 : clipd(vv, pb.l[r], pb.u[r]);
+                acc += pb.Av[s * m + r] * (rho_row(pb, r, rho) * (2.0 * z - vv));
+            }
+            pb.wk[j] = acc;
+        }
+        __syncthreads();
+        PO_TICK(2);
+        if (lane == 0) band_solve<KIND>(pb);
+        __syncthreads();
+        PO_TICK(3);
+        for (int r = lane; r < m; r += 64) {  // ztilde = A xtilde ; v += alpha (ztilde - z)
+            double zt = 0;
+#pragma unroll
+            for (int s = 0; s < KA; ++s) zt += pb.Av[s * m + r] * pb.wk[pb.Ac[s * m + r]];
+            const double vv = pb.v[r];
+            const double z = first ? 0.0 : clipd(vv, pb.l[r], pb.u[r]);
+            const double vn = vv + alpha * (zt - z);
+            pb.v[r] = vn;
+            if (term) pb.tm[r] = rho_row(pb, r, rho) * ((vn - clipd(vn, pb.l[r], pb.u[r])) - (vv - z));  // delta y of this iteration
+        }
+        __syncthreads();
+        for (int j = lane; j < n; j += 64) {
+            const double xo = pb.x[j];
+            const double xn = xo + alpha * (pb.wk[j] - xo);
+            pb.x[j] = xn;
+            pb.wk[j] = xn - xo;  // delta x (dual-infeasibility certificate)
+        }
+        __syncthreads();
+        PO_TICK(4);
+        if (!(term || can_adapt)) continue;
+
+        // ---- update_info: residuals, unscaled (termination) and scaled (rho estimate) ----
+        double pr = 0, nz = 0, nAx = 0, prs = 0, nzs = 0, nAxs = 0;
+        for (int r = lane; r < m; r += 64) {
+            double ax = 0;
+#pragma unroll
+            for (int s = 0; s < KA; ++s) ax += pb.Av[s * m + r] * pb.x[pb.Ac[s * m + r]];
+            const double z = clipd(pb.v[r], pb.l[r], pb.u[r]);
+            const double ei = 1.0 / pb.Ev[r];
+            prs = fmax(prs, fabs(ax - z)); nzs = fmax(nzs, fabs(z)); nAxs = fmax(nAxs, fabs(ax));
+            pr = fmax(pr, ei * fabs(ax - z)); nz = fmax(nz, ei * fabs(z)); nAx = fmax(nAx, ei * fabs(ax));
+        }
+        double du = 0, nq = 0, nAty = 0, nPx = 0, dus = 0, nqs = 0, nAtys = 0, nPxs = 0;
+        for (int j = lane; j < n; j += 64) {
+            double px = 0;
+#pragma unroll
+            for (int d = 0; d <= WP; ++d) {
+                if (j + d < n) px += pb.Pb[(size_t)d * n + j] * pb.x[j + d];
+                if (d > 0 && j - d >= 0) px += pb.Pb[(size_t)d * n + j - d] * pb.x[j - d];
+            }
+            double aty = 0;
+            const int cnt = pb.Tc[j];
+            for (int t = 0; t < cnt; ++t) {
+                const int code = pb.Tl[j * kKT + t], r = code >> 2, s = code & 3;
+                const double vv = pb.v[r];
+                aty += pb.Av[s * m + r] * (rho_row(pb, r, rho) * (vv - clipd(vv, pb.l[r], pb.u[r])));
+            }
+            const double qq = pb.q[j], di = 1.0 / pb.Dv[j];
+            const double dres = px + qq + aty;
+            dus = fmax(dus, fabs(dres)); nqs = fmax(nqs, fabs(qq)); nAtys = fmax(nAtys, fabs(aty)); nPxs = fmax(nPxs, fabs(px));
+            du = fmax(du, di * fabs(dres)); nq = fmax(nq, di * fabs(qq)); nAty = fmax(nAty, di * fabs(aty)); nPx = fmax(nPx, di * fabs(px));
+        }
+        pr = wave_max(pr); nz = wave_max(nz); nAx = wave_max(nAx); prs = wave_max(prs); nzs = wave_max(nzs); nAxs = wave_max(nAxs);
+        du = wave_max(du); nq = wave_max(nq); nAty = wave_max(nAty); nPx = wave_max(nPx);
+        dus = wave_max(dus); nqs = wave_max(nqs); nAtys = wave_max(nAtys); nPxs = wave_max(nPxs);
+        pri_res = pr;
+        dua_res = cinv * du;
+        if (term) {
+            const double eps_prim = a.eps_abs + a.eps_rel * fmax(nz, nAx);
+            const double eps_dual = a.eps_abs + a.eps_rel * cinv * fmax(fmax(nq, nAty), nPx);
+            const bool prim_ok = pri_res < eps_prim, dual_ok = dua_res < eps_dual;  // strict, as OSQP
+            bool prim_inf = false, dual_inf = false;
+            if (!prim_ok) {  // is_primal_infeasible on delta y
+                double ndy = 0, lhs = 0;
+                for (int r = lane; r < m; r += 64) {
+                    double d = pb.tm[r];
+                    const bool uinf = pb.u[r] > kInfThresh, linf = pb.l[r] < -kInfThresh;
+                    if (uinf) d = linf ? 0.0 : fmin(d, 0.0);
+                    else if (linf) d = fmax(d, 0.0);
+                    pb.tm[r] = d;
+                    ndy = fmax(ndy, pb.Ev[r] * fabs(d));
+                    lhs += (uinf ? 0.0 : pb.u[r] * fmax(d, 0.0)) + (linf ? 0.0 : pb.l[r] * fmin(d, 0.0));
+                }
+                ndy = wave_max(ndy); lhs = wave_sum(lhs);
+                __syncthreads();
+                if (ndy > a.eps_pinf && lhs < -a.eps_pinf * ndy) {
+                    double na = 0;
+                    for (int j = lane; j < n; j += 64) {
+                        double s2 = 0;
+                        const int cnt = pb.Tc[j];
+                        for (int t = 0; t < cnt; ++t) {
+                            const int code = pb.Tl[j * kKT + t];
+                            s2 += pb.Av[(code & 3) * m + (code >> 2)] * pb.tm[code >> 2];
+                        }
+                        na = fmax(na, fabs(s2) / pb.Dv[j]);
+                    }
+                    prim_inf = wave_max(na) < a.eps_pinf * ndy;
+                }
+            }
+            if (!dual_ok && !prim_inf) {  // is_dual_infeasible on delta x
+                double ndx = 0, qdx = 0;
+                for (int j = lane; j < n; j += 64) { ndx = fmax(ndx, pb.Dv[j] * fabs(pb.wk[j])); qdx += pb.q[j] * pb.wk[j]; }
+                ndx = wave_max(ndx); qdx = wave_sum(qdx);
+                if (ndx > a.eps_dinf && qdx < -cscale * a.eps_dinf * ndx) {
+                    double npdx = 0;
+                    for (int j = lane; j < n; j += 64) {
+                        double px = 0;
+#pragma unroll
+                        for (int d = 0; d <= WP; ++d) {
+                            if (j + d < n) px += pb.Pb[(size_t)d * n + j] * pb.wk[j + d];
+                            if (d > 0 && j - d >= 0) px += pb.Pb[(size_t)d * n + j - d] * pb.wk[j - d];
+                        }
+                        npdx = fmax(npdx, fabs(px) / pb.Dv[j]);
+                    }
+                    if (wave_max(npdx) < cscale * a.eps_dinf * ndx) {
+                        double viol = 0;
+                        for (int r = lane; r < m; r += 64) {
+                            double adx = 0;
+#pragma unroll
+                            for (int s = 0; s < KA; ++s) adx += pb.Av[s * m + r] * pb.wk[pb.Ac[s * m + r]];
+                            adx /= pb.Ev[r];
+                            if ((pb.u[r] < kInfThresh && adx > a.eps_dinf * ndx) || (pb.l[r] > -kInfThresh && adx < -a.eps_dinf * ndx)) viol = 1.0;
+                        }
+                        dual_inf = wave_max(viol) == 0.0;
+                    }
+                }
+            }
+            if (prim_ok && dual_ok) { status = PO_STATUS_SOLVED; break; }
+            if (prim_inf) { status = PO_STATUS_PRIMAL_INFEASIBLE; break; }
+            if (dual_inf) { status = PO_STATUS_DUAL_INFEASIBLE; break; }
+        }
+        PO_TICK(5);
+        if (can_adapt) {  // compute_rho_estimate + adapt_rho on the scaled quantities
+            const double prn = prs / (fmax(nzs, nAxs) + 1e-10);
+            const double drn = dus / (fmax(fmax(nqs, nAtys), nPxs) + 1e-10);
+            double rho_new = rho * sqrt(prn / (drn + 1e-10));
+            rho_new = fmin(fmax(rho_new, kRhoMin), kRhoMax);
+            if (rho_new > rho * a.adapt_tol || rho_new < rho / a.adapt_tol) {
+                const double ratio = rho / rho_new;
+                for (int r = lane; r < m; r += 64) {  // keep z and y: v = z + y / rho_new
+                    if (pb.cls[r] == 2u) continue;
+                    const double vv = pb.v[r], z = clipd(vv, pb.l[r], pb.u[r]);
+                    pb.v[r] = z + ratio * (vv - z);
+                }
+                rho = rho_new;
+                __syncthreads();
+                factorise<KIND>(pb, rho, sigma, lane);
+                ++n_refactor;
+            }
+            PO_TICK(1);
+        }
+    }
+    if (iter > a.max_iter) {
+        iter = a.max_iter;
+        if (status == PO_STATUS_UNSOLVED) status = PO_STATUS_MAX_ITER;
+    }
+    __syncthreads();
+
+    // ---- unscale, objective, outputs ----
+    double obj = 0;
+    for (int j = lane; j < n; j += 64) {
+        double px = 0;
+#pragma unroll
+        for (int d = 0; d <= WP; ++d) {
+            if (j + d < n) px += pb.Pb[(size_t)d * n + j] * pb.x[j + d];
+            if (d > 0 && j - d >= 0) px += pb.Pb[(size_t)d * n + j - d] * pb.x[j - d];
+        }
+        obj += (0.5 * px + pb.q[j]) * pb.x[j];
+    }
+    obj = wave_sum(obj) * cinv;
+    for (int j = lane; j < n; j += 64) pb.wk[j] = pb.x[j] * pb.Dv[j];
+    __syncthreads();
+    if (a.raw) {
+        double *rw = a.raw + (size_t)b * a.raw_stride;
+        for (int j = lane; j < a.raw_stride; j += 64) rw[j] = 0;
+        __syncthreads();
+        for (int j = lane; j < n; j += 64) rw[ref_var<KIND>(j, P)] = pb.wk[j];
+    }
+    constexpr int NVV = KIND == PO_SMOOTH_TENSION2 ? 4 : 3;
+    for (int i = lane; i < a.P; i += 64) {
+        a.out_x[o + i] = i < P ? pb.wk[NVV * i] : 0.0;
+        if (a.out_y) a.out_y[o + i] = (KIND != PO_SMOOTH_POST && i < P) ? pb.wk[NVV * i + 1] : 0.0;
+        if (KIND == PO_SMOOTH_POST && a.out_s) a.out_s[o + i] = 0.0;
+    }
+    if (KIND != PO_SMOOTH_POST && a.out_s && lane == 0) {  // running chord length, tension_smoother_2.cpp:208-216
+        double tmp_s = 0;
+        for (int i = 0; i < a.P; ++i) {
+            if (i > 0 && i < P) {
+                const double ddx = pb.wk[NVV * i] - pb.wk[NVV * (i - 1)], ddy = pb.wk[NVV * i + 1] - pb.wk[NVV * (i - 1) + 1];
+                tmp_s += sqrt(ddx * ddx + ddy * ddy);
+            }
+            a.out_s[o + i] = i < P ? tmp_s : 0.0;
+        }
+    }
+    PO_TICK(6);
+    if (a.dbg_cycles && lane == 0)
+        for (int i = 0; i < 8; ++i) a.dbg_cycles[(size_t)b * 8 + i] = acc_[i];
+    if (lane == 0) {
+        info.status = status; info.iters = iter; info.n_refactor = n_refactor;
+        info.r_prim = pri_res; info.r_dual = dua_res; info.rho = rho; info.obj = obj;
+        a.info[b] = info;
+    }
+}
+
+template <int KIND> static hipError_t launch_kind(const DevSmooth &a, hipStream_t st, size_t lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&smooth_kernel<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(smooth_kernel<KIND>, dim3(a.B), dim3(64), lds, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace po
+
+extern "C" size_t po_smooth_lds_bytes(int kind, int P) {
+    switch (kind) {
+        case PO_SMOOTH_TENSION2: return po::Lds<PO_SMOOTH_TENSION2>::bytes(P);
+        case PO_SMOOTH_TENSION: return po::Lds<PO_SMOOTH_TENSION>::bytes(P);
+        case PO_SMOOTH_POST: return po::Lds<PO_SMOOTH_POST>::bytes(P);
+    }
+    return 0;
+}
+extern "C" size_t po_smooth_scratch_doubles(int kind, int P) {
+    switch (kind) {
+        case PO_SMOOTH_TENSION2: return (size_t)(4 + 2) * po::ST<PO_SMOOTH_TENSION2>::n(P) + po::ST<PO_SMOOTH_TENSION2>::m(P);
+        case PO_SMOOTH_TENSION: return (size_t)(9 + 2) * po::ST<PO_SMOOTH_TENSION>::n(P) + po::ST<PO_SMOOTH_TENSION>::m(P);
+        case PO_SMOOTH_POST: return (size_t)(0 + 2) * po::ST<PO_SMOOTH_POST>::n(P) + po::ST<PO_SMOOTH_POST>::m(P);
+    }
+    return 0;
+}
+extern "C" hipError_t po_launch_smooth(const po::DevSmooth *a, hipStream_t st) {
+    const size_t lds = po_smooth_lds_bytes(a->kind, a->P);
+    switch (a->kind) {
+        case PO_SMOOTH_TENSION2: return po::launch_kind<PO_SMOOTH_TENSION2>(*a, st, lds);
+        case PO_SMOOTH_TENSION: return po::launch_kind<PO_SMOOTH_TENSION>(*a, st, lds);
+        case PO_SMOOTH_POST: return po::launch_kind<PO_SMOOTH_POST>(*a, st, lds);
+    }
+    return hipErrorInvalidValue;
+}

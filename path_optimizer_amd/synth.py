@@ -187,3 +187,55 @@ def make_spline_paths(seed: int, B: int, N: int = 200, ds: float = 0.3, knot_ds:
         s = out["ref_s"][b]
         out["ref_x"][b] = np.interp(s, fine, x); out["ref_y"][b] = np.interp(s, fine, y); out["ref_z"][b] = np.interp(s, fine, z)
     return out
+
+
+def make_smooth_inputs(seed: int, B: int, P: int = 100, kind: int = 0, ragged: bool = False, jitter_ds: bool = False):
+    """Inputs of the reference-smoothing QPs in the layout of po_smooth_in.
+    kind 0/1 (TENSION2 / TENSION): the five lists ReferencePathSmoother::segmentRawReference hands to osqpSmooth
+    (/root/reference/src/reference_path_smoother/reference_path_smoother.cpp:50-91): a raw planner path = smooth curve + a lateral
+    wiggle of a few metres wavelength, sampled every 1.0 m (the reference's fixed delta_s), with heading and curvature of the raw
+    curve at the samples.  kind 2 (POST): layers_s_list_ every FLAGS_search_longitudial_spacing = 1.5 m (last gap shorter), corridor
+    bounds layers_bounds_ as graphSearchDp leaves them (multiples of 0.2 m around the chosen lattice node, within +-6 m), and the
+    vehicle's lateral offset.  jitter_ds: non-uniform spacing (test only).  Returns dict of [B,P] arrays (+ n_points if ragged)."""
+    rng = np.random.default_rng(np.random.SeedSequence([SEED0, 79, seed, kind]))
+    out = dict(x=np.zeros((B, P)), y=np.zeros((B, P)), angle=np.zeros((B, P)), k=np.zeros((B, P)), s=np.zeros((B, P)),
+               lb=np.zeros((B, P)), ub=np.zeros((B, P)), l0=np.zeros(B))
+    npts = np.full(B, P, dtype=np.int32)
+    for b in range(B):
+        n = P if not ragged else int(rng.integers(max(4, P // 3), P + 1))
+        npts[b] = n
+        if kind == 2:
+            gaps = np.full(n - 1, 1.5)
+            gaps[-1] = rng.uniform(0.2, 1.5)
+            if jitter_ds:
+                gaps *= rng.uniform(0.6, 1.2, n - 1)
+            s = np.concatenate(([0.0], np.cumsum(gaps)))
+            centre = 1.5 * np.sin(2 * math.pi * s / rng.uniform(25, 60) + rng.uniform(0, 6.28)) * rng.uniform(0, 1)
+            lo = centre - 0.2 * rng.integers(2, 12, n)
+            hi = centre + 0.2 * rng.integers(2, 12, n)
+            out["lb"][b, :n] = np.maximum(np.round(lo / 0.2) * 0.2, -6.0)
+            out["ub"][b, :n] = np.minimum(np.round(hi / 0.2) * 0.2, 6.0)
+            out["lb"][b, 0], out["ub"][b, 0] = -10.0, 10.0
+            out["l0"][b] = rng.uniform(-0.5, 0.5)
+            out["s"][b, :n] = s
+            continue
+        gaps = np.ones(n - 1)
+        if jitter_ds:
+            gaps = rng.uniform(0.6, 1.4, n - 1)
+        s = np.concatenate(([0.0], np.cumsum(gaps)))
+        fine = np.linspace(0.0, s[-1], 40 * n)
+        kk = rng.uniform(0, 0.06) * np.sin(2 * math.pi * fine / rng.uniform(30, 80) + rng.uniform(0, 6.28))
+        z = rng.uniform(-math.pi, math.pi) + np.concatenate(([0.0], np.cumsum(0.5 * (kk[1:] + kk[:-1]) * np.diff(fine))))
+        xb = rng.uniform(-8, 8) + np.concatenate(([0.0], np.cumsum(np.cos(0.5 * (z[1:] + z[:-1])) * np.diff(fine))))
+        yb = rng.uniform(-8, 8) + np.concatenate(([0.0], np.cumsum(np.sin(0.5 * (z[1:] + z[:-1])) * np.diff(fine))))
+        e = rng.uniform(0.05, 0.3) * np.sin(2 * math.pi * fine / rng.uniform(4, 12) + rng.uniform(0, 6.28))
+        xr, yr = xb - e * np.sin(z), yb + e * np.cos(z)
+        dx, dy = np.gradient(xr, fine), np.gradient(yr, fine)
+        ddx, ddy = np.gradient(dx, fine), np.gradient(dy, fine)
+        ang = np.arctan2(dy, dx)
+        cur = (dx * ddy - dy * ddx) / np.power(dx * dx + dy * dy, 1.5)
+        idx = np.clip(np.searchsorted(fine, s), 0, len(fine) - 1)
+        out["x"][b, :n], out["y"][b, :n], out["angle"][b, :n], out["k"][b, :n], out["s"][b, :n] = xr[idx], yr[idx], ang[idx], cur[idx], s
+    if ragged:
+        out["n_points"] = npts
+    return out
