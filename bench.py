@@ -63,6 +63,22 @@ def stage_legs(torch, binding, synth, eng, stream, dbatch, B, with_cpu):
                               "workload": f"{B} spline reference paths x 200 states x 4 circles, <= 28 bilinear samples each"},
           "post_check": {"ms": ms_c, "paths_per_s": B / (ms_c * 1e-3), "states_per_s": B * 200 / (ms_c * 1e-3),
                          "ok_frac": float(ok.float().mean().item())}}
+    # reference-smoothing QPs: TENSION2 (100 points) and the post-smoothing QP (60 layers), 4096 instances each
+    from path_optimizer_amd.abi import INFO_DTYPE
+    sm = {}
+    sm_inputs = {}
+    for name, kind, npts in (("tension2", 0, 100), ("post", 2, 60)):
+        si = synth.make_smooth_inputs(30, 256, P=npts, kind=kind)
+        sm_inputs[name] = (kind, si)
+        tt = {k: torch.from_numpy(np.ascontiguousarray(np.concatenate([v] * reps, axis=0)[:B])).cuda() for k, v in si.items() if v is not None}
+        so = dict(x=torch.zeros((B, npts), dtype=torch.float64, device="cuda"), y=torch.zeros((B, npts), dtype=torch.float64, device="cuda"),
+                  s=torch.zeros((B, npts), dtype=torch.float64, device="cuda"), info=torch.zeros((B, 48), dtype=torch.uint8, device="cuda"))
+        ms_s = timed(lambda: eng.smooth_batch_device(kind, tt, so))
+        inf = so["info"].cpu().numpy().view(INFO_DTYPE).reshape(-1)
+        n_q, m_q = binding.smooth_dims(kind, npts)
+        sm[name] = {"ms": ms_s, "qps_per_s": B / (ms_s * 1e-3), "qp_iters_per_s": float(inf["iters"].sum()) / (ms_s * 1e-3), "iters_mean": float(inf["iters"].mean()),
+                    "iters_max": int(inf["iters"].max()), "unsolved": int((inf["status"] != 1).sum()), "points": npts, "n": n_q, "m": m_q}
+    st["smoothing_qps"] = sm
     if with_cpu:
         from oracle import oracle_py
 
@@ -75,6 +91,10 @@ def stage_legs(torch, binding, synth, eng, stream, dbatch, B, with_cpu):
         oracle_py.postcheck_batch(p, m, states, info)
         c2 = time.perf_counter()
         st["cpu_port"] = {"bounds_paths_per_s": 64 / (c1 - c0), "post_check_paths_per_s": 64 / (c2 - c1), "cores": 1, "sample": "64 paths each, oracle (C)"}
+        for name, (kind, si) in sm_inputs.items():
+            c3 = time.perf_counter()
+            oracle_py.smooth_batch(kind, p, {k: (None if v is None else v[:64]) for k, v in si.items()})
+            st["cpu_port"][f"smoothing_{name}_qps_per_s"] = 64 / (time.perf_counter() - c3)
     return st
 
 

@@ -89,6 +89,14 @@ typedef struct po_params {
     double cart_w_curv;         /* FLAGS_cartesian_curvature_weight       (1)     */
     double cart_w_curv_rate;    /* FLAGS_cartesian_curvature_rate_weight  (50)    */
     double cart_w_dev;          /* FLAGS_cartesian_deviation_weight       (0)     */
+    /* re-sampling, limits and the DP lattice search, planning_flags.cpp:41-43,57-63,137 */
+    double mu;                  /* FLAGS_mu                          (0.4)  */
+    double max_curvature_rate;  /* FLAGS_max_curvature_rate          (0.1)  */
+    double search_lateral_range;   /* FLAGS_search_lateral_range        (10.0) */
+    double search_long_spacing;    /* FLAGS_search_longitudial_spacing  (1.5)  */
+    double search_lat_spacing;     /* FLAGS_search_lateral_spacing      (0.6)  */
+    int    enable_dynamic_segmentation; /* FLAGS_enable_dynamic_segmentation (true) */
+    int    reserved0;
 } po_params;
 
 typedef struct po_info {
@@ -232,6 +240,41 @@ typedef struct po_smooth_out {
 int po_smooth_dims(int kind, int P, int *n, int *m);
 int po_smooth_batch(po_handle h, const po_smooth_in *in, const po_smooth_out *out);        /* host pointers, synchronous  */
 int po_smooth_batch_device(po_handle h, const po_smooth_in *in, const po_smooth_out *out); /* device pointers, on the stream */
+
+/* ---- reference re-sampling, limits and the DP lattice search ----
+ * A batch of planar splines x(s), y(s) (tk::spline, natural boundary conditions) given by the knots they were set from, plus the arc
+ * length the reference attaches to them (ReferencePath::getLength(), i.e. max_s_). */
+typedef struct po_spline_in {
+    int B, K;                                /* instances, knots per instance (stride) */
+    const double *knot_s, *knot_x, *knot_y;  /* [B][K], knot_s strictly increasing */
+    const int    *n_knots;                   /* optional [B]: 3 <= n_knots[b] <= K */
+    const double *length;                    /* [B]: max_s_ */
+} po_spline_in;
+/* ReferencePathImpl::buildReferenceFromSpline (src/data_struct/reference_path_impl.cpp:474-499): walk the spline from s = 0 while
+ * s <= length with the curvature-adaptive step (FLAGS_enable_dynamic_segmentation; |k| >= 0.2 -> delta_s_smaller, |k| <= 0.08 ->
+ * delta_s_larger, linear in between) and emit State{x, y, heading, k, s} (getHeading / getCurvature, src/tools/tools.cpp:34-47).
+ * Outputs [B][N] (directly consumable as po_batch_in.ref_* / po_bounds_in.ref_*) and n_points[b]; n_points[b] = -1 when the reference
+ * returns false (length <= 0) and -2 when more than N states would be produced (raise N); rows beyond n_points are zero. */
+int po_resample_batch(po_handle h, const po_spline_in *in, double delta_s_smaller, double delta_s_larger, int N, double *ref_x, double *ref_y,
+                      double *ref_z, double *ref_k, double *ref_s, int *n_points);
+int po_resample_batch_device(po_handle h, const po_spline_in *in, double delta_s_smaller, double delta_s_larger, int N, double *ref_x,
+                             double *ref_y, double *ref_z, double *ref_k, double *ref_s, int *n_points);
+/* ReferencePathImpl::updateLimits (reference_path_impl.cpp:203-235), the branch the KPC formulation uses (reference states given
+ * directly, with speed v and acceleration a): max_k = sqrt((mu g)^2 - a^2) / v^2, max_kp = max_curvature_rate / v, DBL_MAX for
+ * v <= 1e-4.  Outputs [B][N] are directly consumable as po_batch_in.max_k / max_kp. */
+int po_limits_batch(po_handle h, int B, int N, const int *n_points, const double *v, const double *a, double *max_k, double *max_kp);
+int po_limits_batch_device(po_handle h, int B, int N, const int *n_points, const double *v, const double *a, double *max_k, double *max_kp);
+/* ReferencePathSmoother::graphSearchDp (src/reference_path_smoother/reference_path_smoother.cpp:147-300, cost :110-145): project the
+ * vehicle onto the spline (findClosestPoint, tools.cpp:71-112), lay out layers every FLAGS_search_longitudial_spacing, sample each at
+ * lateral offsets -range..range every FLAGS_search_lateral_spacing against the obstacle map (po_set_map), run the layer-by-layer
+ * min-cost recursion and walk back from the cheapest node of the last reachable layer widening each node's rough corridor in 0.2 m
+ * steps.  start [B][3] = start_state (x, y, heading).  Outputs, [B][L]: layer_s = layers_s_list_, lb / ub = layers_bounds_
+ * (.first / .second); l0[b] = vehicle_l_wrt_smoothed_ref_; n_layers[b] = layers kept, -1 when the reference returns false (vehicle
+ * further than the lateral range from the spline), -2 when more than L layers are needed.  These are the inputs of PO_SMOOTH_POST. */
+int po_dp_search_batch(po_handle h, const po_spline_in *in, const double *start, int L, double *layer_s, double *lb, double *ub, double *l0,
+                       int *n_layers);
+int po_dp_search_batch_device(po_handle h, const po_spline_in *in, const double *start, int L, double *layer_s, double *lb, double *ub,
+                              double *l0, int *n_layers);
 
 /* Test/diagnostic entry: Map::getObstacleDistance at `n` world positions xy[n][2] (host pointers); inside[n] = Map::isInside. */
 int po_map_sample(po_handle h, int n, const double *xy, double *dist, int *inside);

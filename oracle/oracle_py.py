@@ -289,3 +289,33 @@ def smooth_batch(kind, params, inp, m_map=None, want_raw=False):
         if want_raw:
             raw[b] = tr
     return ox, oy, os_, info, raw
+
+
+# ---- reference re-sampling, limits and the DP lattice search ----
+def dp_search(params, m: PoMap, ks, kx, ky, length, start, cap=512):
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    ks, kx, ky, start = map(f, (ks, kx, ky, start))
+    ls = np.zeros(cap); lb = np.zeros(cap); ub = np.zeros(cap); l0 = C.c_double(0)
+    L = lib()
+    L.po_oracle_dp_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int] + [C.c_void_p] * 4
+    n = L.po_oracle_dp_search(C.byref(params), C.byref(m), len(ks), _p(ks), _p(kx), _p(ky), float(length), _p(start), cap, _p(ls), _p(lb), _p(ub), C.byref(l0))
+    return n, ls[:max(n, 0)], lb[:max(n, 0)], ub[:max(n, 0)], l0.value
+
+
+def resample(params, ks, kx, ky, max_s, ds_smaller, ds_larger, cap=4096):
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    ks, kx, ky = map(f, (ks, kx, ky))
+    out = [np.zeros(cap) for _ in range(5)]
+    L = lib()
+    L.po_oracle_resample.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int] + [C.c_void_p] * 5
+    n = L.po_oracle_resample(C.byref(params), len(ks), _p(ks), _p(kx), _p(ky), float(max_s), float(ds_smaller), float(ds_larger), cap, *[_p(o) for o in out])
+    return n, [o[:max(n, 0)] for o in out]
+
+
+def limits(params, v, a):
+    v = np.ascontiguousarray(v, np.float64); a = np.ascontiguousarray(a, np.float64)
+    mk = np.zeros(len(v)); mkp = np.zeros(len(v))
+    L = lib()
+    L.po_oracle_limits.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
+    L.po_oracle_limits(C.byref(params), len(v), _p(v), _p(a), _p(mk), _p(mkp))
+    return mk, mkp

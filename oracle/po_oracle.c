@@ -74,6 +74,9 @@ void po_oracle_default_params(po_params *p) {
     /* planning_flags.cpp:76-86 (reference-smoothing QPs) */
     p->t2_w_dev = 0.005; p->t2_w_curv = 1; p->t2_w_curv_rate = 10;
     p->cart_w_curv = 1; p->cart_w_curv_rate = 50; p->cart_w_dev = 0.0;
+    /* planning_flags.cpp:41-43,57-63,137 */
+    p->mu = 0.4; p->max_curvature_rate = 0.1; p->search_lateral_range = 10.0; p->search_long_spacing = 1.5; p->search_lat_spacing = 0.6;
+    p->enable_dynamic_segmentation = 1;
 }
 
 /* tools.hpp:24-35 — recursive in the reference; same fixed point as this loop */
@@ -1874,4 +1877,217 @@ int po_oracle_smooth_solve(int kind, const po_params *p, const po_map *map, int 
     }
     free(Pp); free(Pi); free(Ap); free(Ai); free(Px); free(Ax); free(q); free(l); free(u); free(xs); free(ys); free(zs);
     return rc ? rc : ok;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Part 7: reference re-sampling, limits and the DP lattice search.           */
+/*   tk::spline::deriv             src/tools/spline.cpp:273-318                                 */
+/*   getHeading / getCurvature / global2Local / findClosestPoint   src/tools/tools.cpp:34-112   */
+/*   buildReferenceFromSpline / updateLimits   src/data_struct/reference_path_impl.cpp:474-499 / :203-235 */
+/*   graphSearchDp / calculateCostAt   src/reference_path_smoother/reference_path_smoother.cpp:147-300 / :110-145 */
+/* ------------------------------------------------------------------------------------------ */
+#include <float.h>
+double po_oracle_spline_deriv(int K, const double *x, const double *y, const double *a, const double *b, const double *c, int order, double at) {
+    (void)y;
+    int lo = 0, hi = K;
+    while (lo < hi) { const int mid = (lo + hi) / 2; if (x[mid] < at) lo = mid + 1; else hi = mid; }
+    const int idx = lo - 1 > 0 ? lo - 1 : 0;
+    const double h = at - x[idx];
+    if (at < x[0]) return order == 1 ? 2.0 * b[0] * h + c[0] : (order == 2 ? 2.0 * b[0] * h : 0.0); /* sic: the reference's order-2 left branch keeps the h */
+    if (at > x[K - 1]) return order == 1 ? 2.0 * b[K - 1] * h + c[K - 1] : (order == 2 ? 2.0 * b[K - 1] : 0.0);
+    if (order == 1) return (3.0 * a[idx] * h + 2.0 * b[idx]) * h + c[idx];
+    if (order == 2) return 6.0 * a[idx] * h + 2.0 * b[idx];
+    return order == 3 ? 6.0 * a[idx] : 0.0;
+}
+
+typedef struct { int K; const double *s, *vx, *vy; double *ax, *bx, *cx, *ay, *by, *cy; } spl2_t;
+static int spl2_init(spl2_t *S, int K, const double *ks, const double *kx, const double *ky) {
+    S->K = K; S->s = ks; S->vx = kx; S->vy = ky;
+    S->ax = (double *)malloc(sizeof(double) * (size_t)K * 6);
+    if (!S->ax) return -1;
+    S->bx = S->ax + K; S->cx = S->ax + 2 * K; S->ay = S->ax + 3 * K; S->by = S->ax + 4 * K; S->cy = S->ax + 5 * K;
+    po_oracle_spline_fit(K, ks, kx, S->ax, S->bx, S->cx);
+    po_oracle_spline_fit(K, ks, ky, S->ay, S->by, S->cy);
+    return 0;
+}
+static double spl2_x(const spl2_t *S, double at) { return po_oracle_spline_eval(S->K, S->s, S->vx, S->ax, S->bx, S->cx, at); }
+static double spl2_y(const spl2_t *S, double at) { return po_oracle_spline_eval(S->K, S->s, S->vy, S->ay, S->by, S->cy, at); }
+static double spl2_dx(const spl2_t *S, int o, double at) { return po_oracle_spline_deriv(S->K, S->s, S->vx, S->ax, S->bx, S->cx, o, at); }
+static double spl2_dy(const spl2_t *S, int o, double at) { return po_oracle_spline_deriv(S->K, S->s, S->vy, S->ay, S->by, S->cy, o, at); }
+static double spl2_heading(const spl2_t *S, double at) { return atan2(spl2_dy(S, 1, at), spl2_dx(S, 1, at)); } /* tools.cpp:34-38 */
+static double spl2_curvature(const spl2_t *S, double at) {                                                      /* tools.cpp:40-46 */
+    const double x1 = spl2_dx(S, 1, at), y1 = spl2_dy(S, 1, at), x2 = spl2_dx(S, 2, at), y2 = spl2_dy(S, 2, at);
+    return (x1 * y2 - y1 * x2) / pow(x1 * x1 + y1 * y1, 1.5);
+}
+/* findClosestPoint(xs, ys, x, y, max_s, start_s = 0): the arc length it settles on (tools.cpp:71-112) */
+static double spl2_closest_s(const spl2_t *S, double x, double y, double max_s) {
+    const double start_s = 0.0;
+    if (max_s <= start_s) return 0.0; /* State{xs(start_s), ys(start_s)}: s stays 0 */
+    double tmp_s = start_s, min_dis_s = start_s, min_dis = DBL_MAX;
+    while (tmp_s <= max_s) {
+        const double ddx = spl2_x(S, tmp_s) - x, ddy = spl2_y(S, tmp_s) - y;
+        const double d = sqrt(ddx * ddx + ddy * ddy);
+        if (d < min_dis) { min_dis = d; min_dis_s = tmp_s; }
+        tmp_s += 0.5;
+    }
+    double cur_s = min_dis_s, prev_s = min_dis_s;
+    for (int i = 0; i < 20; ++i) { /* Newton on the squared distance */
+        const double px = spl2_x(S, cur_s), py = spl2_y(S, cur_s), dx = spl2_dx(S, 1, cur_s), dy = spl2_dy(S, 1, cur_s);
+        const double ddx = spl2_dx(S, 2, cur_s), ddy = spl2_dy(S, 2, cur_s);
+        const double j = (px - x) * dx + (py - y) * dy;
+        const double hh = dx * dx + (px - x) * ddx + dy * dy + (py - y) * ddy;
+        cur_s -= j / hh;
+        if (fabs(cur_s - prev_s) < 1e-5) break;
+        prev_s = cur_s;
+    }
+    return cur_s < max_s ? cur_s : max_s;
+}
+
+int po_oracle_resample(const po_params *p, int K, const double *ks, const double *kx, const double *ky, double max_s, double ds_smaller,
+                       double ds_larger, int N, double *ox, double *oy, double *oz, double *ok, double *os) {
+    if (max_s <= 0) return -1; /* "Cannot build reference line from spline!" */
+    spl2_t S;
+    if (spl2_init(&S, K, ks, kx, ky)) return PO_ERR_NOMEM;
+    const double large_k = 0.2, small_k = 0.08;
+    double tmp_s = 0;
+    int n = 0;
+    while (tmp_s <= max_s) {
+        if (n == N) { n = -2; break; }
+        const double k = spl2_curvature(&S, tmp_s);
+        ox[n] = spl2_x(&S, tmp_s); oy[n] = spl2_y(&S, tmp_s); oz[n] = spl2_heading(&S, tmp_s); ok[n] = k; os[n] = tmp_s;
+        ++n;
+        if (p->enable_dynamic_segmentation) {
+            const double k_share = fabs(k) > large_k ? 1 : fabs(k) < small_k ? 0 : (fabs(k) - small_k) / (large_k - small_k);
+            tmp_s += ds_larger - k_share * (ds_larger - ds_smaller);
+        } else tmp_s += ds_larger;
+    }
+    free(S.ax);
+    return n;
+}
+
+void po_oracle_limits(const po_params *p, int N, const double *v, const double *a, double *max_k, double *max_kp) {
+    for (int i = 0; i < N; ++i) {
+        const double mg = p->mu * 9.8;
+        const double ay_allowed = sqrt(mg * mg - a[i] * a[i]);
+        max_k[i] = v[i] > 0.0001 ? ay_allowed / (v[i] * v[i]) : DBL_MAX;
+        max_kp[i] = v[i] > 0.0001 ? p->max_curvature_rate / v[i] : DBL_MAX;
+    }
+}
+
+#define PO_DP_MAXLAT 64
+int po_oracle_dp_search(const po_params *p, const po_map *map, int K, const double *ks, const double *kx, const double *ky, double length,
+                        const double *start /*x,y,heading*/, int Lcap, double *layer_s, double *lb, double *ub, double *l0) {
+    spl2_t S;
+    if (spl2_init(&S, K, ks, kx, ky)) return PO_ERR_NOMEM;
+    const double range = p->search_lateral_range, spacing = p->search_lat_spacing;
+    const double search_threshold = 1.45;
+    int rc = 0;
+    /* layers */
+    double tmp_s = spl2_closest_s(&S, start[0], start[1], length);
+    const double search_ds = length > 6 ? p->search_long_spacing : 0.5;
+    int L = 0;
+    double *ls = (double *)malloc(sizeof(double) * (size_t)(Lcap + 1));
+    while (tmp_s < length) {
+        if (L >= Lcap) { rc = -2; goto done0; }
+        ls[L++] = tmp_s;
+        tmp_s += search_ds;
+    }
+    if (L >= Lcap) { rc = -2; goto done0; }
+    ls[L++] = length;
+    {
+        const double vs = ls[0], pxr = spl2_x(&S, vs), pyr = spl2_y(&S, vs), pz = spl2_heading(&S, vs);
+        const double dx = start[0] - pxr, dy = start[1] - pyr;
+        const double vl = -dx * sin(pz) + dy * cos(pz); /* global2Local(proj_point, start_state).y */
+        *l0 = vl;
+        if (fabs(vl) > range) { rc = -1; goto done0; }
+        const int start_idx = (int)((range + vl) / spacing);
+        /* lateral offsets by the reference's running sum */
+        double lat[PO_DP_MAXLAT];
+        int nlat = 0;
+        for (double cur_l = -range; cur_l <= range && nlat < PO_DP_MAXLAT; cur_l += spacing) lat[nlat++] = cur_l;
+        typedef struct { double x, y, heading, s, l, cost, dir, dis, rlo, rhi; int parent, feas; } node_t;
+        node_t *nd = (node_t *)malloc(sizeof(node_t) * (size_t)L * (size_t)nlat);
+        for (int i = 0; i < L; ++i) {
+            const double cur_s = ls[i], rx = spl2_x(&S, cur_s), ry = spl2_y(&S, cur_s), rh = spl2_heading(&S, cur_s);
+            const double rk = spl2_curvature(&S, cur_s), rr = 1 / rk;
+            node_t *row = nd + (size_t)i * nlat;
+            for (int j = 0; j < nlat; ++j) {
+                node_t *q = row + j;
+                const double cur_l = lat[j];
+                q->x = rx + cur_l * cos(rh + M_PI_2); q->y = ry + cur_l * sin(rh + M_PI_2);
+                q->heading = rh; q->s = cur_s; q->l = cur_l; q->cost = DBL_MAX; q->dir = 0; q->parent = -1; q->feas = 1;
+                q->dis = po_oracle_map_inside(map, q->x, q->y) ? po_oracle_map_distance(map, q->x, q->y) : -1;
+                if ((rk < 0 && cur_l < rr) || (rk > 0 && cur_l > rr) || q->dis < search_threshold) q->feas = 0;
+                if (i == 0 && j != start_idx) q->feas = 0;
+                if (i == 0 && j == start_idx) { q->feas = 1; q->dir = start[2]; q->cost = 0.0; }
+            }
+            for (int j = 0; j < nlat; ++j) row[j].rlo = (j == 0 || !row[j - 1].feas || !row[j].feas) ? row[j].l : row[j - 1].rlo;
+            for (int j = nlat - 1; j >= 0; --j) row[j].rhi = (j == nlat - 1 || !row[j + 1].feas || !row[j].feas) ? row[j].l : row[j + 1].rhi;
+        }
+        /* cost recursion (calculateCostAt) */
+        int max_layer = 0;
+        for (int i = 0; i < L; ++i) {
+            int any = 0;
+            node_t *row = nd + (size_t)i * nlat;
+            for (int j = 0; j < nlat && i > 0; ++j) {
+                node_t *q = row + j;
+                if (!q->feas) continue;
+                double self = 0;
+                if (q->dis < 3.0) self += (3.0 - q->dis) / 3.0 * 0.5;
+                self += fabs(q->l) / range * 1.0;
+                double min_cost = DBL_MAX;
+                const node_t *prow = row - nlat;
+                for (int k = 0; k < nlat; ++k) {
+                    const node_t *pp = prow + k;
+                    if (!pp->feas) continue;
+                    if (fabs(pp->l - q->l) > (q->s - pp->s)) continue;
+                    const double direction = atan2(q->y - pp->y, q->x - pp->x);
+                    const double edge = fabs(po_oracle_wrap_angle(direction - pp->dir)) / M_PI_2 * 16.0 +
+                                        fabs(po_oracle_wrap_angle(direction - q->heading)) / M_PI_2 * 0.5;
+                    const double total = self + edge + pp->cost;
+                    if (total < min_cost) { min_cost = total; q->parent = k; q->dir = direction; }
+                }
+                if (q->parent >= 0) { q->cost = min_cost; any = 1; }
+            }
+            if (i != 0 && !any) break;
+            max_layer = i;
+        }
+        /* cheapest node of the last reachable layer, then walk back */
+        int best = -1;
+        double min_cost = DBL_MAX;
+        for (int j = 0; j < nlat; ++j)
+            if (nd[(size_t)max_layer * nlat + j].cost < min_cost) { best = j; min_cost = nd[(size_t)max_layer * nlat + j].cost; }
+        int count = 0;
+        for (int i = max_layer, j = best; j >= 0 && i >= 0; --i) {
+            const node_t *q = nd + (size_t)i * nlat + j;
+            double lo, hi;
+            if (i == 0) { lo = -10; hi = 10; }
+            else {
+                const double check_s = 0.2, check_limit = 6.0;
+                hi = check_s + q->rhi; lo = -check_s + q->rlo;
+                const double rx = spl2_x(&S, q->s), ry = spl2_y(&S, q->s);
+                while (hi < check_limit) {
+                    const double px2 = rx + hi * cos(q->heading + M_PI_2), py2 = ry + hi * sin(q->heading + M_PI_2);
+                    if (po_oracle_map_inside(map, px2, py2) && po_oracle_map_distance(map, px2, py2) > search_threshold) hi += check_s;
+                    else { hi -= check_s; break; }
+                }
+                while (lo > -check_limit) {
+                    const double px2 = rx + lo * cos(q->heading + M_PI_2), py2 = ry + lo * sin(q->heading + M_PI_2);
+                    if (po_oracle_map_inside(map, px2, py2) && po_oracle_map_distance(map, px2, py2) > search_threshold) lo -= check_s;
+                    else { lo += check_s; break; }
+                }
+            }
+            lb[i] = lo; ub[i] = hi; /* index == layer: the chain is contiguous from max_layer down to 0 (std::reverse) */
+            ++count;
+            j = q->parent;
+            if (i == 0) break;
+        }
+        for (int i = 0; i < count; ++i) layer_s[i] = ls[i]; /* layers_s_list_.resize(layers_bounds_.size()) */
+        rc = count;
+        free(nd);
+    }
+done0:
+    free(ls);
+    free(S.ax);
+    return rc;
 }

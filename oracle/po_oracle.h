@@ -127,6 +127,17 @@ int po_oracle_smooth_solve(int kind, const po_params *p, const po_map *map, int 
                            const double *k, const double *s, const double *lb, const double *ub, double l0,
                            double *out_x, double *out_y, double *out_s, double *raw, po_info *info);
 
+/* ---- reference re-sampling, limits and the DP lattice search ---- */
+double po_oracle_spline_deriv(int K, const double *ks, const double *kv, const double *a, const double *b, const double *c, int order, double at);
+/* ReferencePathImpl::buildReferenceFromSpline: returns the number of states (<= N), -1 if the reference returns false, -2 if N is too small */
+int po_oracle_resample(const po_params *p, int K, const double *ks, const double *kx, const double *ky, double max_s, double ds_smaller,
+                       double ds_larger, int N, double *ox, double *oy, double *oz, double *ok, double *os);
+/* ReferencePathImpl::updateLimits, states-given-directly branch */
+void po_oracle_limits(const po_params *p, int N, const double *v, const double *a, double *max_k, double *max_kp);
+/* ReferencePathSmoother::graphSearchDp: returns layers kept (layer_s, lb, ub filled), -1 if the reference returns false, -2 if Lcap is too small */
+int po_oracle_dp_search(const po_params *p, const po_map *map, int K, const double *ks, const double *kx, const double *ky, double length,
+                        const double *start, int Lcap, double *layer_s, double *lb, double *ub, double *l0);
+
 #ifdef __cplusplus
 }
 #endif

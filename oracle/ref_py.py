@@ -180,3 +180,31 @@ def post_smooth(params, layer_s, lb, ub, l0, ks, kx, ky):
     out = _captured_smooth()
     out.update(rc=rc, s_end=send.value, new_x=nx, new_y=ny)
     return out
+
+
+# ---- f-4: the reference's own graphSearchDp / buildReferenceFromSpline / updateLimits (same library) ----
+def dp_search(m_map, ks, kx, ky, length, start, cap=512):
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    ks, kx, ky, start = map(f, (ks, kx, ky, start))
+    ls = np.zeros(cap); lb = np.zeros(cap); ub = np.zeros(cap); l0 = C.c_double(0)
+    L = lib_smooth()
+    L.po_ref_dp_search.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double] + [C.c_void_p] * 5
+    n = L.po_ref_dp_search(C.byref(m_map), len(ks), _p(ks), _p(kx), _p(ky), float(length), _p(start), _p(ls), _p(lb), _p(ub), C.byref(l0))
+    return n, ls[:max(n, 0)], lb[:max(n, 0)], ub[:max(n, 0)], l0.value
+
+
+def resample(ks, kx, ky, max_s, ds_smaller, ds_larger, cap=4096):
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    ks, kx, ky = map(f, (ks, kx, ky))
+    out = [np.zeros(cap) for _ in range(5)]
+    L = lib_smooth()
+    L.po_ref_resample.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int] + [C.c_void_p] * 5
+    n = L.po_ref_resample(len(ks), _p(ks), _p(kx), _p(ky), float(max_s), float(ds_smaller), float(ds_larger), cap, *[_p(o) for o in out])
+    return n, [o[:max(n, 0)] for o in out]
+
+
+def limits(v, a):
+    v = np.ascontiguousarray(v, np.float64); a = np.ascontiguousarray(a, np.float64)
+    mk = np.zeros(len(v)); mkp = np.zeros(len(v))
+    lib_smooth().po_ref_limits(len(v), _p(v), _p(a), _p(mk), _p(mkp))
+    return mk, mkp

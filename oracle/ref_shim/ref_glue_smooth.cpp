@@ -92,6 +92,60 @@ int po_ref_post_smooth(int L, const double *layer_s, const double *lb, const dou
     return ok ? 1 : 0;
 }
 
+// ReferencePathSmoother::graphSearchDp (private; reference_path_smoother.cpp:147-300) on a spline reference and an obstacle map.
+// Returns -1 when it returns false, else the number of layers kept; outputs layers_s_list_, layers_bounds_, vehicle_l_wrt_smoothed_ref_.
+int po_ref_dp_search(const po_map *m, int K, const double *ks, const double *kx, const double *ky, double length, const double *start,
+                     double *layer_s, double *lb, double *ub, double *l0) {
+    using namespace PathOptimizationNS;
+    updateConfig();
+    grid_map::GridMap gm(*m);
+    Map map(gm);
+    std::vector<State> input(4);
+    State st(start[0], start[1], start[2]);
+    TensionSmoother2 sm(input, st, map);
+    ReferencePath ref;
+    tk::spline xs, ys;
+    xs.set_points(std::vector<double>(ks, ks + K), std::vector<double>(kx, kx + K));
+    ys.set_points(std::vector<double>(ks, ks + K), std::vector<double>(ky, ky + K));
+    ref.setSpline(xs, ys, length);
+    const bool ok = sm.graphSearchDp(&ref);
+    *l0 = sm.vehicle_l_wrt_smoothed_ref_;
+    if (!ok) return -1;
+    for (size_t i = 0; i < sm.layers_bounds_.size(); ++i) { layer_s[i] = sm.layers_s_list_[i]; lb[i] = sm.layers_bounds_[i].first; ub[i] = sm.layers_bounds_[i].second; }
+    return (int)sm.layers_bounds_.size();
+}
+
+// ReferencePath::buildReferenceFromSpline (reference_path_impl.cpp:474-499): returns the number of states, -1 if it returns false.
+int po_ref_resample(int K, const double *ks, const double *kx, const double *ky, double max_s, double ds_smaller, double ds_larger, int cap,
+                    double *ox, double *oy, double *oz, double *ok, double *os) {
+    using namespace PathOptimizationNS;
+    updateConfig();
+    ReferencePath ref;
+    tk::spline xs, ys;
+    xs.set_points(std::vector<double>(ks, ks + K), std::vector<double>(kx, kx + K));
+    ys.set_points(std::vector<double>(ks, ks + K), std::vector<double>(ky, ky + K));
+    ref.setSpline(xs, ys, max_s);
+    if (!ref.buildReferenceFromSpline(ds_smaller, ds_larger)) return -1;
+    const auto &st = ref.getReferenceStates();
+    for (size_t i = 0; i < st.size() && (int)i < cap; ++i) { ox[i] = st[i].x; oy[i] = st[i].y; oz[i] = st[i].z; ok[i] = st[i].k; os[i] = st[i].s; }
+    return (int)st.size();
+}
+
+// ReferencePath::updateLimits (reference_path_impl.cpp:203-235) with FLAGS_optimization_method = "KPC" and states given directly.
+void po_ref_limits(int N, const double *v, const double *a, double *max_k, double *max_kp) {
+    using namespace PathOptimizationNS;
+    updateConfig();
+    const std::string keep = FLAGS_optimization_method;
+    FLAGS_optimization_method = "KPC";
+    ReferencePath ref;
+    std::vector<State> states;
+    for (int i = 0; i < N; ++i) { State s(0.1 * i, 0, 0, 0, 0.1 * i); s.v = v[i]; s.a = a[i]; states.push_back(s); }
+    ref.setReference(states);
+    ref.updateLimits();
+    for (int i = 0; i < N; ++i) { max_k[i] = ref.getMaxKList()[i]; max_kp[i] = ref.getMaxKpList()[i]; }
+    FLAGS_optimization_method = keep;
+}
+
 void po_ref_smooth_get_dims(int *n, int *m, int *pnz, int *anz) {
     const auto &c = OsqpEigen::g_cap;
     *n = c.n; *m = c.m; *pnz = (int)c.Px.size(); *anz = (int)c.Ax.size();

@@ -24,6 +24,8 @@ class PoParams(C.Structure):
         ("car_width", C.c_double), ("car_length", C.c_double), ("rear_axle_to_center", C.c_double), ("safety_margin", C.c_double),
         ("t2_w_dev", C.c_double), ("t2_w_curv", C.c_double), ("t2_w_curv_rate", C.c_double),
         ("cart_w_curv", C.c_double), ("cart_w_curv_rate", C.c_double), ("cart_w_dev", C.c_double),
+        ("mu", C.c_double), ("max_curvature_rate", C.c_double), ("search_lateral_range", C.c_double),
+        ("search_long_spacing", C.c_double), ("search_lat_spacing", C.c_double), ("enable_dynamic_segmentation", C.c_int), ("reserved0", C.c_int),
     ]
 
 
@@ -69,3 +71,8 @@ class PoSmoothIn(C.Structure):
 
 class PoSmoothOut(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("s", C.c_void_p), ("info", C.c_void_p), ("raw", C.c_void_p)]
+
+
+class PoSplineIn(C.Structure):
+    _fields_ = [("B", C.c_int), ("K", C.c_int), ("knot_s", C.c_void_p), ("knot_x", C.c_void_p), ("knot_y", C.c_void_p),
+                ("n_knots", C.c_void_p), ("length", C.c_void_p)]

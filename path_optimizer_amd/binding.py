@@ -20,7 +20,9 @@ _LIB = None
 EXPORTS = ["po_default_params", "po_problem_dims", "po_keep_control_steps", "po_create", "po_destroy", "po_set_stream",
            "po_solve_batch", "po_solve_batch_device", "po_assemble_batch", "po_scaling_batch", "po_last_kernel_ms", "po_strerror",
            "po_last_hip_error", "po_version", "po_set_map", "po_postcheck_batch", "po_postcheck_batch_device", "po_bounds_batch",
-           "po_bounds_batch_device", "po_map_sample", "po_smooth_dims", "po_smooth_batch", "po_smooth_batch_device"]
+           "po_bounds_batch_device", "po_map_sample", "po_smooth_dims", "po_smooth_batch", "po_smooth_batch_device",
+           "po_resample_batch", "po_resample_batch_device", "po_limits_batch", "po_limits_batch_device", "po_dp_search_batch",
+           "po_dp_search_batch_device"]
 
 
 class PoError(RuntimeError):
@@ -236,6 +238,62 @@ class Engine:
         si = PoSmoothIn(kind, B, P, p(t, "n_points"), *[p(t, k) for k in ("x", "y", "angle", "k", "s", "lb", "ub", "l0")])
         so = PoSmoothOut(p(out, "x"), p(out, "y"), p(out, "s"), p(out, "info"), p(out, "raw"))
         _check(lib().po_smooth_batch_device(self._h, C.byref(si), C.byref(so)))
+
+    # ---- reference re-sampling, limits, DP lattice search ----
+    @staticmethod
+    def _spline_in(sp: dict, length, n_knots=None):
+        from .abi import PoSplineIn
+
+        arr = {k: np.ascontiguousarray(sp[k], dtype=np.float64) for k in ("knot_s", "knot_x", "knot_y")}
+        arr["length"] = np.ascontiguousarray(length, dtype=np.float64)
+        B, K = arr["knot_s"].shape
+        nk = _i32(n_knots)
+        return PoSplineIn(B, K, _np(arr["knot_s"]), _np(arr["knot_x"]), _np(arr["knot_y"]), _np(nk), _np(arr["length"])), arr, B
+
+    def resample_batch(self, sp: dict, length, ds_smaller: float, ds_larger: float, N: int, n_knots=None):
+        """buildReferenceFromSpline over a batch of splines (knots knot_s/knot_x/knot_y [B,K], length [B]).  Returns dict ref_x, ref_y,
+        ref_z, ref_k, ref_s [B,N] and n_points [B]."""
+        si, keep, B = self._spline_in(sp, length, n_knots)
+        out = {k: np.zeros((B, N)) for k in ("ref_x", "ref_y", "ref_z", "ref_k", "ref_s")}
+        npts = np.zeros(B, dtype=np.int32)
+        _check(lib().po_resample_batch(self._h, C.byref(si), C.c_double(ds_smaller), C.c_double(ds_larger), N, _np(out["ref_x"]), _np(out["ref_y"]),
+                                       _np(out["ref_z"]), _np(out["ref_k"]), _np(out["ref_s"]), _np(npts)))
+        out["n_points"] = npts
+        return out
+
+    def limits_batch(self, v, a, n_points=None):
+        v = np.ascontiguousarray(v, dtype=np.float64); a = np.ascontiguousarray(a, dtype=np.float64)
+        B, N = v.shape
+        mk = np.zeros((B, N)); mkp = np.zeros((B, N))
+        _check(lib().po_limits_batch(self._h, B, N, _np(_i32(n_points)), _np(v), _np(a), _np(mk), _np(mkp)))
+        return mk, mkp
+
+    def dp_search_batch(self, sp: dict, length, start, L: int, n_knots=None):
+        """graphSearchDp over a batch.  start [B,3] = (x, y, heading).  Returns layer_s, lb, ub [B,L], l0 [B], n_layers [B]."""
+        si, keep, B = self._spline_in(sp, length, n_knots)
+        start = np.ascontiguousarray(start, dtype=np.float64)
+        ls = np.zeros((B, L)); lb = np.zeros((B, L)); ub = np.zeros((B, L)); l0 = np.zeros(B); nl = np.zeros(B, dtype=np.int32)
+        _check(lib().po_dp_search_batch(self._h, C.byref(si), _np(start), L, _np(ls), _np(lb), _np(ub), _np(l0), _np(nl)))
+        return ls, lb, ub, l0, nl
+
+    def dp_search_batch_device(self, t: dict, start, L: int, out: dict):
+        """Device-pointer entry: t holds torch tensors knot_s/knot_x/knot_y [B,K], length [B]; start [B,3]; out: layer_s, lb, ub [B,L], l0 [B], n_layers [B] i32."""
+        from .abi import PoSplineIn
+
+        B, K = t["knot_s"].shape
+        p = lambda d, k: None if d.get(k) is None else C.c_void_p(d[k].data_ptr())
+        si = PoSplineIn(B, K, p(t, "knot_s"), p(t, "knot_x"), p(t, "knot_y"), p(t, "n_knots"), p(t, "length"))
+        _check(lib().po_dp_search_batch_device(self._h, C.byref(si), C.c_void_p(start.data_ptr()), L, p(out, "layer_s"), p(out, "lb"), p(out, "ub"),
+                                               p(out, "l0"), p(out, "n_layers")))
+
+    def resample_batch_device(self, t: dict, ds_smaller: float, ds_larger: float, N: int, out: dict):
+        from .abi import PoSplineIn
+
+        B, K = t["knot_s"].shape
+        p = lambda d, k: None if d.get(k) is None else C.c_void_p(d[k].data_ptr())
+        si = PoSplineIn(B, K, p(t, "knot_s"), p(t, "knot_x"), p(t, "knot_y"), p(t, "n_knots"), p(t, "length"))
+        _check(lib().po_resample_batch_device(self._h, C.byref(si), C.c_double(ds_smaller), C.c_double(ds_larger), N, p(out, "ref_x"), p(out, "ref_y"),
+                                              p(out, "ref_z"), p(out, "ref_k"), p(out, "ref_s"), p(out, "n_points")))
 
     def map_sample(self, xy):
         xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)

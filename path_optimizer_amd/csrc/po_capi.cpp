@@ -27,6 +27,11 @@ extern "C" hipError_t po_launch_bounds(const po::DevMap *m, const po::DevBounds 
 extern "C" hipError_t po_launch_smooth(const po::DevSmooth *a, hipStream_t st);
 extern "C" size_t po_smooth_lds_bytes(int kind, int P);
 extern "C" size_t po_smooth_scratch_doubles(int kind, int P);
+extern "C" hipError_t po_launch_resample(const po::DevSpline *in, const po::DevResample *r, hipStream_t st);
+extern "C" hipError_t po_launch_limits(int B, int N, const int *n_points, const double *v, const double *a, double *max_k, double *max_kp, double mu, double rate, hipStream_t st);
+extern "C" hipError_t po_launch_dp_search(const po::DevMap *m, const po::DevSpline *in, const po::DevSearch *q, hipStream_t st);
+extern "C" size_t po_dp_lds_bytes(int K);
+extern "C" size_t po_spline_lds_bytes(int K);
 extern "C" hipError_t po_launch_map_sample(const po::DevMap *m, int n, const double *xy, double *dist, int *inside, hipStream_t st);
 
 namespace {
@@ -67,7 +72,7 @@ struct po_handle_s {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    DevBuf in_buf, out_buf, asm_buf, scale_buf, dbg_buf, map_buf, post_buf, coef_buf, bnd_buf, smooth_buf, smooth_io;
+    DevBuf in_buf, out_buf, asm_buf, scale_buf, dbg_buf, map_buf, post_buf, coef_buf, bnd_buf, smooth_buf, smooth_io, plan_coef, plan_io;
     po::DevMap map{};  // obstacle-distance layer (po_set_map); map.d == nullptr until set
     std::mutex mu;
 };
@@ -99,6 +104,9 @@ void po_default_params(po_params *p) {
     // reference-smoothing QPs, planning_flags.cpp:76-86
     p->t2_w_dev = 0.005; p->t2_w_curv = 1; p->t2_w_curv_rate = 10;
     p->cart_w_curv = 1; p->cart_w_curv_rate = 50; p->cart_w_dev = 0.0;
+    /* planning_flags.cpp:41-43,57-63,137 */
+    p->mu = 0.4; p->max_curvature_rate = 0.1; p->search_lateral_range = 10.0; p->search_long_spacing = 1.5; p->search_lat_spacing = 0.6;
+    p->enable_dynamic_segmentation = 1;
 }
 
 int po_problem_dims(int form, int N, int keep, int *n, int *m, int *C) {
@@ -158,7 +166,7 @@ int po_destroy(po_handle h) {
     if (!h) return PO_ERR_INVALID;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    h->in_buf.release(); h->out_buf.release(); h->asm_buf.release(); h->scale_buf.release(); h->dbg_buf.release(); h->map_buf.release(); h->post_buf.release(); h->coef_buf.release(); h->bnd_buf.release(); h->smooth_buf.release(); h->smooth_io.release();
+    h->in_buf.release(); h->out_buf.release(); h->asm_buf.release(); h->scale_buf.release(); h->dbg_buf.release(); h->map_buf.release(); h->post_buf.release(); h->coef_buf.release(); h->bnd_buf.release(); h->smooth_buf.release(); h->smooth_io.release(); h->plan_coef.release(); h->plan_io.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -613,6 +621,156 @@ int po_smooth_batch(po_handle h, const po_smooth_in *in, const po_smooth_out *ou
     if (out->s) HIP_TRY(hipMemcpyAsync(out->s, dout.s, bp, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(out->info, dout.info, binfo, hipMemcpyDeviceToHost, h->stream));
     if (out->raw) HIP_TRY(hipMemcpyAsync(out->raw, dout.raw, braw, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PO_OK;
+}
+
+// ---- reference re-sampling, limits, DP lattice search -----------------------------------------------
+static int spline_args_ok(const po_spline_in *in) {
+    return in && in->B >= 0 && in->K >= 3 && (in->B == 0 || (in->knot_s && in->knot_x && in->knot_y && in->length));
+}
+static int make_dev_spline(po_handle h, const po_spline_in *in, po::DevSpline *D) {
+    if (int rc = h->plan_coef.ensure(sizeof(double) * (size_t)in->B * 2 * 6 * in->K)) return rc;
+    D->B = in->B; D->K = in->K; D->knot_s = in->knot_s; D->knot_x = in->knot_x; D->knot_y = in->knot_y; D->n_knots = in->n_knots;
+    D->length = in->length; D->coef = static_cast<double *>(h->plan_coef.p);
+    return PO_OK;
+}
+
+int po_resample_batch_device(po_handle h, const po_spline_in *in, double ds_smaller, double ds_larger, int N, double *ref_x, double *ref_y,
+                             double *ref_z, double *ref_k, double *ref_s, int *n_points) {
+    if (!h || !spline_args_ok(in) || N < 1 || !(ds_smaller <= ds_larger) || !(ds_smaller > 0)) return PO_ERR_INVALID;  // CHECK_LE(delta_s_smaller, delta_s_larger)
+    if (in->B > 0 && (!ref_x || !ref_y || !ref_z || !ref_k || !ref_s || !n_points)) return PO_ERR_INVALID;
+    if (in->B == 0) return PO_OK;
+    if (po_spline_lds_bytes(in->K) > 64 * 1024) return PO_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    po::DevSpline D{};
+    if (int rc = make_dev_spline(h, in, &D)) return rc;
+    po::DevResample R{ds_smaller, ds_larger, h->params.enable_dynamic_segmentation, N, ref_x, ref_y, ref_z, ref_k, ref_s, n_points};
+    HIP_TRY(po_launch_resample(&D, &R, h->stream));
+    return PO_OK;
+}
+
+int po_limits_batch_device(po_handle h, int B, int N, const int *n_points, const double *v, const double *a, double *max_k, double *max_kp) {
+    if (!h || B < 0 || N < 1 || (B > 0 && (!v || !a || !max_k || !max_kp))) return PO_ERR_INVALID;
+    if (B == 0) return PO_OK;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(po_launch_limits(B, N, n_points, v, a, max_k, max_kp, h->params.mu, h->params.max_curvature_rate, h->stream));
+    return PO_OK;
+}
+
+int po_dp_search_batch_device(po_handle h, const po_spline_in *in, const double *start, int L, double *layer_s, double *lb, double *ub, double *l0,
+                              int *n_layers) {
+    if (!h || !spline_args_ok(in) || L < 1) return PO_ERR_INVALID;
+    if (in->B > 0 && (!start || !layer_s || !lb || !ub || !l0 || !n_layers)) return PO_ERR_INVALID;
+    const po_params &p = h->params;
+    if (!(p.search_lat_spacing > 0) || !(p.search_long_spacing > 0) || !(p.search_lateral_range > 0) ||
+        2 * p.search_lateral_range / p.search_lat_spacing + 1 > 64) return PO_ERR_UNSUPPORTED;  // one wave per path: <= 64 lateral samples
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->map.d) return PO_ERR_INVALID;  // po_set_map first
+    if (in->B == 0) return PO_OK;
+    if (po_dp_lds_bytes(in->K) > 160 * 1024) return PO_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(h->device));
+    po::DevSpline D{};
+    if (int rc = make_dev_spline(h, in, &D)) return rc;
+    po::DevSearch Q{p.search_lateral_range, p.search_long_spacing, p.search_lat_spacing, start, L, layer_s, lb, ub, l0, n_layers};
+    HIP_TRY(po_launch_dp_search(&h->map, &D, &Q, h->stream));
+    return PO_OK;
+}
+
+// host-pointer wrappers: stage the spline batch, run the device entry, copy back
+namespace {
+struct StagedSpline { po_spline_in d; char *next; };
+int stage_spline_batch(po_handle h, const po_spline_in *in, size_t extra_bytes, StagedSpline *out) {
+    const size_t bk = sizeof(double) * (size_t)in->B * in->K, bb = sizeof(double) * (size_t)in->B, bi = sizeof(int) * (size_t)in->B;
+    if (int rc = h->plan_io.ensure(3 * bk + bb + bi + 8 + extra_bytes + 64)) return rc;
+    char *base = static_cast<char *>(h->plan_io.p);
+    const void *src[3] = {in->knot_s, in->knot_x, in->knot_y};
+    for (int i = 0; i < 3; ++i) HIP_TRY(hipMemcpyAsync(base + i * bk, src[i], bk, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(base + 3 * bk, in->length, bb, hipMemcpyHostToDevice, h->stream));
+    if (in->n_knots) HIP_TRY(hipMemcpyAsync(base + 3 * bk + bb, in->n_knots, bi, hipMemcpyHostToDevice, h->stream));
+    out->d = *in;
+    out->d.knot_s = reinterpret_cast<const double *>(base); out->d.knot_x = reinterpret_cast<const double *>(base + bk);
+    out->d.knot_y = reinterpret_cast<const double *>(base + 2 * bk); out->d.length = reinterpret_cast<const double *>(base + 3 * bk);
+    out->d.n_knots = in->n_knots ? reinterpret_cast<const int *>(base + 3 * bk + bb) : nullptr;
+    out->next = base + ((3 * bk + bb + bi + 7) & ~(size_t)7);
+    return PO_OK;
+}
+}  // namespace
+
+int po_resample_batch(po_handle h, const po_spline_in *in, double ds_smaller, double ds_larger, int N, double *ref_x, double *ref_y, double *ref_z,
+                      double *ref_k, double *ref_s, int *n_points) {
+    if (!h || !spline_args_ok(in) || N < 1) return PO_ERR_INVALID;
+    if (in->B > 0 && (!ref_x || !ref_y || !ref_z || !ref_k || !ref_s || !n_points)) return PO_ERR_INVALID;
+    if (in->B == 0) return PO_OK;
+    const size_t bn = sizeof(double) * (size_t)in->B * N, bi = sizeof(int) * (size_t)in->B;
+    StagedSpline S{};
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        HIP_TRY(hipSetDevice(h->device));
+        if (int rc = stage_spline_batch(h, in, 5 * bn + bi, &S)) return rc;
+    }
+    double *o = reinterpret_cast<double *>(S.next);
+    int *on = reinterpret_cast<int *>(S.next + 5 * bn);
+    const size_t n1 = (size_t)in->B * N;
+    if (int rc = po_resample_batch_device(h, &S.d, ds_smaller, ds_larger, N, o, o + n1, o + 2 * n1, o + 3 * n1, o + 4 * n1, on)) return rc;
+    std::lock_guard<std::mutex> g(h->mu);
+    double *dst[5] = {ref_x, ref_y, ref_z, ref_k, ref_s};
+    for (int i = 0; i < 5; ++i) HIP_TRY(hipMemcpyAsync(dst[i], o + i * n1, bn, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(n_points, on, bi, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PO_OK;
+}
+
+int po_limits_batch(po_handle h, int B, int N, const int *n_points, const double *v, const double *a, double *max_k, double *max_kp) {
+    if (!h || B < 0 || N < 1 || (B > 0 && (!v || !a || !max_k || !max_kp))) return PO_ERR_INVALID;
+    if (B == 0) return PO_OK;
+    const size_t bn = sizeof(double) * (size_t)B * N, bi = sizeof(int) * (size_t)B;
+    char *base = nullptr;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        HIP_TRY(hipSetDevice(h->device));
+        if (int rc = h->plan_io.ensure(4 * bn + bi + 64)) return rc;
+        base = static_cast<char *>(h->plan_io.p);
+        HIP_TRY(hipMemcpyAsync(base, v, bn, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(base + bn, a, bn, hipMemcpyHostToDevice, h->stream));
+        if (n_points) HIP_TRY(hipMemcpyAsync(base + 4 * bn, n_points, bi, hipMemcpyHostToDevice, h->stream));
+    }
+    double *d = reinterpret_cast<double *>(base);
+    const size_t n1 = (size_t)B * N;
+    if (int rc = po_limits_batch_device(h, B, N, n_points ? reinterpret_cast<const int *>(base + 4 * bn) : nullptr, d, d + n1, d + 2 * n1, d + 3 * n1)) return rc;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIP_TRY(hipMemcpyAsync(max_k, d + 2 * n1, bn, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(max_kp, d + 3 * n1, bn, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PO_OK;
+}
+
+int po_dp_search_batch(po_handle h, const po_spline_in *in, const double *start, int L, double *layer_s, double *lb, double *ub, double *l0, int *n_layers) {
+    if (!h || !spline_args_ok(in) || L < 1) return PO_ERR_INVALID;
+    if (in->B > 0 && (!start || !layer_s || !lb || !ub || !l0 || !n_layers)) return PO_ERR_INVALID;
+    if (in->B == 0) return PO_OK;
+    const size_t bl = sizeof(double) * (size_t)in->B * L, bs = sizeof(double) * 3 * (size_t)in->B, bb = sizeof(double) * (size_t)in->B, bi = sizeof(int) * (size_t)in->B;
+    StagedSpline S{};
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        HIP_TRY(hipSetDevice(h->device));
+        if (int rc = stage_spline_batch(h, in, 3 * bl + bs + bb + bi, &S)) return rc;
+        HIP_TRY(hipMemcpyAsync(S.next, start, bs, hipMemcpyHostToDevice, h->stream));
+    }
+    double *dstart = reinterpret_cast<double *>(S.next);
+    double *o = dstart + 3 * (size_t)in->B;
+    const size_t n1 = (size_t)in->B * L;
+    double *dl0 = o + 3 * n1;
+    int *dn = reinterpret_cast<int *>(dl0 + in->B);
+    if (int rc = po_dp_search_batch_device(h, &S.d, dstart, L, o, o + n1, o + 2 * n1, dl0, dn)) return rc;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIP_TRY(hipMemcpyAsync(layer_s, o, bl, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(lb, o + n1, bl, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(ub, o + 2 * n1, bl, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(l0, dl0, bb, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(n_layers, dn, bi, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return PO_OK;
 }

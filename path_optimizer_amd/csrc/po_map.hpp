@@ -34,6 +34,28 @@ struct DevBounds {
     double *coef;  // [B][2][6][K]: per spline a, b, c + 3K scratch
 };
 
+// re-sampling / DP search launch arguments (po_post.hip), SURVEY.md §8f-4
+struct DevSpline {
+    int B, K;
+    const double *knot_s, *knot_x, *knot_y;
+    const int *n_knots;
+    const double *length;
+    double *coef;  // [B][2][6][K] as in DevBounds
+};
+struct DevSearch {
+    double range, long_spacing, lat_spacing;
+    const double *start;  // [B][3]
+    int L;                // stride / cap of the per-layer outputs
+    double *layer_s, *lb, *ub, *l0;
+    int *n_layers;
+};
+struct DevResample {
+    double ds_small, ds_large;
+    int dynamic, N;
+    double *x, *y, *z, *k, *s;
+    int *n_points;
+};
+
 #ifdef PO_MAP_DEVICE_CODE  // kernels and device functions: po_kernels.hip only (po_capi.cpp needs just the structs)
 // checkIfPositionWithinMap (GridMapMath.cpp): t = -(p - mapPos - 0.5*len); 0 <= t < len on both axes
 __device__ __forceinline__ bool map_inside(const DevMap &m, double x, double y) {

@@ -184,6 +184,280 @@ __global__ __launch_bounds__(256) void bounds_kernel(DevMap m, DevBounds in, dou
     if (threadIdx.x == 0) n_valid[b] = nv;
 }
 
+
+// =====================================================================================================================
+// reference re-sampling, limits, DP lattice search
+// =====================================================================================================================
+// tk::spline::deriv, src/tools/spline.cpp:273-318 (the order-2 left-extrapolation branch keeps its `* h`, as written there)
+__device__ __forceinline__ double spline_deriv(int K, const double *x, const double *a, const double *b, const double *c, int order, double at) {
+    int lo = 0, hi = K;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (x[mid] < at) lo = mid + 1; else hi = mid; }
+    const int idx = lo - 1 > 0 ? lo - 1 : 0;
+    const double h = at - x[idx];
+    if (at < x[0]) return order == 1 ? 2.0 * b[0] * h + c[0] : 2.0 * b[0] * h;
+    if (at > x[K - 1]) return order == 1 ? 2.0 * b[K - 1] * h + c[K - 1] : 2.0 * b[K - 1];
+    return order == 1 ? (3.0 * a[idx] * h + 2.0 * b[idx]) * h + c[idx] : 6.0 * a[idx] * h + 2.0 * b[idx];
+}
+// the pair x(s), y(s) of one path, staged in LDS: s, x, y knots and a, b, c of both splines = 9 arrays of K doubles
+struct Spl2 {
+    int K;
+    const double *s, *vx, *vy, *ax, *bx, *cx, *ay, *by, *cy;
+    __device__ __forceinline__ double x(double at) const { return spline_eval(K, s, vx, ax, bx, cx, at); }
+    __device__ __forceinline__ double y(double at) const { return spline_eval(K, s, vy, ay, by, cy, at); }
+    __device__ __forceinline__ double dx(int o, double at) const { return spline_deriv(K, s, ax, bx, cx, o, at); }
+    __device__ __forceinline__ double dy(int o, double at) const { return spline_deriv(K, s, ay, by, cy, o, at); }
+    __device__ __forceinline__ double heading(double at) const { return atan2(dy(1, at), dx(1, at)); }  // getHeading, tools.cpp:34-38
+    __device__ __forceinline__ double curvature(double at) const {                                     // getCurvature, tools.cpp:40-46
+        const double x1 = dx(1, at), y1 = dy(1, at), x2 = dx(2, at), y2 = dy(2, at);
+        return (x1 * y2 - y1 * x2) / pow(x1 * x1 + y1 * y1, 1.5);
+    }
+};
+__device__ __forceinline__ Spl2 stage_spline(const DevSpline &in, int b, double *lds) {
+    int K = in.n_knots ? in.n_knots[b] : in.K;
+    K = K < 3 ? 3 : (K > in.K ? in.K : K);
+    const double *co = in.coef + (size_t)b * 2 * 6 * in.K;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        lds[i] = in.knot_s[(size_t)b * in.K + i];
+        lds[K + i] = in.knot_x[(size_t)b * in.K + i];
+        lds[2 * K + i] = in.knot_y[(size_t)b * in.K + i];
+        for (int w = 0; w < 3; ++w) { lds[(3 + w) * K + i] = co[w * in.K + i]; lds[(6 + w) * K + i] = co[(6 + w) * in.K + i]; }
+    }
+    __syncthreads();
+    Spl2 S{K, lds, lds + K, lds + 2 * K, lds + 3 * K, lds + 4 * K, lds + 5 * K, lds + 6 * K, lds + 7 * K, lds + 8 * K};
+    return S;
+}
+__global__ void spline2_fit_kernel(DevSpline in) {  // same fit as spline_fit_kernel, for the DevSpline argument block
+    const int b = blockIdx.x, which = threadIdx.x;
+    if (which > 1) return;
+    int K = in.n_knots ? in.n_knots[b] : in.K;
+    K = K < 3 ? 3 : (K > in.K ? in.K : K);
+    double *co = in.coef + ((size_t)b * 2 + which) * 6 * in.K;
+    spline_fit(K, in.knot_s + (size_t)b * in.K, (which ? in.knot_y : in.knot_x) + (size_t)b * in.K, co, co + in.K, co + 2 * in.K, co + 3 * in.K);
+}
+
+// ReferencePathImpl::buildReferenceFromSpline (reference_path_impl.cpp:474-499).  One block per path: lane 0 walks the arc-length
+// sequence (each step depends on the curvature at the previous one), then all lanes fill x, y, heading of the emitted states.
+__global__ __launch_bounds__(64) void resample_kernel(DevSpline in, DevResample r) {
+    extern __shared__ double lds[];
+    const int b = blockIdx.x;
+    const size_t o = (size_t)b * r.N;
+    const double max_s = in.length[b];
+    __shared__ int s_n;
+    if (max_s <= 0) {  // "Cannot build reference line from spline!"
+        for (int i = threadIdx.x; i < r.N; i += 64) { r.x[o + i] = 0; r.y[o + i] = 0; r.z[o + i] = 0; r.k[o + i] = 0; r.s[o + i] = 0; }
+        if (threadIdx.x == 0) r.n_points[b] = -1;
+        return;
+    }
+    const Spl2 S = stage_spline(in, b, lds);
+    if (threadIdx.x == 0) {
+        const double large_k = 0.2, small_k = 0.08;
+        double tmp_s = 0;
+        int n = 0;
+        while (tmp_s <= max_s) {
+            if (n == r.N) { n = -2; break; }
+            const double k = S.curvature(tmp_s);
+            r.k[o + n] = k; r.s[o + n] = tmp_s;
+            ++n;
+            if (r.dynamic) {
+                const double k_share = fabs(k) > large_k ? 1 : fabs(k) < small_k ? 0 : (fabs(k) - small_k) / (large_k - small_k);
+                tmp_s += r.ds_large - k_share * (r.ds_large - r.ds_small);
+            } else tmp_s += r.ds_large;
+        }
+        s_n = n;
+        r.n_points[b] = n;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int n = s_n < 0 ? 0 : s_n;
+    for (int i = threadIdx.x; i < r.N; i += 64) {
+        if (i < n) {
+            const double at = r.s[o + i];
+            r.x[o + i] = S.x(at); r.y[o + i] = S.y(at); r.z[o + i] = S.heading(at);
+        } else { r.x[o + i] = 0; r.y[o + i] = 0; r.z[o + i] = 0; r.k[o + i] = 0; r.s[o + i] = 0; }
+    }
+}
+
+// ReferencePathImpl::updateLimits (reference_path_impl.cpp:203-235), states-given-directly branch.  pow(x, 2) == x * x.
+__global__ void limits_kernel(int B, int N, const int *n_points, const double *v, const double *a, double *max_k, double *max_kp, double mu, double max_kp_rate) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)B * N) return;
+    const int b = (int)(t / N), i = (int)(t - (size_t)b * N);
+    if (n_points && i >= n_points[b]) { max_k[t] = 0; max_kp[t] = 0; return; }
+    const double mg = mu * 9.8, ref_v = v[t], ref_ax = a[t];
+    const double ay_allowed = sqrt(mg * mg - ref_ax * ref_ax);
+    max_k[t] = ref_v > 0.0001 ? ay_allowed / (ref_v * ref_v) : 1.7976931348623157e308;
+    max_kp[t] = ref_v > 0.0001 ? max_kp_rate / ref_v : 1.7976931348623157e308;
+}
+
+// ReferencePathSmoother::graphSearchDp (reference_path_smoother.cpp:147-300) + calculateCostAt (:110-145).
+// One block (one wave) per path, lane = lateral sample.  Layers are visited in order (each needs the costs of the previous one); inside a
+// layer every lane scans the <= 64 nodes of the previous layer from LDS.  Parent indices of all layers stay in LDS for the walk back.
+constexpr int kDpMaxLayers = 512, kDpMaxLat = 64;
+__global__ __launch_bounds__(64) void dp_search_kernel(DevMap m, DevSpline in, DevSearch q) {
+    extern __shared__ double lds[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const size_t o = (size_t)b * q.L;
+    const Spl2 S = stage_spline(in, b, lds);
+    double *ls = lds + 9 * S.K;                // [kDpMaxLayers] layer arc lengths
+    double *nx = ls + kDpMaxLayers;            // node x, y, dir, cost of the previous / current layer (2 x 4 x 64)
+    double *lat = nx + 2 * 4 * kDpMaxLat;      // [kDpMaxLat] lateral offsets
+    unsigned long long *fmask = reinterpret_cast<unsigned long long *>(lat + kDpMaxLat);  // [kDpMaxLayers] feasibility bits
+    unsigned char *parent = reinterpret_cast<unsigned char *>(fmask + kDpMaxLayers);             // [kDpMaxLayers][64]
+    unsigned char *chosen = parent + kDpMaxLayers * kDpMaxLat;                                    // [kDpMaxLayers]
+    __shared__ int s_L, s_rc;
+    const double length = in.length[b], sx = q.start[3 * b], sy = q.start[3 * b + 1], sz = q.start[3 * b + 2];
+    const double search_threshold = 1.45;
+    // ---- findClosestPoint (tools.cpp:71-112): 0.5 m grid (lanes), then Newton (lane 0) ----
+    double tmp_s0 = 0;
+    if (length > 0) {
+        double best = 1.7976931348623157e308;
+        int bestk = 0x7fffffff;
+        for (int k = lane; 0.5 * k <= length; k += 64) {  // tmp_s = 0.5 k exactly (the reference's running sum of 0.5 is exact)
+            const double at = 0.5 * k, ddx = S.x(at) - sx, ddy = S.y(at) - sy;
+            const double d = sqrt(ddx * ddx + ddy * ddy);
+            if (d < best) { best = d; bestk = k; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {  // first minimum in scan order
+            const double ob = __shfl_xor(best, off);
+            const int ok = __shfl_xor(bestk, off);
+            if (ob < best || (ob == best && ok < bestk)) { best = ob; bestk = ok; }
+        }
+        double cur_s = 0.5 * bestk, prev_s = cur_s;
+        for (int i = 0; i < 20; ++i) {
+            const double px = S.x(cur_s), py = S.y(cur_s), dx = S.dx(1, cur_s), dy = S.dy(1, cur_s), ddx = S.dx(2, cur_s), ddy = S.dy(2, cur_s);
+            const double j = (px - sx) * dx + (py - sy) * dy;
+            const double hh = dx * dx + (px - sx) * ddx + dy * dy + (py - sy) * ddy;
+            cur_s -= j / hh;
+            if (fabs(cur_s - prev_s) < 1e-5) break;
+            prev_s = cur_s;
+        }
+        tmp_s0 = cur_s < length ? cur_s : length;
+    }
+    // ---- layers (running sum, like the reference) ----
+    if (lane == 0) {
+        const double search_ds = length > 6 ? q.long_spacing : 0.5;
+        const int cap = q.L < kDpMaxLayers ? q.L : kDpMaxLayers;
+        double t = tmp_s0;
+        int L = 0, rc = 0;
+        while (t < length) {
+            if (L >= cap) { rc = -2; break; }
+            ls[L++] = t;
+            t += search_ds;
+        }
+        if (!rc) { if (L >= cap) rc = -2; else ls[L++] = length; }
+        s_L = L; s_rc = rc;
+    }
+    __syncthreads();
+    int L = s_L, rc = s_rc;
+    double vl = 0;
+    int start_idx = 0;
+    if (!rc) {
+        const double vs = ls[0], pxr = S.x(vs), pyr = S.y(vs), pz = S.heading(vs);
+        const double dx = sx - pxr, dy = sy - pyr;
+        vl = -dx * sin(pz) + dy * cos(pz);  // global2Local(proj_point, start_state).y
+        if (fabs(vl) > q.range) rc = -1;
+        start_idx = (int)((q.range + vl) / q.lat_spacing);
+    }
+    if (rc) {
+        for (int i = lane; i < q.L; i += 64) { q.layer_s[o + i] = 0; q.lb[o + i] = 0; q.ub[o + i] = 0; }
+        if (lane == 0) { q.n_layers[b] = rc; q.l0[b] = vl; }
+        return;
+    }
+    // lateral offsets by the reference's running sum; every lane keeps its own
+    int nlat = 0;
+    double my_l = 0;
+    for (double cur_l = -q.range; cur_l <= q.range && nlat < kDpMaxLat; cur_l += q.lat_spacing) { if (nlat == lane) my_l = cur_l; ++nlat; }
+    const bool act = lane < nlat;
+    lat[lane] = my_l;
+    __syncthreads();
+    int max_layer = 0;
+    double last_cost = 1.7976931348623157e308;  // this lane's cost in layer max_layer
+    for (int i = 0; i < L; ++i) {
+        const double cur_s = ls[i];
+        const double rx = S.x(cur_s), ry = S.y(cur_s), rh = S.heading(cur_s), rk = S.curvature(cur_s), rr = 1 / rk;
+        double *cur = nx + (i & 1) * 4 * kDpMaxLat, *prv = nx + ((i & 1) ^ 1) * 4 * kDpMaxLat;
+        const double x = rx + my_l * cos(rh + M_PI_2), y = ry + my_l * sin(rh + M_PI_2);
+        const double dis = map_inside(m, x, y) ? map_distance(m, x, y) : -1;
+        bool feas = act && !((rk < 0 && my_l < rr) || (rk > 0 && my_l > rr) || dis < search_threshold);
+        double cost = 1.7976931348623157e308, dir = 0;
+        int par = 255;
+        if (i == 0) { feas = act && lane == start_idx; if (feas) { dir = sz; cost = 0.0; } }
+        const unsigned long long fm = __ballot(feas);
+        if (lane == 0) fmask[i] = fm;
+        if (i > 0 && feas) {  // calculateCostAt
+            double self = 0;
+            if (dis < 3.0) self += (3.0 - dis) / 3.0 * 0.5;
+            self += fabs(my_l) / q.range * 1.0;
+            const unsigned long long pm = fmask[i - 1];
+            const double ps = ls[i - 1];
+            double min_cost = 1.7976931348623157e308;
+            for (int k = 0; k < nlat; ++k) {
+                if (!((pm >> k) & 1ull)) continue;
+                if (fabs(lat[k] - my_l) > (cur_s - ps)) continue;
+                const double direction = atan2(y - prv[kDpMaxLat + k], x - prv[k]);
+                const double edge = fabs(wrap_pi(direction - prv[2 * kDpMaxLat + k])) / M_PI_2 * 16.0 + fabs(wrap_pi(direction - rh)) / M_PI_2 * 0.5;
+                const double total = self + edge + prv[3 * kDpMaxLat + k];
+                if (total < min_cost) { min_cost = total; par = k; dir = direction; }
+            }
+            if (par != 255) cost = min_cost;
+        }
+        const bool any = __any(par != 255);
+        if (i != 0 && !any) break;
+        if (act) { cur[lane] = x; cur[kDpMaxLat + lane] = y; cur[2 * kDpMaxLat + lane] = dir; cur[3 * kDpMaxLat + lane] = cost; parent[i * kDpMaxLat + lane] = (unsigned char)par; }
+        max_layer = i;
+        last_cost = act ? cost : 1.7976931348623157e308;
+        __syncthreads();
+    }
+    // ---- cheapest node of the last reachable layer (first minimum), walk back ----
+    double bc = last_cost;
+    int bj = (act && last_cost < 1.7976931348623157e308) ? lane : 0x7fffffff;
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oc = __shfl_xor(bc, off);
+        const int oj = __shfl_xor(bj, off);
+        if (oc < bc || (oc == bc && oj < bj)) { bc = oc; bj = oj; }
+    }
+    int count = 0;
+    if (bj != 0x7fffffff) {
+        if (lane == 0) {
+            int j = bj;
+            for (int i = max_layer; i >= 0; --i) { chosen[i] = (unsigned char)j; j = parent[i * kDpMaxLat + j]; }
+        }
+        count = max_layer + 1;
+    }
+    __syncthreads();
+    for (int i = lane; i < q.L; i += 64) {
+        double lo = 0, hi = 0, sv = 0;
+        if (i < count) {
+            sv = ls[i];
+            if (i == 0) { lo = -10; hi = 10; }
+            else {
+                const int j = chosen[i];
+                const unsigned long long fm = fmask[i];
+                int ja = j, jb = j;  // rough bounds: the run of consecutive feasible samples around j
+                if ((fm >> j) & 1ull) {
+                    while (ja > 0 && ((fm >> (ja - 1)) & 1ull)) --ja;
+                    while (jb < nlat - 1 && ((fm >> (jb + 1)) & 1ull)) ++jb;
+                }
+                const double check_s = 0.2, check_limit = 6.0;
+                hi = check_s + lat[jb]; lo = -check_s + lat[ja];
+                const double rx = S.x(sv), ry = S.y(sv), rh = S.heading(sv);
+                while (hi < check_limit) {
+                    const double px2 = rx + hi * cos(rh + M_PI_2), py2 = ry + hi * sin(rh + M_PI_2);
+                    if (map_inside(m, px2, py2) && map_distance(m, px2, py2) > search_threshold) hi += check_s;
+                    else { hi -= check_s; break; }
+                }
+                while (lo > -check_limit) {
+                    const double px2 = rx + lo * cos(rh + M_PI_2), py2 = ry + lo * sin(rh + M_PI_2);
+                    if (map_inside(m, px2, py2) && map_distance(m, px2, py2) > search_threshold) lo -= check_s;
+                    else { lo += check_s; break; }
+                }
+            }
+        }
+        q.layer_s[o + i] = sv; q.lb[o + i] = lo; q.ub[o + i] = hi;
+    }
+    if (lane == 0) { q.n_layers[b] = count; q.l0[b] = vl; }
+}
+
 }  // namespace po
 
 extern "C" hipError_t po_launch_postcheck(const po::DevMap *m, const po::DevCar *c, int B, int N, const int *n_points, const double *states,
@@ -199,5 +473,29 @@ extern "C" hipError_t po_launch_map_sample(const po::DevMap *m, int n, const dou
 extern "C" hipError_t po_launch_bounds(const po::DevMap *m, const po::DevBounds *in, double *bounds, int *n_valid, hipStream_t st) {
     hipLaunchKernelGGL(po::spline_fit_kernel, dim3(in->B), dim3(64), 0, st, *in);
     hipLaunchKernelGGL(po::bounds_kernel, dim3(in->B), dim3(256), 0, st, *m, *in, bounds, n_valid);
+    return hipGetLastError();
+}
+
+extern "C" size_t po_spline_lds_bytes(int K) { return sizeof(double) * 9 * (size_t)K; }
+extern "C" size_t po_dp_lds_bytes(int K) {
+    return sizeof(double) * (9 * (size_t)K + po::kDpMaxLayers + 2 * 4 * po::kDpMaxLat + po::kDpMaxLat) + 8 * (size_t)po::kDpMaxLayers + (size_t)po::kDpMaxLayers * po::kDpMaxLat + po::kDpMaxLayers;
+}
+extern "C" hipError_t po_launch_resample(const po::DevSpline *in, const po::DevResample *r, hipStream_t st) {
+    hipLaunchKernelGGL(po::spline2_fit_kernel, dim3(in->B), dim3(64), 0, st, *in);
+    hipLaunchKernelGGL(po::resample_kernel, dim3(in->B), dim3(64), po_spline_lds_bytes(in->K), st, *in, *r);
+    return hipGetLastError();
+}
+extern "C" hipError_t po_launch_limits(int B, int N, const int *n_points, const double *v, const double *a, double *max_k, double *max_kp, double mu,
+                                       double rate, hipStream_t st) {
+    const size_t tot = (size_t)B * N;
+    hipLaunchKernelGGL(po::limits_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, N, n_points, v, a, max_k, max_kp, mu, rate);
+    return hipGetLastError();
+}
+extern "C" hipError_t po_launch_dp_search(const po::DevMap *m, const po::DevSpline *in, const po::DevSearch *q, hipStream_t st) {
+    const size_t lds = po_dp_lds_bytes(in->K);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&po::dp_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(po::spline2_fit_kernel, dim3(in->B), dim3(64), 0, st, *in);
+    hipLaunchKernelGGL(po::dp_search_kernel, dim3(in->B), dim3(64), lds, st, *m, *in, *q);
     return hipGetLastError();
 }

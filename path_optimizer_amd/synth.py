@@ -239,3 +239,18 @@ def make_smooth_inputs(seed: int, B: int, P: int = 100, kind: int = 0, ragged: b
     if ragged:
         out["n_points"] = npts
     return out
+
+
+def make_search_inputs(seed: int, B: int, N: int = 200, ds: float = 0.3, max_offset: float = 0.6):
+    """Inputs of the DP lattice search / re-sampling: spline reference paths (make_spline_paths), the arc length the
+    reference attaches to each (shorter than the last knot), and a vehicle start state near the beginning of the path (lateral offset
+    within +-max_offset, small heading error).  Returns (paths dict, length [B], start [B,3])."""
+    sp = make_spline_paths(seed, B, N=N, ds=ds)
+    rng = np.random.default_rng(np.random.SeedSequence([SEED0, 80, seed]))
+    length = sp["ref_s"][:, -1] - rng.uniform(0.0, 3.0, B)
+    i0 = rng.integers(0, 8, B)
+    rows = np.arange(B)
+    z0 = sp["ref_z"][rows, i0]
+    off = rng.uniform(-max_offset, max_offset, B)
+    start = np.stack([sp["ref_x"][rows, i0] - off * np.sin(z0), sp["ref_y"][rows, i0] + off * np.cos(z0), z0 + rng.uniform(-0.1, 0.1, B)], axis=1)
+    return sp, np.ascontiguousarray(length), np.ascontiguousarray(start)
