@@ -79,6 +79,24 @@ def stage_legs(torch, binding, synth, eng, stream, dbatch, B, with_cpu):
         sm[name] = {"ms": ms_s, "qps_per_s": B / (ms_s * 1e-3), "qp_iters_per_s": float(inf["iters"].sum()) / (ms_s * 1e-3), "iters_mean": float(inf["iters"].mean()),
                     "iters_max": int(inf["iters"].max()), "unsolved": int((inf["status"] != 1).sum()), "points": npts, "n": n_q, "m": m_q}
     st["smoothing_qps"] = sm
+    # DP lattice search and curvature-adaptive re-sampling on 4096 spline references
+    spn, length, start = synth.make_search_inputs(9, nb)
+    rp = lambda a: torch.from_numpy(np.ascontiguousarray(np.concatenate([a] * reps, axis=0)[:B])).cuda()
+    ts = {k: rp(spn[k]) for k in ("knot_s", "knot_x", "knot_y")}
+    ts["length"] = rp(length)
+    tstart = rp(start)
+    Lc = 64
+    so = dict(layer_s=torch.zeros((B, Lc), dtype=torch.float64, device="cuda"), lb=torch.zeros((B, Lc), dtype=torch.float64, device="cuda"),
+              ub=torch.zeros((B, Lc), dtype=torch.float64, device="cuda"), l0=torch.zeros(B, dtype=torch.float64, device="cuda"),
+              n_layers=torch.zeros(B, dtype=torch.int32, device="cuda"))
+    ms_d = timed(lambda: eng.dp_search_batch_device(ts, tstart, Lc, so))
+    nl = so["n_layers"].clamp(min=0).double()
+    ro = {k: torch.zeros((B, 256), dtype=torch.float64, device="cuda") for k in ("ref_x", "ref_y", "ref_z", "ref_k", "ref_s")}
+    ro["n_points"] = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ms_r = timed(lambda: eng.resample_batch_device(ts, 0.15, 0.3, 256, ro))
+    st["dp_search"] = {"ms": ms_d, "paths_per_s": B / (ms_d * 1e-3), "layers_mean": float(nl.mean().item()),
+                       "edge_evaluations_per_s": float(nl.sum().item()) * 34 * 34 / (ms_d * 1e-3), "workload": f"{B} spline references, 34 lateral samples per layer, layers every 1.5 m"}
+    st["resample"] = {"ms": ms_r, "paths_per_s": B / (ms_r * 1e-3), "states_mean": float(ro["n_points"].double().mean().item())}
     if with_cpu:
         from oracle import oracle_py
 
@@ -95,6 +113,14 @@ def stage_legs(torch, binding, synth, eng, stream, dbatch, B, with_cpu):
             c3 = time.perf_counter()
             oracle_py.smooth_batch(kind, p, {k: (None if v is None else v[:64]) for k, v in si.items()})
             st["cpu_port"][f"smoothing_{name}_qps_per_s"] = 64 / (time.perf_counter() - c3)
+        c4 = time.perf_counter()
+        for b in range(64):
+            oracle_py.dp_search(p, m, spn["knot_s"][b], spn["knot_x"][b], spn["knot_y"][b], length[b], start[b], cap=Lc)
+        c5 = time.perf_counter()
+        for b in range(64):
+            oracle_py.resample(p, spn["knot_s"][b], spn["knot_x"][b], spn["knot_y"][b], length[b], 0.15, 0.3, cap=256)
+        st["cpu_port"]["dp_search_paths_per_s"] = 64 / (c5 - c4)
+        st["cpu_port"]["resample_paths_per_s"] = 64 / (time.perf_counter() - c5)
     return st
 
 
