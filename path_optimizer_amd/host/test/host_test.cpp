@@ -7,6 +7,7 @@
 #include <string>
 
 #include "path_optimizer_amd/map_tools.hpp"
+#include "path_optimizer_amd/smoother.hpp"
 #include "path_optimizer_amd/solver.hpp"
 
 using namespace PathOptimizationNS;
@@ -103,6 +104,40 @@ int main(int argc, char **argv) {
             std::printf("map stages FAILED\n");
             return 4;
         }
+        // 4) the reference-smoothing stages: TensionSmoother2 -> graphSearchDp -> postSmooth QP -> re-sampling -> limits
+        std::vector<double> xl, yl, al, kl, sl, rx, ry, rs;
+        for (int i = 0; i < 40; ++i) {  // a wiggly raw reference along y = -15, sampled every metre like segmentRawReference does
+            const double s = 1.0 * i, w = 0.3 * std::sin(0.9 * s), dw = 0.27 * std::cos(0.9 * s), ddw = -0.243 * std::sin(0.9 * s);
+            xl.push_back(s - 20.0); yl.push_back(-15.0 + w); al.push_back(std::atan2(dw, 1.0)); kl.push_back(ddw / std::pow(1 + dw * dw, 1.5)); sl.push_back(s);
+        }
+        TensionSmoother2 ts;
+        const bool sm_ok = ts.osqpSmooth(xl, yl, al, kl, sl, &rx, &ry, &rs);
+        double rough_in = 0, rough_out = 0;
+        for (int i = 1; i + 1 < 40; ++i) { rough_in += std::fabs(yl[i + 1] - 2 * yl[i] + yl[i - 1]); rough_out += std::fabs(ry[i + 1] - 2 * ry[i] + ry[i - 1]); }
+        std::printf("tension2 ok=%d iters=%d roughness %.4f -> %.4f start (%.6f, %.6f)\n", (int)sm_ok, ts.lastInfo().iters, rough_in, rough_out, rx[0], ry[0]);
+        SplineKnots sk;  // x_spline.set_points(result_s_list, result_x_list) in TensionSmoother::smooth
+        sk.s = rs; sk.x = rx; sk.y = ry;
+        SearchLayers layers;
+        const bool dp_ok = graphSearchDp(sk, rs.back(), State(-20.0, -14.6, 0.05), map, &layers);
+        std::vector<double> offsets;
+        const bool ps_ok = dp_ok && postSmoothOffsets(layers, &offsets);
+        std::printf("search ok=%d layers=%zu l0=%.6f post ok=%d offset[0]=%.6f offset[last]=%.6f\n", (int)dp_ok, layers.s.size(), layers.vehicle_l, (int)ps_ok,
+                    offsets.empty() ? 0.0 : offsets.front(), offsets.empty() ? 0.0 : offsets.back());
+        ReferencePath resampled;
+        const bool rs_ok = buildReferenceFromSpline(&resampled, sk, rs.back(), 0.15, 0.3);
+        std::vector<State> withv = resampled.getReferenceStates();
+        for (auto &q : withv) { q.v = 8.0; q.a = 1.0; }
+        resampled.setReference(withv);
+        updateLimits(&resampled);
+        const double mk_expect = std::sqrt(0.4 * 9.8 * 0.4 * 9.8 - 1.0) / 64.0;
+        std::printf("resample ok=%d n=%zu ds=%.3f max_k=%.9f (expect %.9f) max_kp=%.9f\n", (int)rs_ok, resampled.getSize(),
+                    resampled.getSize() > 1 ? resampled.getReferenceStates()[1].s : 0.0, resampled.getMaxKList().empty() ? 0.0 : resampled.getMaxKList()[0], mk_expect,
+                    resampled.getMaxKpList().empty() ? 0.0 : resampled.getMaxKpList()[0]);
+        const bool stages_ok = sm_ok && rough_out < 0.5 * rough_in && std::fabs(rx[0] - xl[0]) < 1e-3 && std::fabs(ry[0] - yl[0]) < 1e-3 && dp_ok && layers.s.size() >= 20 &&
+                               std::fabs(layers.vehicle_l) < 1.0 && ps_ok && std::fabs(offsets.front() - layers.vehicle_l) < 1e-3 && rs_ok && resampled.getSize() > 100 &&
+                               std::fabs(resampled.getMaxKList()[0] - mk_expect) < 1e-12 && std::fabs(resampled.getMaxKpList()[0] - 0.1 / 8.0) < 1e-15;
+        std::printf("smoothing stages %s\n", stages_ok ? "ok" : "FAILED");
+        if (!stages_ok) return 5;
     }
     std::string bad = "KCP";
     std::printf("create(KCP)=%s\n", OsqpSolver::create(bad, refs[0], vs[0], N) ? "object" : "nullptr");
