@@ -319,3 +319,90 @@ def limits(params, v, a):
     L.po_oracle_limits.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
     L.po_oracle_limits(C.byref(params), len(v), _p(v), _p(a), _p(mk), _p(mkp))
     return mk, mkp
+
+
+# ---- the remaining glue stages of PathOptimizer::solve and the composed pipeline (restatement of path_optimizer.cpp:40-230) ----
+def bspline(px, py, cap=4096):
+    px = np.ascontiguousarray(px, np.float64); py = np.ascontiguousarray(py, np.float64)
+    x = np.zeros(cap); y = np.zeros(cap); s = np.zeros(cap)
+    n = lib().po_oracle_bspline_sample(len(px), _p(px), _p(py), cap, _p(x), _p(y), _p(s))
+    return n, x[:max(n, 0)], y[:max(n, 0)], s[:max(n, 0)]
+
+
+def segment_raw(ks, kx, ky, cap=4096):
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    ks, kx, ky = map(f, (ks, kx, ky))
+    out = [np.zeros(cap) for _ in range(5)]
+    n = lib().po_oracle_segment_raw(len(ks), _p(ks), _p(kx), _p(ky), cap, *[_p(o) for o in out])
+    return n, [o[:max(n, 0)] for o in out]  # x, y, s, angle, k
+
+
+def post_project(ks, kx, ky, layer_s, offsets):
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    ks, kx, ky, layer_s, offsets = map(f, (ks, kx, ky, layer_s, offsets))
+    L = len(layer_s)
+    x = np.zeros(L); y = np.zeros(L); s = np.zeros(L)
+    rc = lib().po_oracle_post_project(len(ks), _p(ks), _p(kx), _p(ky), L, _p(layer_s), _p(offsets), _p(x), _p(y), _p(s))
+    if rc:
+        raise ValueError(f"po_oracle_post_project rc={rc}")
+    return x, y, s
+
+
+def segment_init(ks, kx, ky, length, start, goal, exact_position=0):
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    ks, kx, ky, start, goal = map(f, (ks, kx, ky, start, goal))
+    out = np.zeros(3)
+    L = lib()
+    L.po_oracle_segment_init.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    ok = L.po_oracle_segment_init(len(ks), _p(ks), _p(kx), _p(ky), float(length), _p(start), _p(goal), exact_position, _p(out))
+    return ok, out[0], out[1], out[2]
+
+
+def path_optimizer_solve(params, m: PoMap, px, py, start, goal, smooth_params=None):
+    """PathOptimizer::solve restated stage by stage on the oracle (start = x, y, heading, k; goal = x, y, heading).
+    Returns (ok, path [n,5], trace dict of the intermediate results).  `smooth_params`: OSQP settings of the smoothing QPs (default: same)."""
+    from path_optimizer_amd import synth
+    from path_optimizer_amd.abi import PO_KP
+
+    sp_ = smooth_params or params
+    tr = {}
+    n, bx, by, bs = bspline(px, py)
+    if n < 0:
+        return False, np.zeros((0, 5)), tr
+    tr["bspline"] = (bx, by, bs)
+    n, (rx, ry, rs, ra, rk) = segment_raw(bs, bx, by)
+    if n < 3:
+        return False, np.zeros((0, 5)), tr
+    inp = dict(x=rx[None], y=ry[None], angle=ra[None], k=rk[None], s=rs[None], lb=None, ub=None, l0=None)
+    ox, oy, os_, info, _ = smooth_batch(0, sp_, inp)
+    tr["tension2"] = (ox[0], oy[0], os_[0], info[0])
+    if info["status"][0] != 1:
+        return False, np.zeros((0, 5)), tr
+    k1s, k1x, k1y = os_[0], ox[0], oy[0]
+    len1 = k1s[-1] + 3
+    nl, ls, lb, ub, l0 = dp_search(params, m, k1s, k1x, k1y, len1, start[:3])
+    tr["dp"] = (nl, ls, lb, ub, l0)
+    if nl < 4:  # graphSearchDp false, or postSmooth "Ref is short"
+        return False, np.zeros((0, 5)), tr
+    pin = dict(x=None, y=None, angle=None, k=None, s=ls[None], lb=lb[None], ub=ub[None], l0=np.array([l0]))
+    off, _, _, info2, _ = smooth_batch(2, sp_, pin)
+    if info2["status"][0] != 1:
+        return False, np.zeros((0, 5)), tr
+    k2x, k2y, k2s = post_project(k1s, k1x, k1y, ls, off[0])
+    tr["post"] = (k2s, k2x, k2y, off[0])
+    ok, e0, e1, len2 = segment_init(k2s, k2x, k2y, k2s[-1], start[:3], goal[:2])
+    tr["init"] = (ok, e0, e1, len2)
+    if not ok:
+        return False, np.zeros((0, 5)), tr
+    nr, (qx, qy, qz, qk, qs) = resample(params, k2s, k2x, k2y, len2, 0.15, 0.3)
+    bounds, nv = bounds_path(params, m, qx, qy, qz, qs, k2s, k2x, k2y)
+    tr["reference"] = (qx, qy, qz, qk, qs, nv)
+    if nv < 2:
+        return False, np.zeros((0, 5)), tr
+    keep = keep_steps(PO_KP, qs[:nv])
+    batch = synth.Batch(PO_KP, 1, nv, keep, qx[None, :nv].copy(), qy[None, :nv].copy(), qz[None, :nv].copy(), qk[None, :nv].copy(), qs[None, :nv].copy(),
+                        bounds[None, :nv].copy(), np.array([[e0, e1, start[3]]]), np.array([goal[2]]))
+    states, sinfo, _ = solve_batch(batch, params, want_x=False)
+    tr["qp"] = sinfo[0]
+    nvalid, okv = postcheck_batch(params, m, states, sinfo)
+    return bool(okv[0]), states[0, :nvalid[0]], tr

@@ -2091,3 +2091,151 @@ done0:
     free(S.ax);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Part 8: the remaining glue stages of PathOptimizer::solve (path_optimizer.cpp:40-178):       */
+/*   ReferencePathSmoother::bSpline        reference_path_smoother.cpp:495-532                  */
+/*     tinyspline (ROS package tinyspline_ros) is NOT in /root/reference and un-pinned: its      */
+/*     clamped B-spline (uniform interior knots, de Boor evaluation) is restated from the        */
+/*     published algorithm — "parity unpinned" for that library.                                 */
+/*   ReferencePathSmoother::segmentRawReference   :50-91                                        */
+/*   the tail of ReferencePathSmoother::postSmooth :568-590 (re-projection of the QP offsets)   */
+/*   PathOptimizer::segmentSmoothedPath    path_optimizer.cpp:119-169 (initial errors, goal trim) */
+/* ------------------------------------------------------------------------------------------ */
+/* clamped B-spline of degree deg with n control points (dim 2) on [0,1]; knots[i] = 0 (i <= deg), (i - deg) / (n - deg), 1 (i >= n) */
+static double bs_knot(int i, int n, int deg) {
+    if (i <= deg) return 0.0;
+    if (i >= n) return 1.0;
+    const double fac = (1.0 - 0.0) / (double)(n + deg + 1 - 2 * deg - 1);
+    return fac * (double)(i - deg) + 0.0;
+}
+int po_oracle_bspline_eval(int n, int deg, const double *cx, const double *cy, double u, double *ox, double *oy) {
+    if (deg < 1 || n <= deg || deg > 7) return PO_ERR_INVALID;
+    if (u >= 1.0) { *ox = cx[n - 1]; *oy = cy[n - 1]; return PO_OK; } /* u at the last knot (multiplicity = order): the last control point */
+    if (u <= 0.0) { *ox = cx[0]; *oy = cy[0]; return PO_OK; }
+    int k = deg; /* span: knots[k] <= u < knots[k+1] */
+    while (k + 1 < n && bs_knot(k + 1, n, deg) <= u) ++k;
+    double dx[8], dy[8];
+    for (int j = 0; j <= deg; ++j) { dx[j] = cx[k - deg + j]; dy[j] = cy[k - deg + j]; }
+    for (int r = 1; r <= deg; ++r)
+        for (int j = deg; j >= r; --j) {
+            const int i = k - deg + j;
+            const double ki = bs_knot(i, n, deg), kj = bs_knot(i + deg - r + 1, n, deg);
+            const double a = (u - ki) / (kj - ki);
+            dx[j] = (1.0 - a) * dx[j - 1] + a * dx[j];
+            dy[j] = (1.0 - a) * dy[j - 1] + a * dy[j];
+        }
+    *ox = dx[deg]; *oy = dy[deg];
+    return PO_OK;
+}
+/* bSpline(): returns the number of samples written to x, y, s (x_list_, y_list_, s_list_), < 0 on error / cap too small (-2) */
+int po_oracle_bspline_sample(int n, const double *px, const double *py, int cap, double *x, double *y, double *s) {
+    if (n < 4) return -1; /* "Few reference points." (ReferencePathSmoother::solve) */
+    double length = 0;
+    for (int i = 0; i + 1 < n; ++i) {
+        const double ddx = px[i] - px[i + 1], ddy = py[i] - py[i + 1];
+        length += sqrt(ddx * ddx + ddy * ddy);
+    }
+    const double average_length = length / (n - 1);
+    const int degree = average_length > 10 ? 3 : (average_length > 5 ? 4 : 5);
+    if (n <= degree) return -1; /* tinyspline throws (fewer control points than the order) */
+    const double delta_t = 1.0 / length;
+    double tmp_t = 0;
+    int m = 0;
+    while (tmp_t < 1) {
+        if (m >= cap - 1) return -2;
+        po_oracle_bspline_eval(n, degree, px, py, tmp_t, &x[m], &y[m]);
+        ++m;
+        tmp_t += delta_t;
+    }
+    po_oracle_bspline_eval(n, degree, px, py, 1.0, &x[m], &y[m]);
+    ++m;
+    s[0] = 0;
+    for (int i = 1; i < m; ++i) {
+        const double ddx = x[i] - x[i - 1], ddy = y[i] - y[i - 1];
+        s[i] = s[i - 1] + sqrt(ddx * ddx + ddy * ddy);
+    }
+    return m;
+}
+
+/* segmentRawReference: spline through the dense raw lists, 1 m stations (the last one may lie beyond max_s), heading and curvature */
+int po_oracle_segment_raw(int K, const double *ks, const double *kx, const double *ky, int cap, double *x, double *y, double *s, double *angle, double *k) {
+    spl2_t S;
+    if (K < 3) return -1;
+    if (spl2_init(&S, K, ks, kx, ky)) return PO_ERR_NOMEM;
+    const double max_s = ks[K - 1], delta_s = 1.0;
+    int n = 0, rc = 0;
+    s[n++] = 0;
+    while (s[n - 1] < max_s) {
+        if (n >= cap) { rc = -2; break; }
+        s[n] = s[n - 1] + delta_s;
+        ++n;
+    }
+    /* `if (max_s - s_list->back() > 1)` can never hold after the loop */
+    for (int i = 0; i < n && !rc; ++i) {
+        const double at = s[i], dx = spl2_dx(&S, 1, at), dy = spl2_dy(&S, 1, at), ddx = spl2_dx(&S, 2, at), ddy = spl2_dy(&S, 2, at);
+        angle[i] = atan2(dy, dx);
+        k[i] = (dx * ddy - dy * ddx) / pow(dx * dx + dy * dy, 1.5);
+        x[i] = spl2_x(&S, at); y[i] = spl2_y(&S, at);
+    }
+    free(S.ax);
+    return rc ? rc : n;
+}
+
+/* postSmooth's tail: x = xs(s) + l cos(dir + pi/2), y = ys(s) + l sin(dir + pi/2), running chord length */
+int po_oracle_post_project(int K, const double *ks, const double *kx, const double *ky, int L, const double *layer_s, const double *offsets,
+                           double *x, double *y, double *s) {
+    spl2_t S;
+    if (K < 3 || L < 1) return PO_ERR_INVALID;
+    if (spl2_init(&S, K, ks, kx, ky)) return PO_ERR_NOMEM;
+    double acc = 0;
+    for (int i = 0; i < L; ++i) {
+        const double ref_s = layer_s[i], ref_dir = spl2_heading(&S, ref_s);
+        x[i] = spl2_x(&S, ref_s) + offsets[i] * cos(ref_dir + M_PI_2);
+        y[i] = spl2_y(&S, ref_s) + offsets[i] * sin(ref_dir + M_PI_2);
+        if (i > 0) {
+            const double ddx = x[i] - x[i - 1], ddy = y[i] - y[i - 1];
+            acc += sqrt(ddx * ddx + ddy * ddy);
+        }
+        s[i] = acc;
+    }
+    free(S.ax);
+    return PO_OK;
+}
+
+/* segmentSmoothedPath up to (not including) the re-sampling: returns 1 (go on) or 0 (the reference returns false);
+ * out[0] = initial_offset, out[1] = initial_heading_error, out[2] = the (possibly trimmed) length */
+int po_oracle_segment_init(int K, const double *ks, const double *kx, const double *ky, double length, const double *start /*x,y,z*/,
+                           const double *goal /*x,y*/, int exact_position, double *out) {
+    spl2_t S;
+    out[0] = out[1] = 0; out[2] = length;
+    if (length == 0) return 0; /* "Smoothed path is empty!" */
+    if (K < 3) return 0;
+    if (spl2_init(&S, K, ks, kx, ky)) return PO_ERR_NOMEM;
+    int ok = 1;
+    const double fx = spl2_x(&S, 0), fy = spl2_y(&S, 0), fz = spl2_heading(&S, 0);
+    const double dx = fx - start[0], dy = fy - start[1];
+    const double local_y = -dx * sin(start[2]) + dy * cos(start[2]); /* global2Local(start_state, first_point).y */
+    const double min_distance = sqrt((start[0] - fx) * (start[0] - fx) + (start[1] - fy) * (start[1] - fy));
+    out[0] = local_y < 0 ? min_distance : -min_distance;
+    out[1] = po_oracle_wrap_angle(start[2] - fz);
+    if (fabs(out[1]) > 75 * M_PI / 180) ok = 0; /* "Initial psi error is larger than 75 deg" */
+    if (ok) {
+        const double ex = goal[0] - spl2_x(&S, length), ey = goal[1] - spl2_y(&S, length);
+        const double end_distance = sqrt(ex * ex + ey * ey);
+        if (!(fabs(end_distance - 0) < 1e-6)) { /* isEqual(end_distance, 0), FLAGS_epsilon */
+            const double search_delta_s = exact_position ? 0.1 : 0.5;
+            double tmp_s = length - search_delta_s, min_dis_to_goal = end_distance, min_dis_s = length;
+            while (tmp_s > 0) {
+                const double px = spl2_x(&S, tmp_s), py = spl2_y(&S, tmp_s);
+                const double tmp_dis = sqrt((px - goal[0]) * (px - goal[0]) + (py - goal[1]) * (py - goal[1]));
+                if (tmp_dis < min_dis_to_goal) { min_dis_to_goal = tmp_dis; min_dis_s = tmp_s; }
+                if (tmp_dis > 8 && min_dis_to_goal < 8) break;
+                tmp_s -= search_delta_s;
+            }
+            out[2] = min_dis_s;
+        }
+    }
+    free(S.ax);
+    return ok;
+}

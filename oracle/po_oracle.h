@@ -138,6 +138,20 @@ void po_oracle_limits(const po_params *p, int N, const double *v, const double *
 int po_oracle_dp_search(const po_params *p, const po_map *map, int K, const double *ks, const double *kx, const double *ky, double length,
                         const double *start, int Lcap, double *layer_s, double *lb, double *ub, double *l0);
 
+/* ---- the remaining glue stages of PathOptimizer::solve (path_optimizer.cpp:40-178) ---- */
+/* tinyspline's clamped B-spline (library absent, un-pinned: restated from the published algorithm, parity unpinned) */
+int po_oracle_bspline_eval(int n, int deg, const double *cx, const double *cy, double u, double *ox, double *oy);
+/* ReferencePathSmoother::bSpline: x_list_, y_list_, s_list_; returns their length, -1 (too few points), -2 (cap too small) */
+int po_oracle_bspline_sample(int n, const double *px, const double *py, int cap, double *x, double *y, double *s);
+/* ReferencePathSmoother::segmentRawReference: returns the number of 1 m stations, -1 / -2 as above */
+int po_oracle_segment_raw(int K, const double *ks, const double *kx, const double *ky, int cap, double *x, double *y, double *s, double *angle, double *k);
+/* the tail of postSmooth: the QP offsets re-projected onto the spline -> knots of the new spline */
+int po_oracle_post_project(int K, const double *ks, const double *kx, const double *ky, int L, const double *layer_s, const double *offsets,
+                           double *x, double *y, double *s);
+/* PathOptimizer::segmentSmoothedPath before the re-sampling: 1 / 0 as the reference's return value so far; out = offset, heading error, length */
+int po_oracle_segment_init(int K, const double *ks, const double *kx, const double *ky, double length, const double *start, const double *goal,
+                           int exact_position, double *out);
+
 #ifdef __cplusplus
 }
 #endif

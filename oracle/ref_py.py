@@ -208,3 +208,48 @@ def limits(v, a):
     mk = np.zeros(len(v)); mkp = np.zeros(len(v))
     lib_smooth().po_ref_limits(len(v), _p(v), _p(a), _p(mk), _p(mkp))
     return mk, mkp
+
+
+# ---- the remaining glue stages and the reference's top-level PathOptimizer (same library) ----
+def bspline(px, py, cap=4096):
+    px = np.ascontiguousarray(px, np.float64); py = np.ascontiguousarray(py, np.float64)
+    x = np.zeros(cap); y = np.zeros(cap); s = np.zeros(cap)
+    n = lib_smooth().po_ref_bspline(len(px), _p(px), _p(py), cap, _p(x), _p(y), _p(s))
+    return n, x[:n], y[:n], s[:n]
+
+
+def segment_raw(ks, kx, ky, cap=4096):
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    ks, kx, ky = map(f, (ks, kx, ky))
+    out = [np.zeros(cap) for _ in range(5)]
+    n = lib_smooth().po_ref_segment_raw(len(ks), _p(ks), _p(kx), _p(ky), cap, *[_p(o) for o in out])
+    return n, [o[:max(n, 0)] for o in out]  # x, y, s, angle, k
+
+
+def segment_smoothed(m_map, ks, kx, ky, length, start, goal, cap=4096):
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    ks, kx, ky, start, goal = map(f, (ks, kx, ky, start, goal))
+    out4 = np.zeros(4); states = np.zeros((cap, 5))
+    L = lib_smooth()
+    L.po_ref_segment_smoothed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    ok = L.po_ref_segment_smoothed(C.byref(m_map), len(ks), _p(ks), _p(kx), _p(ky), float(length), _p(start), _p(goal), _p(out4), cap, _p(states))
+    return ok, out4[0], out4[1], out4[2], states[:int(out4[3])]
+
+
+def path_optimizer_solve(m_map, params, px, py, start, goal, cap=4096):
+    """PathOptimizer(start_state, end_state, map).solve(reference_points, &final_path): returns (bool, path [n,5])."""
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    px, py, start, goal = map(f, (px, py, start, goal))
+    path = np.zeros((cap, 5)); n = C.c_int(0)
+    ok = lib_smooth().po_ref_path_optimizer_solve(C.byref(m_map), len(px), _p(px), _p(py), _p(start), _p(goal), C.byref(params), cap, _p(path), C.byref(n))
+    return ok, path[:n.value]
+
+
+def path_optimizer_solve_without_smoothing(m_map, params, ref, ks, kx, ky, start, goal, cap=4096):
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    rx, ry, rz, rk, rs = map(f, ref)
+    ks, kx, ky, start, goal = map(f, (ks, kx, ky, start, goal))
+    path = np.zeros((cap, 5)); n = C.c_int(0)
+    ok = lib_smooth().po_ref_path_optimizer_solve_without_smoothing(C.byref(m_map), len(rx), _p(rx), _p(ry), _p(rz), _p(rk), _p(rs), len(ks), _p(ks), _p(kx), _p(ky),
+                                                                    _p(start), _p(goal), C.byref(params), cap, _p(path), C.byref(n))
+    return ok, path[:n.value]

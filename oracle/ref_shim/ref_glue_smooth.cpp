@@ -13,12 +13,14 @@
 #define private public      // the entry points are private members of the reference's classes; access only, no layout change
 #define protected public
 #include "path_optimizer/reference_path_smoother/tension_smoother_2.hpp"
+#include "path_optimizer/path_optimizer.hpp"
 #undef private
 #undef protected
 #include "OsqpEigen/OsqpEigen.h"
 #include "path_optimizer/config/planning_flags.hpp"
 #include "path_optimizer/data_struct/reference_path.hpp"
 #include "path_optimizer/tools/Map.hpp"
+#include "path_optimizer/data_struct/vehicle_state_frenet.hpp"
 #include "path_optimizer/tools/spline.h"
 
 namespace OsqpEigen {
@@ -144,6 +146,99 @@ void po_ref_limits(int N, const double *v, const double *a, double *max_k, doubl
     ref.updateLimits();
     for (int i = 0; i < N; ++i) { max_k[i] = ref.getMaxKList()[i]; max_kp[i] = ref.getMaxKpList()[i]; }
     FLAGS_optimization_method = keep;
+}
+
+// ReferencePathSmoother::bSpline (private) on the given input points: x_list_, y_list_, s_list_.
+int po_ref_bspline(int n, const double *px, const double *py, int cap, double *x, double *y, double *s) {
+    using namespace PathOptimizationNS;
+    po_map empty{};
+    grid_map::GridMap gm(empty);
+    Map map(gm);
+    std::vector<State> input;
+    for (int i = 0; i < n; ++i) input.emplace_back(px[i], py[i]);
+    State st;
+    TensionSmoother2 sm(input, st, map);
+    sm.bSpline();
+    const int m = (int)sm.x_list_.size();
+    for (int i = 0; i < m && i < cap; ++i) { x[i] = sm.x_list_[i]; y[i] = sm.y_list_[i]; s[i] = sm.s_list_[i]; }
+    return m;
+}
+
+// ReferencePathSmoother::segmentRawReference (protected) on given dense lists.
+int po_ref_segment_raw(int K, const double *ks, const double *kx, const double *ky, int cap, double *x, double *y, double *s, double *angle, double *k) {
+    using namespace PathOptimizationNS;
+    po_map empty{};
+    grid_map::GridMap gm(empty);
+    Map map(gm);
+    std::vector<State> input(4);
+    State st;
+    TensionSmoother2 sm(input, st, map);
+    sm.s_list_.assign(ks, ks + K); sm.x_list_.assign(kx, kx + K); sm.y_list_.assign(ky, ky + K);
+    std::vector<double> vx, vy, vs, va, vk;
+    if (!sm.segmentRawReference(&vx, &vy, &vs, &va, &vk)) return -1;
+    const int n = (int)vs.size();
+    for (int i = 0; i < n && i < cap; ++i) { x[i] = vx[i]; y[i] = vy[i]; s[i] = vs[i]; angle[i] = va[i]; k[i] = vk[i]; }
+    return n;
+}
+
+// PathOptimizer::segmentSmoothedPath (private) on a spline reference: returns its value; out = init offset, heading error, length after the
+// goal trim, number of reference states, then the states (x, y, z, k, s) of the re-sampled reference (before any bound truncation: map huge).
+int po_ref_segment_smoothed(const po_map *m, int K, const double *ks, const double *kx, const double *ky, double length, const double *start /*x,y,z,k*/,
+                            const double *goal /*x,y,z*/, double *out4, int cap, double *states /*[cap][5]*/) {
+    using namespace PathOptimizationNS;
+    updateConfig();
+    grid_map::GridMap gm(*m);
+    State st(start[0], start[1], start[2], start[3]), en(goal[0], goal[1], goal[2]);
+    PathOptimizer opt(st, en, gm);
+    tk::spline xs, ys;
+    xs.set_points(std::vector<double>(ks, ks + K), std::vector<double>(kx, kx + K));
+    ys.set_points(std::vector<double>(ks, ks + K), std::vector<double>(ky, ky + K));
+    opt.reference_path_->setSpline(xs, ys, length);
+    const bool ok = opt.segmentSmoothedPath();
+    const auto err = opt.vehicle_state_->getInitError();
+    out4[0] = err[0]; out4[1] = err[1]; out4[2] = opt.reference_path_->getLength();
+    const auto &rs = opt.reference_path_->getReferenceStates();
+    out4[3] = (double)rs.size();
+    for (size_t i = 0; i < rs.size() && (int)i < cap; ++i) { states[5 * i] = rs[i].x; states[5 * i + 1] = rs[i].y; states[5 * i + 2] = rs[i].z; states[5 * i + 3] = rs[i].k; states[5 * i + 4] = rs[i].s; }
+    return ok ? 1 : 0;
+}
+
+// The reference's top-level entry points.  PathOptimizer::solve(reference_points, &final_path) and solveWithoutSmoothing (which needs the
+// spline a previous solve() left in reference_path_: set here from the knots).  Returns the bool; path [n][5] = x, y, z, k, s.
+int po_ref_path_optimizer_solve(const po_map *m, int n_pts, const double *px, const double *py, const double *start /*x,y,z,k*/, const double *goal /*x,y,z*/,
+                                const po_params *admm, int cap, double *path, int *n_path) {
+    using namespace PathOptimizationNS;
+    updateConfig();
+    OsqpEigen::g_params = *admm;
+    grid_map::GridMap gm(*m);
+    State st(start[0], start[1], start[2], start[3]), en(goal[0], goal[1], goal[2]);
+    PathOptimizer opt(st, en, gm);
+    std::vector<State> pts, result;
+    for (int i = 0; i < n_pts; ++i) pts.emplace_back(px[i], py[i]);
+    const bool ok = opt.solve(pts, &result);
+    *n_path = (int)result.size();
+    for (size_t i = 0; i < result.size() && (int)i < cap; ++i) { path[5 * i] = result[i].x; path[5 * i + 1] = result[i].y; path[5 * i + 2] = result[i].z; path[5 * i + 3] = result[i].k; path[5 * i + 4] = result[i].s; }
+    return ok ? 1 : 0;
+}
+int po_ref_path_optimizer_solve_without_smoothing(const po_map *m, int N, const double *rx, const double *ry, const double *rz, const double *rk, const double *rs,
+                                                  int K, const double *ks, const double *kx, const double *ky, const double *start, const double *goal,
+                                                  const po_params *admm, int cap, double *path, int *n_path) {
+    using namespace PathOptimizationNS;
+    updateConfig();
+    OsqpEigen::g_params = *admm;
+    grid_map::GridMap gm(*m);
+    State st(start[0], start[1], start[2], start[3]), en(goal[0], goal[1], goal[2]);
+    PathOptimizer opt(st, en, gm);
+    tk::spline xs, ys;
+    xs.set_points(std::vector<double>(ks, ks + K), std::vector<double>(kx, kx + K));
+    ys.set_points(std::vector<double>(ks, ks + K), std::vector<double>(ky, ky + K));
+    opt.reference_path_->setSpline(xs, ys, ks[K - 1]);
+    std::vector<State> pts, result;
+    for (int i = 0; i < N; ++i) pts.emplace_back(rx[i], ry[i], rz[i], rk[i], rs[i]);
+    const bool ok = opt.solveWithoutSmoothing(pts, &result);
+    *n_path = (int)result.size();
+    for (size_t i = 0; i < result.size() && (int)i < cap; ++i) { path[5 * i] = result[i].x; path[5 * i + 1] = result[i].y; path[5 * i + 2] = result[i].z; path[5 * i + 3] = result[i].k; path[5 * i + 4] = result[i].s; }
+    return ok ? 1 : 0;
 }
 
 void po_ref_smooth_get_dims(int *n, int *m, int *pnz, int *anz) {

@@ -254,3 +254,55 @@ def make_search_inputs(seed: int, B: int, N: int = 200, ds: float = 0.3, max_off
     off = rng.uniform(-max_offset, max_offset, B)
     start = np.stack([sp["ref_x"][rows, i0] - off * np.sin(z0), sp["ref_y"][rows, i0] + off * np.cos(z0), z0 + rng.uniform(-0.1, 0.1, B)], axis=1)
     return sp, np.ascontiguousarray(length), np.ascontiguousarray(start)
+
+
+def make_planning_scenes(seed: int, B: int, n_way: int = 24, way_ds: float = 3.0, noise: float = 0.25, map_kw: dict | None = None):
+    """Whole planning instances for PathOptimizer::solve (/root/reference/src/test/path_optimizer_benchmark.cpp:47-100 hands it a
+    list of waypoints, a start and a goal state over an obstacle-distance map): a smooth curve inside the map, waypoints every `way_ds`
+    metres jittered laterally by +-`noise` (what a coarse planner returns), start = first waypoint with the curve's heading, goal =
+    last waypoint; obstacles (discs) kept >= 3 m away from the curve's first 6 m and otherwise scattered beside it.
+    Returns dict: way_x, way_y [B,n_way], start [B,4] (x, y, heading, k), goal [B,3], and the shared map tuple (dist, res, px, py)."""
+    rng = np.random.default_rng(np.random.SeedSequence([SEED0, 81, seed]))
+    kw = dict(size_x=700, size_y=700, resolution=0.2, pos=(0.0, 0.0))
+    kw.update(map_kw or {})
+    lx, ly = kw["size_x"] * kw["resolution"], kw["size_y"] * kw["resolution"]
+    out = dict(way_x=np.zeros((B, n_way)), way_y=np.zeros((B, n_way)), start=np.zeros((B, 4)), goal=np.zeros((B, 3)))
+    curves = []
+    for b in range(B):
+        fine = np.linspace(0.0, way_ds * (n_way - 1), 40 * n_way)
+        kk = rng.uniform(0.0, 0.035) * np.sin(2 * math.pi * fine / rng.uniform(40, 90) + rng.uniform(0, 6.28))
+        z = rng.uniform(-math.pi, math.pi) + np.concatenate(([0.0], np.cumsum(0.5 * (kk[1:] + kk[:-1]) * np.diff(fine))))
+        x = np.concatenate(([0.0], np.cumsum(np.cos(0.5 * (z[1:] + z[:-1])) * np.diff(fine))))
+        y = np.concatenate(([0.0], np.cumsum(np.sin(0.5 * (z[1:] + z[:-1])) * np.diff(fine))))
+        x += kw["pos"][0] - 0.5 * (x.max() + x.min()) + rng.uniform(-10, 10)
+        y += kw["pos"][1] - 0.5 * (y.max() + y.min()) + rng.uniform(-10, 10)
+        idx = np.searchsorted(fine, way_ds * np.arange(n_way)).clip(0, len(fine) - 1)
+        e = rng.uniform(-noise, noise, n_way)
+        e[0] = e[-1] = 0.0
+        out["way_x"][b] = x[idx] - e * np.sin(z[idx]); out["way_y"][b] = y[idx] + e * np.cos(z[idx])
+        out["start"][b] = [x[0], y[0], z[0], kk[0]]
+        out["goal"][b] = [x[idx[-1]], y[idx[-1]], z[idx[-1]]]
+        curves.append((x, y, fine))
+    # one shared map: discs beside the curves, never closer than `clear` to any curve point (wider near the starts)
+    discs = []
+    tries = 0
+    while len(discs) < 60 and tries < 4000:
+        tries += 1
+        ox, oy = rng.uniform(kw["pos"][0] - 0.45 * lx, kw["pos"][0] + 0.45 * lx), rng.uniform(kw["pos"][1] - 0.45 * ly, kw["pos"][1] + 0.45 * ly)
+        r = rng.uniform(0.5, 2.0)
+        okd = True
+        for x, y, fine in curves:
+            d = np.hypot(x - ox, y - oy) - r
+            if d.min() < 3.2 or d[fine < 8.0].min() < 5.0:
+                okd = False
+                break
+        if okd:
+            discs.append((ox, oy, r))
+    cx = kw["pos"][0] + 0.5 * lx - (np.arange(kw["size_x"]) + 0.5) * kw["resolution"]
+    cy = kw["pos"][1] + 0.5 * ly - (np.arange(kw["size_y"]) + 0.5) * kw["resolution"]
+    X, Y = np.meshgrid(cx, cy, indexing="ij")
+    d = np.full((kw["size_x"], kw["size_y"]), 30.0)
+    for ox, oy, r in discs:
+        d = np.minimum(d, np.hypot(X - ox, Y - oy) - r)
+    out["map"] = (np.maximum(d, 0.0).astype(np.float32), kw["resolution"], kw["pos"][0], kw["pos"][1])
+    return out
