@@ -276,6 +276,55 @@ int po_dp_search_batch(po_handle h, const po_spline_in *in, const double *start,
 int po_dp_search_batch_device(po_handle h, const po_spline_in *in, const double *start, int L, double *layer_s, double *lb, double *ub,
                               double *l0, int *n_layers);
 
+/* ---- the remaining glue stages of PathOptimizer::solve, device-pointer entries (each is one kernel on the handle's stream) ----
+ * ReferencePathSmoother::bSpline (reference_path_smoother.cpp:495-532): dense samples x_list_, y_list_, s_list_ [B][M] of the clamped
+ * B-spline whose control points are the input points (tinyspline, a library that is NOT in /root/reference: restated, parity unpinned);
+ * n_samples[b] = -1 for fewer than 4 points ("Few reference points."), -2 if M is too small. */
+int po_bspline_batch_device(po_handle h, int B, int W, const int *n_way, const double *way_x, const double *way_y, int M, double *x, double *y, double *s,
+                            int *n_samples);
+/* ReferencePathSmoother::segmentRawReference (:50-91): the spline through the dense lists (raw->knot_*, raw->n_knots; raw->length unused)
+ * sampled at 1 m stations: x, y, s, angle, k [B][P] = the five inputs of PO_SMOOTH_TENSION2 / PO_SMOOTH_TENSION; n_points as above. */
+int po_segment_raw_batch_device(po_handle h, const po_spline_in *raw, int P, double *x, double *y, double *s, double *angle, double *k, int *n_points);
+/* The tail of ReferencePathSmoother::postSmooth (:568-590): layer i moves to xs(s_i) + l_i (cos, sin)(heading + pi/2); x, y, s [B][L] are the
+ * knots of the re-fitted spline (s = running chord length), length[b] = s.back() (may be NULL). */
+int po_post_project_batch_device(po_handle h, const po_spline_in *spline, int L, const int *n_layers, const double *layer_s, const double *offsets, double *x,
+                                 double *y, double *s, double *length);
+/* PathOptimizer::segmentSmoothedPath up to the re-sampling (path_optimizer.cpp:119-169): init [B][3] = initial_offset,
+ * initial_heading_error, length after the goal trim; ok[b] = 0 where the reference returns false (empty path, heading error > 75 deg).
+ * start [B][start_stride] = x, y, heading, ...; goal [B][goal_stride] = x, y, ... */
+int po_segment_init_batch_device(po_handle h, const po_spline_in *spline, const double *start, int start_stride, const double *goal, int goal_stride,
+                                 double *init, int *ok);
+
+/* ---- PathOptimizer::solve for a batch of planning instances (path_optimizer.cpp:40-85): bSpline -> TensionSmoother2 -> graphSearchDp ->
+ * postSmooth -> segmentSmoothedPath (goal trim, buildReferenceFromSpline(0.15, FLAGS_output_spacing = 0.3), updateBounds) -> KP QP ->
+ * collision check, every stage on the device, chained through HBM (one D2H of 3 ints per instance in the middle to group the QPs by
+ * keep_control_steps_).  Needs po_set_map.  The shipped flag defaults are assumed (smoothing_method TENSION2, tension_solver OSQP,
+ * optimization_method KP, enable_raw_output, enable_collision_check from po_params); OSQP settings from po_params for all three QPs.
+ *   way_x / way_y [B][W]: reference_points (solve() reads only x and y); start [B][4] = start_state x, y, heading, k; goal [B][3].
+ *   states [B][N][5] = final_path (x, y, heading, k, s), n_states[b] its size, ok[b] = the bool solve() returns;
+ *   stage[b] (optional) = 0 or the stage that made it return false: 1 too few points / B-spline, 2 tension smoothing QP, 3 graph search,
+ *   4 post smoothing, 5 segmentation (heading error > 75 deg), 6 reference blocked at its start, 7 path QP, 8 collision check (states
+ *   hold the truncated path), 9 capacity (N / max_length too small or the QP does not fit the on-chip tile).
+ *   max_length: upper bound of the waypoint polyline lengths (sizes the intermediate buffers); <= 0: computed from the waypoints
+ *   (host-pointer entry only). */
+typedef struct po_plan_in {
+    int B, W;
+    const int    *n_way;          /* optional [B] */
+    const double *way_x, *way_y;  /* [B][W] */
+    const double *start, *goal;   /* [B][4], [B][3] */
+    double max_length;
+    int N;                        /* rows of `states` per instance */
+} po_plan_in;
+typedef struct po_plan_out {
+    double  *states;   /* [B][N][5] */
+    int     *n_states; /* [B] */
+    int     *ok;       /* [B] */
+    int     *stage;    /* optional [B] */
+    po_info *info;     /* optional [B]: the path QP */
+} po_plan_out;
+int po_plan_batch(po_handle h, const po_plan_in *in, const po_plan_out *out);         /* host pointers, synchronous */
+int po_plan_batch_device(po_handle h, const po_plan_in *in, const po_plan_out *out);  /* device pointers; synchronises the stream once mid-way */
+
 /* Test/diagnostic entry: Map::getObstacleDistance at `n` world positions xy[n][2] (host pointers); inside[n] = Map::isInside. */
 int po_map_sample(po_handle h, int n, const double *xy, double *dist, int *inside);
 

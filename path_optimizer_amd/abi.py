@@ -76,3 +76,12 @@ class PoSmoothOut(C.Structure):
 class PoSplineIn(C.Structure):
     _fields_ = [("B", C.c_int), ("K", C.c_int), ("knot_s", C.c_void_p), ("knot_x", C.c_void_p), ("knot_y", C.c_void_p),
                 ("n_knots", C.c_void_p), ("length", C.c_void_p)]
+
+
+class PoPlanIn(C.Structure):
+    _fields_ = [("B", C.c_int), ("W", C.c_int), ("n_way", C.c_void_p), ("way_x", C.c_void_p), ("way_y", C.c_void_p), ("start", C.c_void_p),
+                ("goal", C.c_void_p), ("max_length", C.c_double), ("N", C.c_int)]
+
+
+class PoPlanOut(C.Structure):
+    _fields_ = [("states", C.c_void_p), ("n_states", C.c_void_p), ("ok", C.c_void_p), ("stage", C.c_void_p), ("info", C.c_void_p)]

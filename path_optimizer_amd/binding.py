@@ -22,7 +22,8 @@ EXPORTS = ["po_default_params", "po_problem_dims", "po_keep_control_steps", "po_
            "po_last_hip_error", "po_version", "po_set_map", "po_postcheck_batch", "po_postcheck_batch_device", "po_bounds_batch",
            "po_bounds_batch_device", "po_map_sample", "po_smooth_dims", "po_smooth_batch", "po_smooth_batch_device",
            "po_resample_batch", "po_resample_batch_device", "po_limits_batch", "po_limits_batch_device", "po_dp_search_batch",
-           "po_dp_search_batch_device"]
+           "po_dp_search_batch_device", "po_bspline_batch_device", "po_segment_raw_batch_device", "po_post_project_batch_device",
+           "po_segment_init_batch_device", "po_plan_batch", "po_plan_batch_device"]
 
 
 class PoError(RuntimeError):
@@ -294,6 +295,32 @@ class Engine:
         si = PoSplineIn(B, K, p(t, "knot_s"), p(t, "knot_x"), p(t, "knot_y"), p(t, "n_knots"), p(t, "length"))
         _check(lib().po_resample_batch_device(self._h, C.byref(si), C.c_double(ds_smaller), C.c_double(ds_larger), N, p(out, "ref_x"), p(out, "ref_y"),
                                               p(out, "ref_z"), p(out, "ref_k"), p(out, "ref_s"), p(out, "n_points")))
+
+    # ---- PathOptimizer::solve for a batch of planning instances ----
+    def plan_batch(self, way_x, way_y, start, goal, N: int = 512, n_way=None, max_length: float = 0.0):
+        """Host-pointer entry of po_plan_batch.  way_x / way_y [B,W], start [B,4] (x, y, heading, k), goal [B,3].
+        Returns states [B,N,5], n_states [B], ok [B], stage [B], info [B]."""
+        from .abi import PoPlanIn, PoPlanOut
+
+        wx = np.ascontiguousarray(way_x, dtype=np.float64); wy = np.ascontiguousarray(way_y, dtype=np.float64)
+        st = np.ascontiguousarray(start, dtype=np.float64); gl = np.ascontiguousarray(goal, dtype=np.float64)
+        B, W = wx.shape
+        pi = PoPlanIn(B, W, _np(_i32(n_way)), _np(wx), _np(wy), _np(st), _np(gl), float(max_length), N)
+        states = np.zeros((B, N, 5)); n = np.zeros(B, dtype=np.int32); ok = np.zeros(B, dtype=np.int32); stage = np.zeros(B, dtype=np.int32)
+        info = np.zeros(B, dtype=INFO_DTYPE)
+        po = PoPlanOut(_np(states), _np(n), _np(ok), _np(stage), _np(info))
+        _check(lib().po_plan_batch(self._h, C.byref(pi), C.byref(po)))
+        return states, n, ok, stage, info
+
+    def plan_batch_device(self, t: dict, out: dict, N: int, max_length: float):
+        """Device-pointer entry: t: way_x, way_y [B,W], start [B,4], goal [B,3] (+ n_way); out: states [B,N,5], n_states, ok (+ stage, info [B,48] u8)."""
+        from .abi import PoPlanIn, PoPlanOut
+
+        B, W = t["way_x"].shape
+        p = lambda d, k: None if d.get(k) is None else C.c_void_p(d[k].data_ptr())
+        pi = PoPlanIn(B, W, p(t, "n_way"), p(t, "way_x"), p(t, "way_y"), p(t, "start"), p(t, "goal"), float(max_length), N)
+        po = PoPlanOut(p(out, "states"), p(out, "n_states"), p(out, "ok"), p(out, "stage"), p(out, "info"))
+        _check(lib().po_plan_batch_device(self._h, C.byref(pi), C.byref(po)))
 
     def map_sample(self, xy):
         xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)

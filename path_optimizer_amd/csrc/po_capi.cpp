@@ -72,7 +72,7 @@ struct po_handle_s {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    DevBuf in_buf, out_buf, asm_buf, scale_buf, dbg_buf, map_buf, post_buf, coef_buf, bnd_buf, smooth_buf, smooth_io, plan_coef, plan_io;
+    DevBuf in_buf, out_buf, asm_buf, scale_buf, dbg_buf, map_buf, post_buf, coef_buf, bnd_buf, smooth_buf, smooth_io, plan_coef, plan_io, plan_arena;
     po::DevMap map{};  // obstacle-distance layer (po_set_map); map.d == nullptr until set
     std::mutex mu;
 };
@@ -166,7 +166,7 @@ int po_destroy(po_handle h) {
     if (!h) return PO_ERR_INVALID;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    h->in_buf.release(); h->out_buf.release(); h->asm_buf.release(); h->scale_buf.release(); h->dbg_buf.release(); h->map_buf.release(); h->post_buf.release(); h->coef_buf.release(); h->bnd_buf.release(); h->smooth_buf.release(); h->smooth_io.release(); h->plan_coef.release(); h->plan_io.release();
+    h->in_buf.release(); h->out_buf.release(); h->asm_buf.release(); h->scale_buf.release(); h->dbg_buf.release(); h->map_buf.release(); h->post_buf.release(); h->coef_buf.release(); h->bnd_buf.release(); h->smooth_buf.release(); h->smooth_io.release(); h->plan_coef.release(); h->plan_io.release(); h->plan_arena.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -792,6 +792,15 @@ int po_map_sample(po_handle h, int n, const double *xy, double *dist, int *insid
     HIP_TRY(hipStreamSynchronize(h->stream));
     return PO_OK;
 }
+
+// internal accessors for po_plan.cpp (not part of include/po_hip.h)
+void *po_internal_arena(po_handle h, size_t bytes) { return h->plan_arena.ensure(bytes) == PO_OK ? h->plan_arena.p : nullptr; }
+void *po_internal_plan_coef(po_handle h, size_t bytes) { return h->plan_coef.ensure(bytes) == PO_OK ? h->plan_coef.p : nullptr; }
+hipStream_t po_internal_stream(po_handle h) { return h->stream; }
+int po_internal_device(po_handle h) { return h->device; }
+const po_params *po_internal_params(po_handle h) { return &h->params; }
+int po_internal_has_map(po_handle h) { return h->map.d != nullptr; }
+int po_internal_hip_fail(hipError_t e, const char *what) { return hip_ok(e, what) ? 0 : 1; }
 
 const char *po_strerror(int code) {
     switch (code) {

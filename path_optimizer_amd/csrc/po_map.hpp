@@ -10,6 +10,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "../../include/po_hip.h"
+
 namespace po {
 
 struct DevMap {
@@ -54,6 +56,32 @@ struct DevResample {
     int dynamic, N;
     double *x, *y, *z, *k, *s;
     int *n_points;
+};
+
+// plumbing of po_plan_batch (po_post.hip kernels, po_plan.cpp orchestration)
+struct PlanGate {
+    int B, mode;
+    int *stage;
+    int *cnt;               // the count array the next stage reads (n_points / n_layers / n_valid): zeroed for failed instances
+    const int *cnt2;        // mode 1: n_samples of the B-spline stage
+    const po_info *info;    // modes 1, 3, 6: the QP info to test
+    const double *s; int stride;  // mode 1: result_s (for length = s.back() + 3)
+    double *length;         // modes 1, 4: length handed to the next spline stage
+    const double *init; const int *ok;  // mode 4
+    const double *start, *goal;         // mode 5: [B][4], [B][3]
+    const double *ref_s; int ref_stride;  // mode 5: reference arc lengths (keep_control_steps)
+    double *x0, *goal_z; int *keep;     // mode 5 outputs
+    double *start3;         // mode 0: start [B][3] for the search
+};
+struct PlanRows {
+    int G, N, Ng;
+    const int *idx;  // [G] instance of each group row
+    const double *ref_x, *ref_y, *ref_z, *ref_k, *ref_s, *bounds, *x0, *goal_z;
+    const int *n_valid;
+    double *g_x, *g_y, *g_z, *g_k, *g_s, *g_bounds, *g_x0, *g_goal;
+    int *g_n;
+    double *g_states; po_info *g_info;  // solve outputs of the group
+    double *states; po_info *info;      // [B][N][5], [B]
 };
 
 #ifdef PO_MAP_DEVICE_CODE  // kernels and device functions: po_kernels.hip only (po_capi.cpp needs just the structs)

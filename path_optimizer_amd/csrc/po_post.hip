@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64) void resample_kernel(DevSpline in, DevResample 
     const size_t o = (size_t)b * r.N;
     const double max_s = in.length[b];
     __shared__ int s_n;
-    if (max_s <= 0) {  // "Cannot build reference line from spline!"
+    if (max_s <= 0 || (in.n_knots && (in.n_knots[b] < 3 || in.n_knots[b] > in.K))) {  // "Cannot build reference line from spline!"
         for (int i = threadIdx.x; i < r.N; i += 64) { r.x[o + i] = 0; r.y[o + i] = 0; r.z[o + i] = 0; r.k[o + i] = 0; r.s[o + i] = 0; }
         if (threadIdx.x == 0) r.n_points[b] = -1;
         return;
@@ -297,6 +297,11 @@ __global__ __launch_bounds__(64) void dp_search_kernel(DevMap m, DevSpline in, D
     extern __shared__ double lds[];
     const int b = blockIdx.x, lane = threadIdx.x;
     const size_t o = (size_t)b * q.L;
+    if (in.n_knots && (in.n_knots[b] < 3 || in.n_knots[b] > in.K)) {  // no spline (an earlier stage of a pipeline failed): nothing to search
+        for (int i = lane; i < q.L; i += 64) { q.layer_s[o + i] = 0; q.lb[o + i] = 0; q.ub[o + i] = 0; }
+        if (lane == 0) { q.n_layers[b] = -1; q.l0[b] = 0; }
+        return;
+    }
     const Spl2 S = stage_spline(in, b, lds);
     double *ls = lds + 9 * S.K;                // [kDpMaxLayers] layer arc lengths
     double *nx = ls + kDpMaxLayers;            // node x, y, dir, cost of the previous / current layer (2 x 4 x 64)
@@ -458,6 +463,282 @@ __global__ __launch_bounds__(64) void dp_search_kernel(DevMap m, DevSpline in, D
     if (lane == 0) { q.n_layers[b] = count; q.l0[b] = vl; }
 }
 
+
+// =====================================================================================================================
+// The remaining glue stages of PathOptimizer::solve (path_optimizer.cpp:40-178) and the plumbing of po_plan_batch
+// =====================================================================================================================
+// tinyspline's clamped B-spline (library absent from /root/reference: restated, parity unpinned): knots 0 (i <= deg), (i - deg)/(n - deg), 1 (i >= n)
+__device__ __forceinline__ double bs_knot(int i, int n, int deg) {
+    if (i <= deg) return 0.0;
+    if (i >= n) return 1.0;
+    const double fac = (1.0 - 0.0) / (double)(n + deg + 1 - 2 * deg - 1);
+    return fac * (double)(i - deg) + 0.0;
+}
+__device__ void bspline_eval(int n, int deg, const double *cx, const double *cy, double u, double &ox, double &oy) {
+    if (u >= 1.0) { ox = cx[n - 1]; oy = cy[n - 1]; return; }
+    if (u <= 0.0) { ox = cx[0]; oy = cy[0]; return; }
+    int k = deg;
+    while (k + 1 < n && bs_knot(k + 1, n, deg) <= u) ++k;
+    double dx[8], dy[8];
+    for (int j = 0; j <= deg; ++j) { dx[j] = cx[k - deg + j]; dy[j] = cy[k - deg + j]; }
+    for (int r = 1; r <= deg; ++r)
+        for (int j = deg; j >= r; --j) {
+            const int i = k - deg + j;
+            const double ki = bs_knot(i, n, deg), kj = bs_knot(i + deg - r + 1, n, deg);
+            const double a = (u - ki) / (kj - ki);
+            dx[j] = (1.0 - a) * dx[j - 1] + a * dx[j];
+            dy[j] = (1.0 - a) * dy[j - 1] + a * dy[j];
+        }
+    ox = dx[deg]; oy = dy[deg];
+}
+// ReferencePathSmoother::bSpline (reference_path_smoother.cpp:495-532): x_list_, y_list_, s_list_ from the input points.
+__global__ __launch_bounds__(64) void bspline_kernel(int B, int W, const int *n_way, const double *wx, const double *wy, int M, double *x, double *y, double *s,
+                                                     int *n_samples) {
+    extern __shared__ double lds[];  // control points x, y [W]
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const size_t o = (size_t)b * M;
+    __shared__ int s_m, s_deg;
+    const int n = n_way ? n_way[b] : W;
+    double *cx = lds, *cy = lds + W;
+    for (int i = lane; i < W; i += 64) { cx[i] = i < n ? wx[(size_t)b * W + i] : 0.0; cy[i] = i < n ? wy[(size_t)b * W + i] : 0.0; }
+    __syncthreads();
+    if (lane == 0) {
+        int m = -1, degree = 3;
+        if (n >= 4 && n <= W) {  // "Few reference points."
+            double length = 0;
+            for (int i = 0; i + 1 < n; ++i) { const double ddx = cx[i] - cx[i + 1], ddy = cy[i] - cy[i + 1]; length += sqrt(ddx * ddx + ddy * ddy); }
+            const double average_length = length / (n - 1);
+            degree = average_length > 10 ? 3 : (average_length > 5 ? 4 : 5);
+            if (n > degree) {  // tinyspline throws otherwise
+                const double delta_t = 1.0 / length;
+                double tmp_t = 0;
+                m = 0;
+                while (tmp_t < 1) {
+                    if (m >= M - 1) { m = -2; break; }
+                    s[o + m] = tmp_t;  // parameter values parked in the output row until the evaluation below
+                    ++m;
+                    tmp_t += delta_t;
+                }
+                if (m >= 0) { s[o + m] = 1.0; ++m; }
+            }
+        }
+        s_m = m; s_deg = degree;
+        n_samples[b] = m;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int m = s_m < 0 ? 0 : s_m;
+    for (int i = lane; i < M; i += 64) {
+        double ox = 0, oy = 0;
+        if (i < m) bspline_eval(n, s_deg, cx, cy, s[o + i], ox, oy);
+        x[o + i] = ox; y[o + i] = oy;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (lane == 0) {
+        double acc = 0;
+        for (int i = 0; i < M; ++i) {
+            if (i > 0 && i < m) { const double ddx = x[o + i] - x[o + i - 1], ddy = y[o + i] - y[o + i - 1]; acc += sqrt(ddx * ddx + ddy * ddy); }
+            s[o + i] = i < m ? acc : 0.0;
+        }
+    }
+}
+
+// ReferencePathSmoother::segmentRawReference (reference_path_smoother.cpp:50-91): 1 m stations on the spline through the dense lists.
+__global__ __launch_bounds__(64) void segment_raw_kernel(DevSpline in, int P, double *x, double *y, double *s, double *angle, double *k, int *n_points) {
+    extern __shared__ double lds[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const size_t o = (size_t)b * P;
+    const int Kb = in.n_knots ? in.n_knots[b] : in.K;
+    int n = -1;
+    if (Kb >= 3 && Kb <= in.K) {
+        const double max_s = in.knot_s[(size_t)b * in.K + Kb - 1];
+        n = 1;
+        double last = 0;
+        while (last < max_s) {  // s_list: 0, 1, 2, ... until the last station is >= max_s
+            if (n >= P) { n = -2; break; }
+            last += 1.0;
+            ++n;
+        }
+    }
+    if (n <= 0) {
+        for (int i = lane; i < P; i += 64) { x[o + i] = 0; y[o + i] = 0; s[o + i] = 0; angle[o + i] = 0; k[o + i] = 0; }
+        if (lane == 0) n_points[b] = n;
+        return;
+    }
+    const Spl2 S = stage_spline(in, b, lds);
+    for (int i = lane; i < P; i += 64) {
+        if (i < n) {
+            const double at = (double)i, dx = S.dx(1, at), dy = S.dy(1, at), ddx = S.dx(2, at), ddy = S.dy(2, at);
+            angle[o + i] = atan2(dy, dx);
+            k[o + i] = (dx * ddy - dy * ddx) / pow(dx * dx + dy * dy, 1.5);
+            x[o + i] = S.x(at); y[o + i] = S.y(at); s[o + i] = at;
+        } else { x[o + i] = 0; y[o + i] = 0; s[o + i] = 0; angle[o + i] = 0; k[o + i] = 0; }
+    }
+    if (lane == 0) n_points[b] = n;
+}
+
+// The tail of ReferencePathSmoother::postSmooth (reference_path_smoother.cpp:568-590): QP offsets re-projected onto the spline.
+__global__ __launch_bounds__(64) void post_project_kernel(DevSpline in, int L, const int *n_layers, const double *layer_s, const double *off, double *x, double *y,
+                                                          double *s, double *length_out) {
+    extern __shared__ double lds[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const size_t o = (size_t)b * L;
+    const int Kb = in.n_knots ? in.n_knots[b] : in.K;
+    int n = n_layers ? n_layers[b] : L;
+    if (Kb < 3 || Kb > in.K || n < 1 || n > L) n = 0;
+    if (n == 0) {
+        for (int i = lane; i < L; i += 64) { x[o + i] = 0; y[o + i] = 0; s[o + i] = 0; }
+        if (lane == 0 && length_out) length_out[b] = 0;
+        return;
+    }
+    const Spl2 S = stage_spline(in, b, lds);
+    for (int i = lane; i < L; i += 64) {
+        double ox = 0, oy = 0;
+        if (i < n) {
+            const double ref_s = layer_s[o + i], ref_dir = S.heading(ref_s);
+            ox = S.x(ref_s) + off[o + i] * cos(ref_dir + M_PI_2);
+            oy = S.y(ref_s) + off[o + i] * sin(ref_dir + M_PI_2);
+        }
+        x[o + i] = ox; y[o + i] = oy;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (lane == 0) {
+        double acc = 0;
+        for (int i = 0; i < L; ++i) {
+            if (i > 0 && i < n) { const double ddx = x[o + i] - x[o + i - 1], ddy = y[o + i] - y[o + i - 1]; acc += sqrt(ddx * ddx + ddy * ddy); }
+            s[o + i] = i < n ? acc : 0.0;
+        }
+        if (length_out) length_out[b] = acc;
+    }
+}
+
+// PathOptimizer::segmentSmoothedPath before the re-sampling (path_optimizer.cpp:119-169): initial offset / heading error, goal trim.
+__global__ __launch_bounds__(64) void segment_init_kernel(DevSpline in, const double *start, int start_stride, const double *goal, int goal_stride, int exact, double *init,
+                                                          int *ok) {
+    extern __shared__ double lds[];
+    const int b = blockIdx.x;
+    const int Kb = in.n_knots ? in.n_knots[b] : in.K;
+    const double length = in.length[b];
+    if (Kb < 3 || Kb > in.K || length == 0) {  // "Smoothed path is empty!"
+        if (threadIdx.x == 0) { init[3 * b] = 0; init[3 * b + 1] = 0; init[3 * b + 2] = length; ok[b] = 0; }
+        return;
+    }
+    const Spl2 S = stage_spline(in, b, lds);
+    if (threadIdx.x != 0) return;
+    const double sx = start[(size_t)b * start_stride], sy = start[(size_t)b * start_stride + 1], sz = start[(size_t)b * start_stride + 2];
+    const double gx = goal[(size_t)b * goal_stride], gy = goal[(size_t)b * goal_stride + 1];
+    const double fx = S.x(0), fy = S.y(0), fz = S.heading(0);
+    const double dx = fx - sx, dy = fy - sy;
+    const double local_y = -dx * sin(sz) + dy * cos(sz);
+    const double min_distance = sqrt((sx - fx) * (sx - fx) + (sy - fy) * (sy - fy));
+    const double e0 = local_y < 0 ? min_distance : -min_distance, e1 = wrap_pi(sz - fz);
+    int good = !(fabs(e1) > 75 * M_PI / 180);
+    double len = length;
+    if (good) {
+        const double ex = gx - S.x(length), ey = gy - S.y(length);
+        const double end_distance = sqrt(ex * ex + ey * ey);
+        if (!(fabs(end_distance - 0) < 1e-6)) {
+            const double dsr = exact ? 0.1 : 0.5;
+            double tmp_s = length - dsr, min_dis = end_distance, min_s = length;
+            while (tmp_s > 0) {
+                const double px = S.x(tmp_s), py = S.y(tmp_s);
+                const double d = sqrt((px - gx) * (px - gx) + (py - gy) * (py - gy));
+                if (d < min_dis) { min_dis = d; min_s = tmp_s; }
+                if (d > 8 && min_dis < 8) break;
+                tmp_s -= dsr;
+            }
+            len = min_s;
+        }
+    }
+    init[3 * b] = e0; init[3 * b + 1] = e1; init[3 * b + 2] = len; ok[b] = good;
+}
+
+// ---- plumbing of po_plan_batch: per-instance gates between stages (a failed instance turns every later stage into a no-op) ----
+__global__ void plan_gate_kernel(PlanGate g) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= g.B) return;
+    int st = g.stage[b];
+    switch (g.mode) {
+        case 0:  // before everything
+            st = 0;
+            for (int i = 0; i < 3; ++i) g.start3[3 * b + i] = g.start[4 * b + i];
+            break;
+        case 1:  // after TENSION2: few points / bSpline -> 1, QP not solved -> 2; length = result_s.back() + 3 (TensionSmoother::smooth)
+            if (!st && (g.cnt2[b] < 3 || g.cnt[b] < 3)) st = 1;
+            if (!st && g.info[b].status != PO_STATUS_SOLVED) st = 2;
+            g.length[b] = st ? 0.0 : g.s[(size_t)b * g.stride + g.cnt[b] - 1] + 3;
+            if (st) g.cnt[b] = 0;
+            break;
+        case 2:  // after the search: false -> 3, fewer than 4 layers ("Ref is short") -> 4
+            if (!st && g.cnt[b] < 0) st = 3;
+            if (!st && g.cnt[b] < 4) st = 4;
+            if (st) g.cnt[b] = 0;
+            break;
+        case 3:  // after the post-smoothing QP
+            if (!st && g.info[b].status != PO_STATUS_SOLVED) st = 4;
+            if (st) g.cnt[b] = 0;
+            break;
+        case 4:  // after segmentSmoothedPath's first half
+            if (!st && !g.ok[b]) st = 5;
+            g.length[b] = st ? 0.0 : g.init[3 * b + 2];
+            break;
+        case 5: {  // after re-sampling + bounds: blocked reference -> 6; QP inputs
+            if (!st && g.cnt[b] < 2) st = 6;
+            if (st) g.cnt[b] = 0;
+            int keep = 0;
+            if (!st) {  // OsqpSolver::OsqpSolver (solver.cpp:19-27) + SolverKpAsInput (solver_kp_as_input.cpp:17)
+                double interval = 0;
+                for (int i = 1; i < g.cnt[b] && i < 10; ++i) interval = fmax(interval, g.ref_s[(size_t)b * g.ref_stride + i] - g.ref_s[(size_t)b * g.ref_stride + i - 1]);
+                const double q = 1.2 / interval;
+                keep = (q >= 2147483647.0 || q != q) ? 1 : (int)q;
+                keep = keep > 1 ? keep : 1;
+            }
+            g.keep[b] = keep;
+            g.x0[3 * b] = g.init[3 * b]; g.x0[3 * b + 1] = g.init[3 * b + 1]; g.x0[3 * b + 2] = g.start[4 * b + 3];
+            g.goal_z[b] = g.goal[3 * b + 2];
+            break;
+        }
+        case 6:  // after the path QP
+            if (!st && g.info[b].status != PO_STATUS_SOLVED) st = 7;
+            if (st) g.cnt[b] = 0;
+            break;
+        case 7:  // after the collision check: cnt = n_kept, ok = optimizePath's value
+            if (!st && !g.ok[b]) st = 8;
+            if (st && st != 8) g.cnt[b] = 0;
+            break;
+    }
+    g.stage[b] = st;
+}
+// gather the rows of one keep-group into a compact batch (stride Ng) and scatter its results back
+__global__ void plan_gather_kernel(PlanRows r) {
+    const int g = blockIdx.x, b = r.idx[g];
+    for (int i = threadIdx.x; i < r.Ng; i += blockDim.x) {
+        const size_t so = (size_t)b * r.N + i, d = (size_t)g * r.Ng + i;
+        r.g_x[d] = r.ref_x[so]; r.g_y[d] = r.ref_y[so]; r.g_z[d] = r.ref_z[so]; r.g_k[d] = r.ref_k[so]; r.g_s[d] = r.ref_s[so];
+        for (int j = 0; j < 8; ++j) r.g_bounds[d * 8 + j] = r.bounds[so * 8 + j];
+    }
+    if (threadIdx.x == 0) {
+        for (int j = 0; j < 3; ++j) r.g_x0[3 * g + j] = r.x0[3 * b + j];
+        r.g_goal[g] = r.goal_z[b]; r.g_n[g] = r.n_valid[b];
+    }
+}
+__global__ void plan_scatter_kernel(PlanRows r) {
+    const int g = blockIdx.x, b = r.idx[g];
+    for (int i = threadIdx.x; i < r.N * 5; i += blockDim.x) {
+        const int row = i / 5;
+        r.states[(size_t)b * r.N * 5 + i] = row < r.Ng ? r.g_states[(size_t)g * r.Ng * 5 + i] : 0.0;
+    }
+    if (threadIdx.x == 0) r.info[b] = r.g_info[g];
+}
+__global__ void plan_clear_kernel(int B, int N, const int *stage, double *states, po_info *info) {  // rows of instances that never reached the QP
+    const int b = blockIdx.x;
+    if (!stage[b]) return;
+    for (int i = threadIdx.x; i < N * 5; i += blockDim.x) states[(size_t)b * N * 5 + i] = 0.0;
+    if (threadIdx.x == 0) { po_info z{}; z.status = PO_STATUS_UNSOLVED; info[b] = z; }
+}
+
 }  // namespace po
 
 extern "C" hipError_t po_launch_postcheck(const po::DevMap *m, const po::DevCar *c, int B, int N, const int *n_points, const double *states,
@@ -497,5 +778,43 @@ extern "C" hipError_t po_launch_dp_search(const po::DevMap *m, const po::DevSpli
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(po::spline2_fit_kernel, dim3(in->B), dim3(64), 0, st, *in);
     hipLaunchKernelGGL(po::dp_search_kernel, dim3(in->B), dim3(64), lds, st, *m, *in, *q);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t po_launch_bspline(int B, int W, const int *n_way, const double *wx, const double *wy, int M, double *x, double *y, double *s, int *n_samples, hipStream_t st) {
+    hipLaunchKernelGGL(po::bspline_kernel, dim3(B), dim3(64), sizeof(double) * 2 * (size_t)W, st, B, W, n_way, wx, wy, M, x, y, s, n_samples);
+    return hipGetLastError();
+}
+extern "C" hipError_t po_launch_segment_raw(const po::DevSpline *in, int P, double *x, double *y, double *s, double *angle, double *k, int *n_points, hipStream_t st) {
+    hipLaunchKernelGGL(po::spline2_fit_kernel, dim3(in->B), dim3(64), 0, st, *in);
+    hipLaunchKernelGGL(po::segment_raw_kernel, dim3(in->B), dim3(64), po_spline_lds_bytes(in->K), st, *in, P, x, y, s, angle, k, n_points);
+    return hipGetLastError();
+}
+extern "C" hipError_t po_launch_post_project(const po::DevSpline *in, int L, const int *n_layers, const double *layer_s, const double *off, double *x, double *y, double *s,
+                                             double *length_out, hipStream_t st) {
+    hipLaunchKernelGGL(po::spline2_fit_kernel, dim3(in->B), dim3(64), 0, st, *in);
+    hipLaunchKernelGGL(po::post_project_kernel, dim3(in->B), dim3(64), po_spline_lds_bytes(in->K), st, *in, L, n_layers, layer_s, off, x, y, s, length_out);
+    return hipGetLastError();
+}
+extern "C" hipError_t po_launch_segment_init(const po::DevSpline *in, const double *start, int start_stride, const double *goal, int goal_stride, int exact, double *init,
+                                             int *ok, hipStream_t st) {
+    hipLaunchKernelGGL(po::spline2_fit_kernel, dim3(in->B), dim3(64), 0, st, *in);
+    hipLaunchKernelGGL(po::segment_init_kernel, dim3(in->B), dim3(64), po_spline_lds_bytes(in->K), st, *in, start, start_stride, goal, goal_stride, exact, init, ok);
+    return hipGetLastError();
+}
+extern "C" hipError_t po_launch_plan_gate(const po::PlanGate *g, hipStream_t st) {
+    hipLaunchKernelGGL(po::plan_gate_kernel, dim3((g->B + 127) / 128), dim3(128), 0, st, *g);
+    return hipGetLastError();
+}
+extern "C" hipError_t po_launch_plan_gather(const po::PlanRows *r, hipStream_t st) {
+    hipLaunchKernelGGL(po::plan_gather_kernel, dim3(r->G), dim3(128), 0, st, *r);
+    return hipGetLastError();
+}
+extern "C" hipError_t po_launch_plan_scatter(const po::PlanRows *r, hipStream_t st) {
+    hipLaunchKernelGGL(po::plan_scatter_kernel, dim3(r->G), dim3(128), 0, st, *r);
+    return hipGetLastError();
+}
+extern "C" hipError_t po_launch_plan_clear(int B, int N, const int *stage, double *states, po_info *info, hipStream_t st) {
+    hipLaunchKernelGGL(po::plan_clear_kernel, dim3(B), dim3(128), 0, st, B, N, stage, states, info);
     return hipGetLastError();
 }
