@@ -97,10 +97,36 @@ def stage_legs(torch, binding, synth, eng, stream, dbatch, B, with_cpu):
     st["dp_search"] = {"ms": ms_d, "paths_per_s": B / (ms_d * 1e-3), "layers_mean": float(nl.mean().item()),
                        "edge_evaluations_per_s": float(nl.sum().item()) * 34 * 34 / (ms_d * 1e-3), "workload": f"{B} spline references, 34 lateral samples per layer, layers every 1.5 m"}
     st["resample"] = {"ms": ms_r, "paths_per_s": B / (ms_r * 1e-3), "states_mean": float(ro["n_points"].double().mean().item())}
+    # PathOptimizer::solve end to end (po_plan_batch_device): waypoints + start + goal -> final path, every stage on the device
+    scn = synth.make_planning_scenes(2, 64)
+    eng.set_map(*scn["map"])
+    rs = -(-B // 64)
+    tp = {k: torch.from_numpy(np.ascontiguousarray(np.concatenate([scn[k]] * rs, axis=0)[:B])).cuda() for k in ("way_x", "way_y", "start", "goal")}
+    Np = 320
+    po_ = dict(states=torch.zeros((B, Np, 5), dtype=torch.float64, device="cuda"), n_states=torch.zeros(B, dtype=torch.int32, device="cuda"),
+               ok=torch.zeros(B, dtype=torch.int32, device="cuda"), stage=torch.zeros(B, dtype=torch.int32, device="cuda"), info=torch.zeros((B, 48), dtype=torch.uint8, device="cuda"))
+    way_len = float(np.hypot(np.diff(scn["way_x"], axis=1), np.diff(scn["way_y"], axis=1)).sum(axis=1).max())
+    eng.plan_batch_device(tp, po_, Np, way_len); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        eng.plan_batch_device(tp, po_, Np, way_len)
+    torch.cuda.synchronize()
+    ms_p = (time.perf_counter() - t0) / 3 * 1e3  # wall clock: the call synchronises mid-way to group the QPs by keep_control_steps_
+    pinf = po_["info"].cpu().numpy().view(INFO_DTYPE).reshape(-1)
+    st["full_pipeline"] = {"ms": ms_p, "instances_per_s": B / (ms_p * 1e-3), "ok_frac": float(po_["ok"].double().mean().item()),
+                           "states_mean": float(po_["n_states"].double().mean().item()), "qp_iters_mean": float(pinf["iters"].mean()),
+                           "workload": f"{B} planning instances (24 waypoints over ~70 m, 60-disc map 700 x 700 cells): bSpline -> TENSION2 QP -> DP search -> post QP -> "
+                                       "re-sampling (0.15..0.3 m) -> bounds -> KP QP -> collision check"}
+    eng.set_map(d, res, px, py)
     if with_cpu:
         from oracle import oracle_py
 
         m = oracle_py.make_map(d, res, px, py); p = oracle_py.default_params()
+        ms_ = oracle_py.make_map(*scn["map"])
+        c6 = time.perf_counter()
+        for b in range(16):
+            oracle_py.path_optimizer_solve(p, ms_, scn["way_x"][b], scn["way_y"][b], scn["start"][b], scn["goal"][b])
+        cpu_pipeline = 16 / (time.perf_counter() - c6)
         c0 = time.perf_counter()
         for b in range(64):
             oracle_py.bounds_path(p, m, *[P[k][b] for k in keys])
@@ -119,6 +145,7 @@ def stage_legs(torch, binding, synth, eng, stream, dbatch, B, with_cpu):
         c5 = time.perf_counter()
         for b in range(64):
             oracle_py.resample(p, spn["knot_s"][b], spn["knot_x"][b], spn["knot_y"][b], length[b], 0.15, 0.3, cap=256)
+        st["cpu_port"]["full_pipeline_instances_per_s"] = cpu_pipeline
         st["cpu_port"]["dp_search_paths_per_s"] = 64 / (c5 - c4)
         st["cpu_port"]["resample_paths_per_s"] = 64 / (time.perf_counter() - c5)
     return st

@@ -1,0 +1,35 @@
+"""Generates tests/golden/pipeline_ref.npz from the REFERENCE's own PathOptimizer (oracle/_ref/libpo_ref_smooth.so: path_optimizer.cpp,
+the smoothers, ReferencePath, solver and collision checker compiled where they lie; OSQP stood in by the oracle's ADMM, tinyspline by the
+restated clamped B-spline).  Run in the build container: python tests/golden/make_pipeline_golden.py"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle_py as o, ref_py as r  # noqa: E402
+from path_optimizer_amd import synth  # noqa: E402
+
+SEED, B = 1, 8
+
+
+def main():
+    sc = synth.make_planning_scenes(SEED, B)
+    mp = o.make_map(*sc["map"])
+    p = o.default_params()
+    out = dict(seed=SEED, B=B, ok=np.zeros(B, np.int32), n=np.zeros(B, np.int32))
+    for b in range(B):
+        ok, path = r.path_optimizer_solve(mp, p, sc["way_x"][b], sc["way_y"][b], sc["start"][b], sc["goal"][b])
+        out["ok"][b] = ok; out["n"][b] = len(path); out[f"path_{b}"] = path
+        n, x, y, s = r.bspline(sc["way_x"][b], sc["way_y"][b])
+        out[f"bs_{b}"] = np.stack([x, y, s])
+        m, lists = r.segment_raw(s, x, y)
+        out[f"raw_{b}"] = np.stack(lists)
+    # blocked start: an obstacle on the first metres -> solve() returns false
+    np.savez_compressed(os.path.join(os.path.dirname(__file__), "pipeline_ref.npz"), **out)
+    print("wrote pipeline_ref.npz", out["ok"], out["n"])
+
+
+if __name__ == "__main__":
+    main()
