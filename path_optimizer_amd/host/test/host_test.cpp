@@ -7,6 +7,7 @@
 #include <string>
 
 #include "path_optimizer_amd/map_tools.hpp"
+#include "path_optimizer_amd/path_optimizer.hpp"
 #include "path_optimizer_amd/smoother.hpp"
 #include "path_optimizer_amd/solver.hpp"
 
@@ -138,6 +139,28 @@ int main(int argc, char **argv) {
                                std::fabs(resampled.getMaxKList()[0] - mk_expect) < 1e-12 && std::fabs(resampled.getMaxKpList()[0] - 0.1 / 8.0) < 1e-15;
         std::printf("smoothing stages %s\n", stages_ok ? "ok" : "FAILED");
         if (!stages_ok) return 5;
+        // 5) the top-level class, used like path_optimizer_benchmark.cpp:84-100: PathOptimizer(start, end, map).solve(points, &result)
+        std::vector<State> pts;
+        for (int i = 0; i < 20; ++i) pts.emplace_back(3.0 * i - 30.0, -15.0 + 0.3 * std::sin(1.3 * i), 0.0);
+        State start_state(-30.0, -15.0, 0.0, 0.0), end_state(27.0, pts.back().y, 0.0);
+        PathOptimizer path_optimizer(start_state, end_state, map);
+        std::vector<State> result;
+        const bool po_ok = path_optimizer.solve(pts, &result);
+        std::printf("PathOptimizer::solve ok=%d stage=%d n=%zu end=(%.4f, %.4f) s_end=%.4f\n", (int)po_ok, path_optimizer.lastStage(), result.size(),
+                    result.empty() ? 0.0 : result.back().x, result.empty() ? 0.0 : result.back().y, result.empty() ? 0.0 : result.back().s);
+        std::vector<State> again;
+        SplineKnots kk;
+        for (int i = 0; i < 20; ++i) { kk.s.push_back(3.0 * i); kk.x.push_back(3.0 * i - 30.0); kk.y.push_back(-15.0); }
+        std::vector<State> direct;
+        for (int i = 0; i < 150; ++i) direct.emplace_back(0.3 * i - 30.0, -15.0, 0.0, 0.0, 0.3 * i);
+        const bool ws_ok = path_optimizer.solveWithoutSmoothing(direct, kk, &again);
+        std::printf("solveWithoutSmoothing ok=%d n=%zu y[50]=%.6f\n", (int)ws_ok, again.size(), again.size() > 50 ? again[50].y : 0.0);
+        std::vector<State> none;
+        const bool empty_ok = path_optimizer.solve(std::vector<State>(), &none);
+        const bool top_ok = po_ok && result.size() > 100 && std::fabs(result.back().x - 27.0) < 1.5 && std::fabs(result.back().y + 15.0) < 1.0 && ws_ok && again.size() == 150 &&
+                            std::fabs(again[50].y + 15.0) < 1e-6 && !empty_ok;
+        std::printf("top-level %s\n", top_ok ? "ok" : "FAILED");
+        if (!top_ok) return 6;
     }
     std::string bad = "KCP";
     std::printf("create(KCP)=%s\n", OsqpSolver::create(bad, refs[0], vs[0], N) ? "object" : "nullptr");

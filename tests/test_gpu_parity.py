@@ -238,6 +238,7 @@ def test_host_side_cpp_mirror(binding):
         assert "single ok=1" in r.stdout and "batch rc=0" in r.stdout and "create(KCP)=nullptr" in r.stdout
         assert r.stdout.count("status=1") == 3
         assert "check free=1 hit=1" in r.stdout and "map stages FAILED" not in r.stdout  # Map / updateBounds / CollisionChecker mirrors
+        assert "top-level ok" in r.stdout  # PathOptimizer(start, end, map).solve(points, &path) / solveWithoutSmoothing
         assert "smoothing stages ok" in r.stdout  # TensionSmoother2 / graphSearchDp / postSmooth / buildReferenceFromSpline / updateLimits mirrors
 
 
