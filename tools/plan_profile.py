@@ -1,0 +1,30 @@
+"""Dev tool: po_plan_batch_device on 4096 planning instances (run under rocprofv3 --kernel-trace --stats for the per-kernel split)."""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from path_optimizer_amd import binding, synth  # noqa: E402
+from path_optimizer_amd.abi import INFO_DTYPE  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+scn = synth.make_planning_scenes(2, 64)
+eng = binding.Engine(0)
+eng.set_map(*scn["map"])
+rs = -(-B // 64)
+tp = {k: torch.from_numpy(np.ascontiguousarray(np.concatenate([scn[k]] * rs, axis=0)[:B])).cuda() for k in ("way_x", "way_y", "start", "goal")}
+Np = 320
+out = dict(states=torch.zeros((B, Np, 5), dtype=torch.float64, device="cuda"), n_states=torch.zeros(B, dtype=torch.int32, device="cuda"),
+           ok=torch.zeros(B, dtype=torch.int32, device="cuda"), stage=torch.zeros(B, dtype=torch.int32, device="cuda"), info=torch.zeros((B, 48), dtype=torch.uint8, device="cuda"))
+way_len = float(np.hypot(np.diff(scn["way_x"], axis=1), np.diff(scn["way_y"], axis=1)).sum(axis=1).max())
+eng.plan_batch_device(tp, out, Np, way_len); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(3):
+    eng.plan_batch_device(tp, out, Np, way_len)
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / 3 * 1e3
+inf = out["info"].cpu().numpy().view(INFO_DTYPE).reshape(-1)
+print("plan: %.2f ms / %d = %.0f instances/s, ok %.3f, states mean %.1f, QP iters mean %.0f max %d" % (ms, B, B / ms * 1e3, out["ok"].double().mean().item(),
+      out["n_states"].double().mean().item(), inf["iters"].mean(), inf["iters"].max()))

@@ -5,7 +5,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from path_optimizer_amd import binding, synth  # noqa: E402
 from path_optimizer_amd.abi import INFO_DTYPE  # noqa: E402
 
