@@ -256,7 +256,8 @@ def make_search_inputs(seed: int, B: int, N: int = 200, ds: float = 0.3, max_off
     return sp, np.ascontiguousarray(length), np.ascontiguousarray(start)
 
 
-def make_planning_scenes(seed: int, B: int, n_way: int = 24, way_ds: float = 3.0, noise: float = 0.25, map_kw: dict | None = None):
+def make_planning_scenes(seed: int, B: int, n_way: int = 24, way_ds: float = 3.0, noise: float = 0.25, map_kw: dict | None = None, clear: float = 3.2,
+                         n_discs: int = 60, near: int = 0):
     """Whole planning instances for PathOptimizer::solve (/root/reference/src/test/path_optimizer_benchmark.cpp:47-100 hands it a
     list of waypoints, a start and a goal state over an obstacle-distance map): a smooth curve inside the map, waypoints every `way_ds`
     metres jittered laterally by +-`noise` (what a coarse planner returns), start = first waypoint with the curve's heading, goal =
@@ -286,18 +287,25 @@ def make_planning_scenes(seed: int, B: int, n_way: int = 24, way_ds: float = 3.0
     # one shared map: discs beside the curves, never closer than `clear` to any curve point (wider near the starts)
     discs = []
     tries = 0
-    while len(discs) < 60 and tries < 4000:
+    while len(discs) < n_discs and tries < 4000:
         tries += 1
         ox, oy = rng.uniform(kw["pos"][0] - 0.45 * lx, kw["pos"][0] + 0.45 * lx), rng.uniform(kw["pos"][1] - 0.45 * ly, kw["pos"][1] + 0.45 * ly)
         r = rng.uniform(0.5, 2.0)
         okd = True
         for x, y, fine in curves:
             d = np.hypot(x - ox, y - oy) - r
-            if d.min() < 3.2 or d[fine < 8.0].min() < 5.0:
+            if d.min() < clear or d[fine < 8.0].min() < 5.0:
                 okd = False
                 break
         if okd:
             discs.append((ox, oy, r))
+    for x, y, fine in curves:  # `near` discs per curve right beside it (1.3 .. 2.6 m of free space), wherever the other curves run
+        for _ in range(near):
+            i = int(rng.integers(np.searchsorted(fine, 10.0), len(fine) - 1))
+            r = rng.uniform(0.5, 1.5)
+            gap = r + rng.uniform(1.3, 2.6)
+            hz = math.atan2(y[i + 1] - y[i - 1], x[i + 1] - x[i - 1]) + (math.pi / 2 if rng.uniform() < 0.5 else -math.pi / 2)
+            discs.append((x[i] + gap * math.cos(hz), y[i] + gap * math.sin(hz), r))
     cx = kw["pos"][0] + 0.5 * lx - (np.arange(kw["size_x"]) + 0.5) * kw["resolution"]
     cy = kw["pos"][1] + 0.5 * ly - (np.arange(kw["size_y"]) + 0.5) * kw["resolution"]
     X, Y = np.meshgrid(cx, cy, indexing="ij")
