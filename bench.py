@@ -323,6 +323,26 @@ def main():
                                    "sample": f"first {ns} paths of the same batch, oracle/libpo_oracle.so (OSQP-style ADMM, "
                                              f"sparse LDL', gcc -O3), {c1 - c0:.1f} s, mean iters {float(oinfo['iters'].mean()):.1f}",
                                    "host_cpus": os.cpu_count()}
+            # the reference's OWN solver classes (oracle/_ref/libpo_ref.so = src/solver/*.cpp compiled where they lie: dense-scratch
+            # setHessianMatrix / setConstraintMatrix + getOptimizedPath; OSQP itself stood in by the oracle's ADMM), when that library was built
+            try:
+                from oracle import ref_py
+
+                if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libpo_ref.so")):
+                    nr = min(24, ns)
+                    rp = oracle_py.default_params()
+                    inst = lambda b_: dict(ref_x=batch.ref_x[b_], ref_y=batch.ref_y[b_], ref_z=batch.ref_z[b_], ref_k=batch.ref_k[b_], ref_s=batch.ref_s[b_],
+                                           bounds=batch.bounds[b_], x0=batch.x0[b_], goal_z=batch.goal_z[b_])
+                    ref_py.solve("KP", inst(0), rp)
+                    r0 = time.perf_counter()
+                    for b_ in range(nr):
+                        ref_py.solve("KP", inst(b_), rp)
+                    r1 = time.perf_counter()
+                    out["cpu_baseline_reference_code"] = {"value": nr / (r1 - r0), "unit": "paths/s", "cores": 1, "kind": "reference",
+                                                          "sample": f"first {nr} paths through the reference's OsqpSolver::create(\"KP\")->solve() compiled from its own sources "
+                                                                    f"(18.9 MB dense scratch per solve) with the oracle's ADMM in place of OSQP, {r1 - r0:.1f} s"}
+            except Exception as e:
+                out["cpu_baseline_reference_code"] = {"error": repr(e)}
             # the same sample on every host core, one path slice per process (the reference itself is single-threaded)
             try:
                 import multiprocessing as mp

@@ -72,9 +72,10 @@ struct po_handle_s {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    DevBuf in_buf, out_buf, asm_buf, scale_buf, dbg_buf, map_buf, post_buf, coef_buf, bnd_buf, smooth_buf, smooth_io, plan_coef, plan_io, plan_arena;
+    DevBuf in_buf, out_buf, asm_buf, scale_buf, dbg_buf, map_buf, post_buf, coef_buf, bnd_buf, smooth_buf, smooth_io, plan_coef, plan_io, plan_arena, plan_host;
     po::DevMap map{};  // obstacle-distance layer (po_set_map); map.d == nullptr until set
     std::mutex mu;
+    std::mutex plan_mu;  // held for a whole po_plan_batch* call: its stages share the plan arena
 };
 
 extern "C" {
@@ -166,7 +167,7 @@ int po_destroy(po_handle h) {
     if (!h) return PO_ERR_INVALID;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    h->in_buf.release(); h->out_buf.release(); h->asm_buf.release(); h->scale_buf.release(); h->dbg_buf.release(); h->map_buf.release(); h->post_buf.release(); h->coef_buf.release(); h->bnd_buf.release(); h->smooth_buf.release(); h->smooth_io.release(); h->plan_coef.release(); h->plan_io.release(); h->plan_arena.release();
+    h->in_buf.release(); h->out_buf.release(); h->asm_buf.release(); h->scale_buf.release(); h->dbg_buf.release(); h->map_buf.release(); h->post_buf.release(); h->coef_buf.release(); h->bnd_buf.release(); h->smooth_buf.release(); h->smooth_io.release(); h->plan_coef.release(); h->plan_io.release(); h->plan_arena.release(); h->plan_host.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -801,6 +802,8 @@ int po_internal_device(po_handle h) { return h->device; }
 const po_params *po_internal_params(po_handle h) { return &h->params; }
 int po_internal_has_map(po_handle h) { return h->map.d != nullptr; }
 int po_internal_hip_fail(hipError_t e, const char *what) { return hip_ok(e, what) ? 0 : 1; }
+void *po_internal_plan_host(po_handle h, size_t bytes) { return h->plan_host.ensure(bytes) == PO_OK ? h->plan_host.p : nullptr; }
+std::mutex *po_internal_plan_mutex(po_handle h) { return &h->plan_mu; }
 
 const char *po_strerror(int code) {
     switch (code) {

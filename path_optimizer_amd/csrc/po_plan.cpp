@@ -21,6 +21,9 @@ extern "C" int po_internal_device(po_handle h);
 extern "C" const po_params *po_internal_params(po_handle h);
 extern "C" int po_internal_has_map(po_handle h);
 extern "C" int po_internal_hip_fail(hipError_t e, const char *what);
+extern "C" void *po_internal_plan_host(po_handle h, size_t bytes);
+#include <mutex>
+extern "C" std::mutex *po_internal_plan_mutex(po_handle h);
 // po_post.hip
 extern "C" size_t po_spline_lds_bytes(int K);
 extern "C" hipError_t po_launch_bspline(int B, int W, const int *n_way, const double *wx, const double *wy, int M, double *x, double *y, double *s, int *n_samples, hipStream_t st);
@@ -108,7 +111,7 @@ int po_segment_init_batch_device(po_handle h, const po_spline_in *spline, const 
     return PO_OK;
 }
 
-int po_plan_batch_device(po_handle h, const po_plan_in *in, const po_plan_out *out) {
+static int plan_device_locked(po_handle h, const po_plan_in *in, const po_plan_out *out) {
     if (!h || !in || !out || in->B < 0 || in->W < 4 || in->N < 2) return PO_ERR_INVALID;
     if (in->B > 0 && (!in->way_x || !in->way_y || !in->start || !in->goal || !out->states || !out->n_states || !out->ok)) return PO_ERR_INVALID;
     if (!(in->max_length > 0)) return PO_ERR_INVALID;  // the device entry cannot look at the waypoints
@@ -233,6 +236,12 @@ int po_plan_batch_device(po_handle h, const po_plan_in *in, const po_plan_out *o
     return PO_OK;
 }
 
+int po_plan_batch_device(po_handle h, const po_plan_in *in, const po_plan_out *out) {
+    if (!h) return PO_ERR_INVALID;
+    std::lock_guard<std::mutex> g(*po_internal_plan_mutex(h));
+    return plan_device_locked(h, in, out);
+}
+
 int po_plan_batch(po_handle h, const po_plan_in *in, const po_plan_out *out) {
     if (!h || !in || !out || in->B < 0 || in->W < 4 || in->N < 2) return PO_ERR_INVALID;
     if (in->B > 0 && (!in->way_x || !in->way_y || !in->start || !in->goal || !out->states || !out->n_states || !out->ok)) return PO_ERR_INVALID;
@@ -252,15 +261,16 @@ int po_plan_batch(po_handle h, const po_plan_in *in, const po_plan_out *out) {
     HIP_TRY(hipSetDevice(po_internal_device(h)));
     const size_t bw = sizeof(double) * (size_t)B * in->W, bstates = sizeof(double) * (size_t)B * in->N * 5;
     const size_t total = 2 * bw + sizeof(double) * 7 * (size_t)B + sizeof(int) * 4 * (size_t)B + bstates + sizeof(po_info) * (size_t)B + 256;
-    void *raw = nullptr;
-    HIP_TRY(hipMalloc(&raw, total));  // the arena belongs to the device entry; this staging block is per call
+    std::lock_guard<std::mutex> g(*po_internal_plan_mutex(h));
+    void *raw = po_internal_plan_host(h, total);  // staging block of the host-pointer entry (the arena belongs to the device entry)
+    if (!raw) return PO_ERR_NOMEM;
     Arena A; A.p = static_cast<char *>(raw); A.cap = total;
     double *wx = A.take<double>((size_t)B * in->W), *wy = A.take<double>((size_t)B * in->W), *d_start = A.take<double>(4 * (size_t)B), *d_goal = A.take<double>(3 * (size_t)B);
     double *d_states = A.take<double>((size_t)B * in->N * 5);
     po_info *d_info = A.take<po_info>(B);
     int *d_nway = A.take<int>(B), *d_n = A.take<int>(B), *d_ok = A.take<int>(B), *d_stage = A.take<int>(B);
     int rc = PO_OK;
-    auto fail = [&](int code) { (void)hipFree(raw); return code; };
+    auto fail = [&](int code) { return code; };
     if (po_internal_hip_fail(hipMemcpyAsync(wx, in->way_x, bw, hipMemcpyHostToDevice, st), "H2D way_x")) return fail(PO_ERR_HIP);
     if (po_internal_hip_fail(hipMemcpyAsync(wy, in->way_y, bw, hipMemcpyHostToDevice, st), "H2D way_y")) return fail(PO_ERR_HIP);
     if (po_internal_hip_fail(hipMemcpyAsync(d_start, in->start, sizeof(double) * 4 * B, hipMemcpyHostToDevice, st), "H2D start")) return fail(PO_ERR_HIP);
@@ -269,7 +279,7 @@ int po_plan_batch(po_handle h, const po_plan_in *in, const po_plan_out *out) {
     po_plan_in din = *in;
     din.way_x = wx; din.way_y = wy; din.start = d_start; din.goal = d_goal; din.n_way = in->n_way ? d_nway : nullptr; din.max_length = Lmax;
     po_plan_out dout{d_states, d_n, d_ok, d_stage, d_info};
-    rc = po_plan_batch_device(h, &din, &dout);
+    rc = plan_device_locked(h, &din, &dout);
     if (rc != PO_OK) return fail(rc);
     if (po_internal_hip_fail(hipMemcpyAsync(out->states, d_states, bstates, hipMemcpyDeviceToHost, st), "D2H states")) return fail(PO_ERR_HIP);
     if (po_internal_hip_fail(hipMemcpyAsync(out->n_states, d_n, sizeof(int) * B, hipMemcpyDeviceToHost, st), "D2H n")) return fail(PO_ERR_HIP);
@@ -277,7 +287,6 @@ int po_plan_batch(po_handle h, const po_plan_in *in, const po_plan_out *out) {
     if (out->stage && po_internal_hip_fail(hipMemcpyAsync(out->stage, d_stage, sizeof(int) * B, hipMemcpyDeviceToHost, st), "D2H stage")) return fail(PO_ERR_HIP);
     if (out->info && po_internal_hip_fail(hipMemcpyAsync(out->info, d_info, sizeof(po_info) * B, hipMemcpyDeviceToHost, st), "D2H info")) return fail(PO_ERR_HIP);
     if (po_internal_hip_fail(hipStreamSynchronize(st), "sync")) return fail(PO_ERR_HIP);
-    (void)hipFree(raw);
     return PO_OK;
 }
 
