@@ -117,6 +117,22 @@ def stage_legs(torch, binding, synth, eng, stream, dbatch, B, with_cpu):
                            "states_mean": float(po_["n_states"].double().mean().item()), "qp_iters_mean": float(pinf["iters"].mean()),
                            "workload": f"{B} planning instances (24 waypoints over ~70 m, 60-disc map 700 x 700 cells): bSpline -> TENSION2 QP -> DP search -> post QP -> "
                                        "re-sampling (0.15..0.3 m) -> bounds -> KP QP -> collision check"}
+    # serving pattern: consecutive batches from 3 host threads, one handle (= stream) each; the QP tail of one batch drains under the next
+    import threading
+    engs3, outs3 = [], []
+    for _ in range(3):
+        e3 = binding.Engine(torch.cuda.current_device()); e3.set_map(*scn["map"]); engs3.append(e3)
+        outs3.append({k: torch.zeros_like(v) for k, v in po_.items()})
+        e3.plan_batch_device(tp, outs3[-1], Np, way_len)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=lambda i=i: [engs3[i].plan_batch_device(tp, outs3[i], Np, way_len) for _ in range(2)]) for i in range(3)]
+    [t.start() for t in th]; [t.join() for t in th]
+    torch.cuda.synchronize()
+    ms_p3 = (time.perf_counter() - t0) / 6 * 1e3
+    st["full_pipeline"]["pipelined_3_handles"] = {"ms_per_batch": ms_p3, "instances_per_s": B / (ms_p3 * 1e-3)}
+    for e3 in engs3:
+        e3.close()
     eng.set_map(d, res, px, py)
     if with_cpu:
         from oracle import oracle_py
