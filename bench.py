@@ -101,7 +101,9 @@ def stage_legs(torch, binding, synth, eng, stream, dbatch, B, with_cpu):
     scn = synth.make_planning_scenes(2, 64)
     eng.set_map(*scn["map"])
     rs = -(-B // 64)
-    tp = {k: torch.from_numpy(np.ascontiguousarray(np.concatenate([scn[k]] * rs, axis=0)[:B])).cuda() for k in ("way_x", "way_y", "start", "goal")}
+    # replicate the 64 scenes in a shuffled order: blocks go to the 8 XCDs round-robin, a period-64 pattern would pin scenes to XCDs
+    perm = np.random.default_rng(5).permutation(64 * rs)[:B] % 64
+    tp = {k: torch.from_numpy(np.ascontiguousarray(scn[k][perm])).cuda() for k in ("way_x", "way_y", "start", "goal")}
     Np = 320
     po_ = dict(states=torch.zeros((B, Np, 5), dtype=torch.float64, device="cuda"), n_states=torch.zeros(B, dtype=torch.int32, device="cuda"),
                ok=torch.zeros(B, dtype=torch.int32, device="cuda"), stage=torch.zeros(B, dtype=torch.int32, device="cuda"), info=torch.zeros((B, 48), dtype=torch.uint8, device="cuda"))

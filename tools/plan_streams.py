@@ -14,7 +14,8 @@ from path_optimizer_amd import binding, synth  # noqa: E402
 B = 4096
 scn = synth.make_planning_scenes(2, 64)
 rs = -(-B // 64)
-tp = {k: torch.from_numpy(np.ascontiguousarray(np.concatenate([scn[k]] * rs, axis=0)[:B])).cuda() for k in ("way_x", "way_y", "start", "goal")}
+perm = np.random.default_rng(5).permutation(64 * rs)[:B] % 64  # shuffled replication: a period-64 pattern would pin scenes to XCDs
+tp = {k: torch.from_numpy(np.ascontiguousarray(scn[k][perm])).cuda() for k in ("way_x", "way_y", "start", "goal")}
 Np = 320
 way_len = float(np.hypot(np.diff(scn["way_x"], axis=1), np.diff(scn["way_y"], axis=1)).sum(axis=1).max())
 for T in (1, 2, 3, 4):
