@@ -96,7 +96,8 @@ typedef struct po_params {
     double search_long_spacing;    /* FLAGS_search_longitudial_spacing  (1.5)  */
     double search_lat_spacing;     /* FLAGS_search_lateral_spacing      (0.6)  */
     int    enable_dynamic_segmentation; /* FLAGS_enable_dynamic_segmentation (true) */
-    int    reserved0;
+    int    enable_raw_output;           /* FLAGS_enable_raw_output (true): output the QP states directly; false: densify through a spline */
+    double output_spacing;              /* FLAGS_output_spacing (0.3) */
 } po_params;
 
 typedef struct po_info {
@@ -188,6 +189,15 @@ int po_postcheck_batch(po_handle h, int B, int N, const int *n_points, const dou
                        int *n_valid, int *ok);
 int po_postcheck_batch_device(po_handle h, int B, int N, const int *n_points, const double *states, const po_info *info,
                               int *n_valid, int *ok);
+/* The other output branch of optimizePath (FLAGS_enable_raw_output = false, path_optimizer.cpp:201-226): x(s), y(s) splines through the
+ * solved states, sampled every FLAGS_output_spacing with heading and curvature from the spline, each sample collision-checked; the walk
+ * stops at the first colliding sample.  out_states [B][M][5]; n_out[b] samples kept; ok[b] as po_postcheck_batch (0 for an unsolved QP;
+ * the reference dereferences back() of an empty vector when the very first sample collides: reported as ok = 0, n_out = 0);
+ * n_out[b] = -2 when M is too small. */
+int po_densify_batch(po_handle h, int B, int N, const int *n_points, const double *states, const po_info *info, int M, double *out_states, int *n_out,
+                     int *ok);
+int po_densify_batch_device(po_handle h, int B, int N, const int *n_points, const double *states, const po_info *info, int M, double *out_states,
+                            int *n_out, int *ok);
 /* ---- corridor-bounds producer: ReferencePath::updateBounds -> ReferencePathImpl::updateBoundsImproved,
  * src/data_struct/reference_path_impl.cpp:142-201 (+ getApproxState :121-140, getClearanceWithDirectionStrict :283-472 with
  * FLAGS_enable_simple_boundary_decision = true as shipped, tk::spline src/tools/spline.cpp).  Needs po_set_map.

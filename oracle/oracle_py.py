@@ -358,6 +358,14 @@ def segment_init(ks, kx, ky, length, start, goal, exact_position=0):
     return ok, out[0], out[1], out[2]
 
 
+def densify(params, m: PoMap, states, status, cap=4096):
+    """optimizePath's densifying output branch for one path: (ok, out [n,5])."""
+    st = np.ascontiguousarray(states, dtype=np.float64)
+    out = np.zeros((cap, 5)); n = C.c_int(0)
+    ok = lib().po_oracle_densify(C.byref(params), C.byref(m), st.shape[0], _p(st), int(status), cap, _p(out), C.byref(n))
+    return ok, out[:max(n.value, 0)]
+
+
 def path_optimizer_solve(params, m: PoMap, px, py, start, goal, smooth_params=None):
     """PathOptimizer::solve restated stage by stage on the oracle (start = x, y, heading, k; goal = x, y, heading).
     Returns (ok, path [n,5], trace dict of the intermediate results).  `smooth_params`: OSQP settings of the smoothing QPs (default: same)."""
@@ -394,7 +402,8 @@ def path_optimizer_solve(params, m: PoMap, px, py, start, goal, smooth_params=No
     tr["init"] = (ok, e0, e1, len2)
     if not ok:
         return False, np.zeros((0, 5)), tr
-    nr, (qx, qy, qz, qk, qs) = resample(params, k2s, k2x, k2y, len2, 0.15, 0.3)
+    raw_out = bool(params.enable_raw_output)
+    nr, (qx, qy, qz, qk, qs) = resample(params, k2s, k2x, k2y, len2, 0.15 if raw_out else 0.5, params.output_spacing if raw_out else 1.0)
     bounds, nv = bounds_path(params, m, qx, qy, qz, qs, k2s, k2x, k2y)
     tr["reference"] = (qx, qy, qz, qk, qs, nv)
     if nv < 2:
@@ -404,5 +413,8 @@ def path_optimizer_solve(params, m: PoMap, px, py, start, goal, smooth_params=No
                         bounds[None, :nv].copy(), np.array([[e0, e1, start[3]]]), np.array([goal[2]]))
     states, sinfo, _ = solve_batch(batch, params, want_x=False)
     tr["qp"] = sinfo[0]
+    if not raw_out:
+        okd, dense = densify(params, m, states[0], sinfo["status"][0])
+        return bool(okd), dense, tr
     nvalid, okv = postcheck_batch(params, m, states, sinfo)
     return bool(okv[0]), states[0, :nvalid[0]], tr

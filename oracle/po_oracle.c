@@ -77,6 +77,7 @@ void po_oracle_default_params(po_params *p) {
     /* planning_flags.cpp:41-43,57-63,137 */
     p->mu = 0.4; p->max_curvature_rate = 0.1; p->search_lateral_range = 10.0; p->search_long_spacing = 1.5; p->search_lat_spacing = 0.6;
     p->enable_dynamic_segmentation = 1;
+    p->enable_raw_output = 1; p->output_spacing = 0.3; /* planning_flags.cpp:127-129 */
 }
 
 /* tools.hpp:24-35 — recursive in the reference; same fixed point as this loop */
@@ -2237,5 +2238,33 @@ int po_oracle_segment_init(int K, const double *ks, const double *kx, const doub
         }
     }
     free(S.ax);
+    return ok;
+}
+
+
+/* optimizePath's densifying output branch (path_optimizer.cpp:201-226, FLAGS_enable_raw_output = false).  states [n][5] as solved;
+ * out [cap][5]; returns ok, *n_out = samples kept (-2: cap too small). */
+int po_oracle_densify(const po_params *p, const po_map *m, int n, const double *states, int status, int cap, double *out, int *n_out) {
+    *n_out = 0;
+    if (status != PO_STATUS_SOLVED || n < 3) return 0;
+    double *rx = (double *)malloc(sizeof(double) * (size_t)n * 3), *ry = rx + n, *rs = rx + 2 * n;
+    for (int i = 0; i < n; ++i) { rx[i] = states[5 * i]; ry[i] = states[5 * i + 1]; rs[i] = states[5 * i + 4]; }
+    spl2_t S;
+    if (spl2_init(&S, n, rs, rx, ry)) { free(rx); return 0; }
+    const double delta_s = p->output_spacing;
+    int ok = 1, cnt = 0;
+    for (int i = 0; i * delta_s <= rs[n - 1]; ++i) {
+        const double tmp_s = i * delta_s;
+        const double x = spl2_x(&S, tmp_s), y = spl2_y(&S, tmp_s), z = spl2_heading(&S, tmp_s), k = spl2_curvature(&S, tmp_s);
+        if (p->enable_collision_check && !po_oracle_collision_free(p, m, x, y, z)) {
+            ok = cnt > 0 && out[5 * (cnt - 1) + 4] >= 20.0;
+            break;
+        }
+        if (cnt >= cap) { cnt = -2; ok = 0; break; }
+        out[5 * cnt] = x; out[5 * cnt + 1] = y; out[5 * cnt + 2] = z; out[5 * cnt + 3] = k; out[5 * cnt + 4] = tmp_s;
+        ++cnt;
+    }
+    *n_out = cnt;
+    free(S.ax); free(rx);
     return ok;
 }

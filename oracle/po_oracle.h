@@ -152,6 +152,9 @@ int po_oracle_post_project(int K, const double *ks, const double *kx, const doub
 int po_oracle_segment_init(int K, const double *ks, const double *kx, const double *ky, double length, const double *start, const double *goal,
                            int exact_position, double *out);
 
+/* optimizePath's densifying output branch (path_optimizer.cpp:201-226) */
+int po_oracle_densify(const po_params *p, const po_map *m, int n, const double *states, int status, int cap, double *out, int *n_out);
+
 #ifdef __cplusplus
 }
 #endif

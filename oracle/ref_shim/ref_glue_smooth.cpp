@@ -210,6 +210,9 @@ int po_ref_path_optimizer_solve(const po_map *m, int n_pts, const double *px, co
     using namespace PathOptimizationNS;
     updateConfig();
     OsqpEigen::g_params = *admm;
+    const bool keep_raw = FLAGS_enable_raw_output;
+    FLAGS_enable_raw_output = admm->enable_raw_output != 0;  // the two output branches of optimizePath
+    struct Restore { bool v; ~Restore() { FLAGS_enable_raw_output = v; } } restore{keep_raw};
     grid_map::GridMap gm(*m);
     State st(start[0], start[1], start[2], start[3]), en(goal[0], goal[1], goal[2]);
     PathOptimizer opt(st, en, gm);

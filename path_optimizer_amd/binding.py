@@ -23,7 +23,7 @@ EXPORTS = ["po_default_params", "po_problem_dims", "po_keep_control_steps", "po_
            "po_bounds_batch_device", "po_map_sample", "po_smooth_dims", "po_smooth_batch", "po_smooth_batch_device",
            "po_resample_batch", "po_resample_batch_device", "po_limits_batch", "po_limits_batch_device", "po_dp_search_batch",
            "po_dp_search_batch_device", "po_bspline_batch_device", "po_segment_raw_batch_device", "po_post_project_batch_device",
-           "po_segment_init_batch_device", "po_plan_batch", "po_plan_batch_device"]
+           "po_segment_init_batch_device", "po_plan_batch", "po_plan_batch_device", "po_densify_batch", "po_densify_batch_device"]
 
 
 class PoError(RuntimeError):
@@ -180,6 +180,15 @@ class Engine:
         nv = np.zeros(B, dtype=np.int32); ok = np.zeros(B, dtype=np.int32)
         _check(lib().po_postcheck_batch(self._h, B, N, _np(_i32(n_points)), _np(states), _np(info), _np(nv), _np(ok)))
         return nv, ok
+
+    def densify_batch(self, states, info, M: int, n_points=None):
+        """optimizePath's densifying output branch (host-pointer entry): states [B,N,5], info -> out [B,M,5], n_out [B], ok [B]."""
+        states = np.ascontiguousarray(states, dtype=np.float64)
+        info = np.ascontiguousarray(info)
+        B, N = states.shape[0], states.shape[1]
+        out = np.zeros((B, M, 5)); n = np.zeros(B, dtype=np.int32); ok = np.zeros(B, dtype=np.int32)
+        _check(lib().po_densify_batch(self._h, B, N, _np(_i32(n_points)), _np(states), _np(info), M, _np(out), _np(n), _np(ok)))
+        return out, n, ok
 
     def postcheck_batch_device(self, dev: "DeviceBatch", n_valid, ok):
         """Device-pointer entry on the outputs of solve_batch_device; n_valid / ok are int32 torch tensors [B]."""

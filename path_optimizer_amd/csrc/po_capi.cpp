@@ -23,6 +23,8 @@ extern "C" hipError_t po_launch_assemble(int form, const po::DevBatch *in, const
 extern "C" size_t po_lds_bytes(int form, int N, int C, int keep);
 extern "C" hipError_t po_launch_postcheck(const po::DevMap *m, const po::DevCar *c, int B, int N, const int *n_points, const double *states,
                                           const po_info *info, int *n_valid, int *ok, hipStream_t st);
+extern "C" hipError_t po_launch_densify(const po::DevMap *m, const po::DevCar *c, int B, int N, const int *n_points, const double *states, const po_info *info,
+                                        double spacing, int M, double *out, int *n_out, int *ok, hipStream_t st);
 extern "C" hipError_t po_launch_bounds(const po::DevMap *m, const po::DevBounds *in, double *bounds, int *n_valid, hipStream_t st);
 extern "C" hipError_t po_launch_smooth(const po::DevSmooth *a, hipStream_t st);
 extern "C" size_t po_smooth_lds_bytes(int kind, int P);
@@ -108,6 +110,7 @@ void po_default_params(po_params *p) {
     /* planning_flags.cpp:41-43,57-63,137 */
     p->mu = 0.4; p->max_curvature_rate = 0.1; p->search_lateral_range = 10.0; p->search_long_spacing = 1.5; p->search_lat_spacing = 0.6;
     p->enable_dynamic_segmentation = 1;
+    p->enable_raw_output = 1; p->output_spacing = 0.3; /* planning_flags.cpp:127-129 */
 }
 
 int po_problem_dims(int form, int N, int keep, int *n, int *m, int *C) {
@@ -433,6 +436,45 @@ int po_postcheck_batch_device(po_handle h, int B, int N, const int *n_points, co
     HIP_TRY(hipSetDevice(h->device));
     const po::DevCar car = make_car(h->params);
     HIP_TRY(po_launch_postcheck(&h->map, &car, B, N, n_points, states, info, n_valid, ok, h->stream));
+    return PO_OK;
+}
+
+int po_densify_batch_device(po_handle h, int B, int N, const int *n_points, const double *states, const po_info *info, int M, double *out_states, int *n_out, int *ok) {
+    if (!h || B < 0 || N < 3 || M < 1 || (B > 0 && (!states || !info || !out_states || !n_out || !ok))) return PO_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->map.d && h->params.enable_collision_check) return PO_ERR_INVALID;  // no map set
+    if (!(h->params.output_spacing > 0)) return PO_ERR_INVALID;
+    if (B == 0) return PO_OK;
+    if (sizeof(double) * 15 * (size_t)N > 160 * 1024) return PO_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(h->device));
+    const po::DevCar car = make_car(h->params);
+    HIP_TRY(po_launch_densify(&h->map, &car, B, N, n_points, states, info, h->params.output_spacing, M, out_states, n_out, ok, h->stream));
+    return PO_OK;
+}
+
+int po_densify_batch(po_handle h, int B, int N, const int *n_points, const double *states, const po_info *info, int M, double *out_states, int *n_out, int *ok) {
+    if (!h || B < 0 || N < 3 || M < 1 || (B > 0 && (!states || !info || !out_states || !n_out || !ok))) return PO_ERR_INVALID;
+    if (B == 0) return PO_OK;
+    const size_t bs = sizeof(double) * 5 * (size_t)B * N, bo = sizeof(double) * 5 * (size_t)B * M, bi = sizeof(po_info) * (size_t)B, bn = sizeof(int) * (size_t)B;
+    char *base = nullptr;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        HIP_TRY(hipSetDevice(h->device));
+        if (int rc = h->post_buf.ensure(bs + bo + bi + 3 * bn + 64)) return rc;
+        base = static_cast<char *>(h->post_buf.p);
+        HIP_TRY(hipMemcpyAsync(base, states, bs, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(base + bs + bo, info, bi, hipMemcpyHostToDevice, h->stream));
+        if (n_points) HIP_TRY(hipMemcpyAsync(base + bs + bo + bi, n_points, bn, hipMemcpyHostToDevice, h->stream));
+    }
+    int *dn = reinterpret_cast<int *>(base + bs + bo + bi);
+    const int rc = po_densify_batch_device(h, B, N, n_points ? dn : nullptr, reinterpret_cast<const double *>(base), reinterpret_cast<const po_info *>(base + bs + bo), M,
+                                           reinterpret_cast<double *>(base + bs), dn + B, dn + 2 * B);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIP_TRY(hipMemcpyAsync(out_states, base + bs, bo, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(n_out, dn + B, bn, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(ok, dn + 2 * B, bn, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     return PO_OK;
 }
 

@@ -129,6 +129,8 @@ static int plan_device_locked(po_handle h, const po_plan_in *in, const po_plan_o
     const size_t bM = (size_t)B * M, bP = (size_t)B * P, bL = (size_t)B * Lc, bN = (size_t)B * N;
     size_t need = sizeof(double) * (3 * bM + 8 * bP + 7 * bL + 13 * bN + 5 * bN + 16 * (size_t)B) + sizeof(po_info) * 3 * (size_t)B + sizeof(int) * 16 * (size_t)B + 4096;
     need += sizeof(double) * (18 * bN + 8 * (size_t)B) + sizeof(po_info) * (size_t)B;  // group staging (worst case: one group of everything)
+    const bool raw_out = prm->enable_raw_output != 0;
+    if (!raw_out) need += sizeof(double) * 5 * bN + 64;  // QP states before the densifying output branch
     Arena A;
     A.p = static_cast<char *>(po_internal_arena(h, need));
     if (!A.p) return PO_ERR_NOMEM;
@@ -148,6 +150,7 @@ static int plan_device_locked(po_handle h, const po_plan_in *in, const po_plan_o
     double *g_x = A.take<double>(bN), *g_y = A.take<double>(bN), *g_z = A.take<double>(bN), *g_k = A.take<double>(bN), *g_s = A.take<double>(bN);
     double *g_b = A.take<double>(8 * bN), *g_x0 = A.take<double>(3 * (size_t)B), *g_goal = A.take<double>(B), *g_states = A.take<double>(5 * bN);
     po_info *g_info = A.take<po_info>(B);
+    double *qp_states = raw_out ? out->states : A.take<double>(5 * bN);  // optimizePath's two output branches (path_optimizer.cpp:191 / :201)
     if (A.off > A.cap) return PO_ERR_NOMEM;
 
     po::PlanGate G{};
@@ -182,7 +185,8 @@ static int plan_device_locked(po_handle h, const po_plan_in *in, const po_plan_o
     G.mode = 4; G.init = init; G.ok = okseg; G.length = len3;
     HIP_TRY(po_launch_plan_gate(&G, st));
     po_spline_in sp3{B, Lc, k2_s, k2_x, k2_y, n_lay, len3};
-    PO_TRY(po_resample_batch_device(h, &sp3, 0.15, 0.3, N, rf_x, rf_y, rf_z, rf_k, rf_s, n_ref));  // enable_raw_output: 0.15 / FLAGS_output_spacing
+    // path_optimizer.cpp:171-172: 0.15 / FLAGS_output_spacing when the QP states are output directly, 0.5 / 1.0 when they are densified later
+    PO_TRY(po_resample_batch_device(h, &sp3, raw_out ? 0.15 : 0.5, raw_out ? prm->output_spacing : 1.0, N, rf_x, rf_y, rf_z, rf_k, rf_s, n_ref));
     po_bounds_in bi{B, N, Lc, rf_x, rf_y, rf_z, rf_s, n_ref, k2_s, k2_x, k2_y, n_lay};
     PO_TRY(po_bounds_batch_device(h, &bi, bnd, n_val));
     G.mode = 5; G.cnt = n_val; G.ref_s = rf_s; G.ref_stride = N; G.x0 = x0; G.goal_z = goal_z; G.keep = keep;
@@ -210,7 +214,7 @@ static int plan_device_locked(po_handle h, const po_plan_in *in, const po_plan_o
         R.G = Gn; R.N = N; R.Ng = Ng; R.idx = gidx;
         R.ref_x = rf_x; R.ref_y = rf_y; R.ref_z = rf_z; R.ref_k = rf_k; R.ref_s = rf_s; R.bounds = bnd; R.x0 = x0; R.goal_z = goal_z; R.n_valid = n_val;
         R.g_x = g_x; R.g_y = g_y; R.g_z = g_z; R.g_k = g_k; R.g_s = g_s; R.g_bounds = g_b; R.g_x0 = g_x0; R.g_goal = g_goal; R.g_n = g_n;
-        R.g_states = g_states; R.g_info = g_info; R.states = out->states; R.info = info3;
+        R.g_states = g_states; R.g_info = g_info; R.states = qp_states; R.info = info3;
         HIP_TRY(po_launch_plan_gather(&R, st));
         po_batch_in qi{PO_KP, Gn, Ng, kv.first, g_x, g_y, g_z, g_k, g_s, g_b, g_x0, g_goal, nullptr, nullptr, g_n};
         po_batch_out qo{g_states, g_info, nullptr};
@@ -226,11 +230,12 @@ static int plan_device_locked(po_handle h, const po_plan_in *in, const po_plan_o
         HIP_TRY(hipStreamSynchronize(st));  // gidx / staging are reused by the next group
     }
     if (capacity) HIP_TRY(hipMemcpyAsync(stage, h_stage.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
-    HIP_TRY(po_launch_plan_clear(B, N, stage, out->states, info3, st));
+    HIP_TRY(po_launch_plan_clear(B, N, stage, qp_states, info3, st));
     G.mode = 6; G.cnt = n_val; G.info = info3;
     HIP_TRY(po_launch_plan_gate(&G, st));
     // 8. the tail of optimizePath: arc length + collision check + truncation rule
-    PO_TRY(po_postcheck_batch_device(h, B, N, n_val, out->states, info3, out->n_states, out->ok));
+    if (raw_out) PO_TRY(po_postcheck_batch_device(h, B, N, n_val, out->states, info3, out->n_states, out->ok));
+    else PO_TRY(po_densify_batch_device(h, B, N, n_val, qp_states, info3, N, out->states, out->n_states, out->ok));
     G.mode = 7; G.cnt = out->n_states; G.ok = out->ok;
     HIP_TRY(po_launch_plan_gate(&G, st));
     return PO_OK;

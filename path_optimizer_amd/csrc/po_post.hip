@@ -655,6 +655,58 @@ __global__ __launch_bounds__(64) void segment_init_kernel(DevSpline in, const do
     init[3 * b] = e0; init[3 * b + 1] = e1; init[3 * b + 2] = len; ok[b] = good;
 }
 
+// optimizePath's densifying output branch (path_optimizer.cpp:201-226): splines x(s), y(s) through the solved states (fitted by two lanes
+// in LDS), samples every `spacing` on all lanes, first colliding sample by atomicMin.
+__global__ __launch_bounds__(128) void densify_kernel(DevMap m, DevCar c, int B, int N, const int *n_points, const double *states, const po_info *info, double spacing,
+                                                      int M, double *out, int *n_out, int *ok) {
+    extern __shared__ double lds[];  // knots s, x, y [N] + 2 x (a, b, c, 3 scratch) [N]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ int first;
+    int n = n_points ? n_points[b] : N;
+    n = n < 0 ? 0 : (n > N ? N : n);
+    double *o = out + (size_t)b * M * 5;
+    const bool solved = info[b].status == PO_STATUS_SOLVED && n >= 3;
+    if (!solved) {
+        for (int i = tid; i < M * 5; i += blockDim.x) o[i] = 0;
+        if (tid == 0) { n_out[b] = 0; ok[b] = 0; }
+        return;
+    }
+    double *ks = lds, *kx = lds + N, *ky = lds + 2 * N, *cx = lds + 3 * N, *cy = lds + 9 * N;
+    const double *st = states + (size_t)b * N * 5;
+    for (int i = tid; i < n; i += blockDim.x) { kx[i] = st[5 * i]; ky[i] = st[5 * i + 1]; ks[i] = st[5 * i + 4]; }
+    __syncthreads();
+    if (tid < 2) spline_fit(n, ks, tid ? ky : kx, (tid ? cy : cx), (tid ? cy : cx) + N, (tid ? cy : cx) + 2 * N, (tid ? cy : cx) + 3 * N);
+    __syncthreads();
+    const Spl2 S{n, ks, kx, ky, cx, cx + N, cx + 2 * N, cy, cy + N, cy + 2 * N};
+    const double s_end = ks[n - 1];
+    int total = 0;  // samples i with i * spacing <= s_end (same float test as the reference's loop)
+    while ((double)total * spacing <= s_end) ++total;
+    const int lim = total < M ? total : M;
+    if (tid == 0) first = total;
+    __syncthreads();
+    for (int i = tid; i < M; i += blockDim.x) {
+        double v[5] = {0, 0, 0, 0, 0};
+        if (i < lim) {
+            const double at = (double)i * spacing;
+            v[0] = S.x(at); v[1] = S.y(at); v[2] = S.heading(at); v[3] = S.curvature(at); v[4] = at;
+            if (c.enable && !collision_free(m, c, v[0], v[1], v[2])) atomicMin(&first, i);
+        }
+        for (int j = 0; j < 5; ++j) o[5 * i + j] = v[j];
+    }
+    __syncthreads();
+    const int f = first;
+    if (f < total || total > M) {  // truncated by a collision (or by the capacity)
+        const int keepn = f < lim ? f : lim;
+        for (int i = tid; i < M; i += blockDim.x)
+            if (i >= keepn) for (int j = 0; j < 5; ++j) o[5 * i + j] = 0;
+    }
+    if (tid == 0) {
+        if (f >= total && total <= M) { n_out[b] = total; ok[b] = 1; }
+        else if (f >= lim && total > M) { n_out[b] = -2; ok[b] = 0; }  // M too small before any collision
+        else { n_out[b] = f; ok[b] = (f > 0 && (double)(f - 1) * spacing >= 20.0) ? 1 : 0; }
+    }
+}
+
 // ---- plumbing of po_plan_batch: per-instance gates between stages (a failed instance turns every later stage into a no-op) ----
 __global__ void plan_gate_kernel(PlanGate g) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -816,5 +868,14 @@ extern "C" hipError_t po_launch_plan_scatter(const po::PlanRows *r, hipStream_t 
 }
 extern "C" hipError_t po_launch_plan_clear(int B, int N, const int *stage, double *states, po_info *info, hipStream_t st) {
     hipLaunchKernelGGL(po::plan_clear_kernel, dim3(B), dim3(128), 0, st, B, N, stage, states, info);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t po_launch_densify(const po::DevMap *m, const po::DevCar *c, int B, int N, const int *n_points, const double *states, const po_info *info,
+                                        double spacing, int M, double *out, int *n_out, int *ok, hipStream_t st) {
+    const size_t lds = sizeof(double) * 15 * (size_t)N;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&po::densify_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(po::densify_kernel, dim3(B), dim3(128), lds, st, *m, *c, B, N, n_points, states, info, spacing, M, out, n_out, ok);
     return hipGetLastError();
 }

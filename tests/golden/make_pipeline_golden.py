@@ -26,7 +26,12 @@ def main():
         out[f"bs_{b}"] = np.stack([x, y, s])
         m, lists = r.segment_raw(s, x, y)
         out[f"raw_{b}"] = np.stack(lists)
-    # blocked start: an obstacle on the first metres -> solve() returns false
+    pd = o.default_params()
+    pd.enable_raw_output = 0  # the densifying output branch of optimizePath (path_optimizer.cpp:201-226)
+    for b in range(B):
+        ok, path = r.path_optimizer_solve(mp, pd, sc["way_x"][b], sc["way_y"][b], sc["start"][b], sc["goal"][b])
+        out[f"dense_{b}"] = path
+        assert ok
     np.savez_compressed(os.path.join(os.path.dirname(__file__), "pipeline_ref.npz"), **out)
     print("wrote pipeline_ref.npz", out["ok"], out["n"])
 

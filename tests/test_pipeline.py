@@ -71,6 +71,28 @@ def test_oracle_pipeline_matches_reference_fixtures(oracle, scenes):
         assert np.array_equal(np.stack(lists), g[f"raw_{b}"])
 
 
+def test_oracle_densifying_output_branch(oracle, scenes):
+    """FLAGS_enable_raw_output = false: 0.5 / 1.0 m reference spacing, then x(s), y(s) splines through the QP states sampled every 0.3 m."""
+    sc, g = scenes
+    mp = oracle.make_map(*sc["map"])
+    p = oracle.default_params()
+    p.enable_raw_output = 0
+    for b in range(int(g["B"])):
+        ok, path, tr = oracle.path_optimizer_solve(p, mp, sc["way_x"][b], sc["way_y"][b], sc["start"][b], sc["goal"][b])
+        ref = g[f"dense_{b}"]
+        assert ok and path.shape == ref.shape and np.abs(path - ref).max() < 1e-9
+        assert np.allclose(np.diff(path[:, 4]), 0.3) and tr["reference"][5] < 100  # dense output from a coarse (<= 1 m) reference
+    if HAVE_REF:
+        from oracle import ref_py
+
+        sc2 = synth.make_planning_scenes(7, 24, near=2)
+        mp2 = oracle.make_map(*sc2["map"])
+        for b in (4, 7, 12, 14):  # shortened searches, an infeasible corridor
+            rok, rpath = ref_py.path_optimizer_solve(mp2, p, sc2["way_x"][b], sc2["way_y"][b], sc2["start"][b], sc2["goal"][b])
+            ook, opath, _ = oracle.path_optimizer_solve(p, mp2, sc2["way_x"][b], sc2["way_y"][b], sc2["start"][b], sc2["goal"][b])
+            assert bool(rok) == bool(ook) and rpath.shape == opath.shape and (len(rpath) == 0 or np.abs(rpath - opath).max() < 1e-9)
+
+
 def test_bspline_restatement_properties(oracle):
     """tinyspline is absent (parity unpinned): the restated clamped B-spline at least has the defining properties — end-point
     interpolation, affine invariance, partition of unity (a constant control polygon gives that constant), convex-hull containment."""
@@ -231,3 +253,40 @@ def test_device_pipeline_on_cluttered_scenes(oracle):
         agree += same
     assert agree >= 22, (agree, list(zip(ok, n, stage)))  # a DP tie / threshold may flip on the device (last-ulp trigonometry)
     assert len({s for _, s in outcomes}) >= 3  # the batch really mixes outcomes
+
+
+@pytest.mark.gpu
+def test_device_densifying_output_branch(oracle, scenes):
+    from path_optimizer_amd import binding
+
+    sc, g = scenes
+    p = binding.default_params()
+    p.enable_raw_output = 0
+    eng = binding.Engine(0, p)
+    eng.set_map(*sc["map"])
+    states, n, ok, stage, info = eng.plan_batch(sc["way_x"], sc["way_y"], sc["start"], sc["goal"], N=512)
+    assert ok.all() and not stage.any()
+    for b in range(int(g["B"])):
+        ref = g[f"dense_{b}"]  # the reference's own PathOptimizer::solve with FLAGS_enable_raw_output = false
+        assert n[b] == len(ref) and np.abs(states[b, :n[b]] - ref).max() < 1e-6 and not states[b, n[b]:].any()
+    # the stand-alone entry on states that run into an obstacle: the walk stops at the first colliding sample
+    mp = oracle.make_map(*sc["map"])
+    op = oracle.default_params(); op.enable_raw_output = 0
+    d = sc["map"][0]
+    ix, iy = np.unravel_index(np.argmin(d), d.shape)  # a cell inside a disc
+    res, px, py = sc["map"][1], sc["map"][2], sc["map"][3]
+    ox = px + 0.5 * d.shape[0] * res - (ix + 0.5) * res; oy = py + 0.5 * d.shape[1] * res - (iy + 0.5) * res
+    N = 60
+    t = np.linspace(0, 1, N)
+    st = np.zeros((3, N, 5))
+    for k, (x0, y0) in enumerate(((ox - 40.0, oy), (ox - 12.0, oy + 0.1), (ox - 30.0, oy + 25.0))):  # far away and free / through the disc / beside it
+        st[k, :, 0] = x0 + 42.0 * t; st[k, :, 1] = y0 + 0.5 * np.sin(3 * t); st[k, :, 4] = 42.0 * t
+    inf = np.zeros(3, dtype=info.dtype); inf["status"] = 1; inf["status"][2] = -2
+    out, no, okd = eng.densify_batch(st, inf, 200)
+    for k in range(3):
+        ook, opath = oracle.densify(op, mp, st[k], int(inf["status"][k]), cap=200)
+        assert okd[k] == ook and no[k] == len(opath), (k, okd[k], ook, no[k], len(opath))
+        if len(opath):
+            assert np.abs(out[k, :no[k]] - opath).max() < 1e-9
+    assert no[2] == 0 and okd[2] == 0  # unsolved QP
+    assert eng.densify_batch(st[:1], inf[:1], 20)[1][0] in (-2, no[0])  # capacity flagged unless a collision came first
