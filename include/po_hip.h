@@ -98,6 +98,9 @@ typedef struct po_params {
     int    enable_dynamic_segmentation; /* FLAGS_enable_dynamic_segmentation (true) */
     int    enable_raw_output;           /* FLAGS_enable_raw_output (true): output the QP states directly; false: densify through a spline */
     double output_spacing;              /* FLAGS_output_spacing (0.3) */
+    /* po_plan_batch only: which smoother QP and which path formulation the chain uses */
+    int    smoothing_method;            /* FLAGS_smoothing_method: PO_SMOOTH_TENSION2 (default "TENSION2") or PO_SMOOTH_TENSION ("TENSION") */
+    int    optimization_method;         /* FLAGS_optimization_method: PO_KP (default "KP"), PO_K ("K") or PO_KPC */
 } po_params;
 
 typedef struct po_info {

@@ -8,6 +8,8 @@ import ctypes as C
 import os
 import subprocess
 
+import math
+
 import numpy as np
 
 from path_optimizer_amd.abi import INFO_DTYPE, PoBatchIn, PoBatchOut, PoInfo, PoMap, PoParams
@@ -382,7 +384,7 @@ def path_optimizer_solve(params, m: PoMap, px, py, start, goal, smooth_params=No
     if n < 3:
         return False, np.zeros((0, 5)), tr
     inp = dict(x=rx[None], y=ry[None], angle=ra[None], k=rk[None], s=rs[None], lb=None, ub=None, l0=None)
-    ox, oy, os_, info, _ = smooth_batch(0, sp_, inp)
+    ox, oy, os_, info, _ = smooth_batch(1 if params.smoothing_method == 1 else 0, sp_, inp, m_map=m)
     tr["tension2"] = (ox[0], oy[0], os_[0], info[0])
     if info["status"][0] != 1:
         return False, np.zeros((0, 5)), tr
@@ -408,9 +410,11 @@ def path_optimizer_solve(params, m: PoMap, px, py, start, goal, smooth_params=No
     tr["reference"] = (qx, qy, qz, qk, qs, nv)
     if nv < 2:
         return False, np.zeros((0, 5)), tr
-    keep = keep_steps(PO_KP, qs[:nv])
-    batch = synth.Batch(PO_KP, 1, nv, keep, qx[None, :nv].copy(), qy[None, :nv].copy(), qz[None, :nv].copy(), qk[None, :nv].copy(), qs[None, :nv].copy(),
-                        bounds[None, :nv].copy(), np.array([[e0, e1, start[3]]]), np.array([goal[2]]))
+    form = params.optimization_method if params.optimization_method in (1, 2) else PO_KP
+    keep = keep_steps(form, qs[:nv])
+    lim = (np.full((1, nv), math.tan(params.max_steer) / params.wheel_base), np.full((1, nv), np.finfo(np.float64).max)) if form == 1 else (None, None)
+    batch = synth.Batch(form, 1, nv, keep, qx[None, :nv].copy(), qy[None, :nv].copy(), qz[None, :nv].copy(), qk[None, :nv].copy(), qs[None, :nv].copy(),
+                        bounds[None, :nv].copy(), np.array([[e0, e1, start[3]]]), np.array([goal[2]]), lim[0], lim[1])
     states, sinfo, _ = solve_batch(batch, params, want_x=False)
     tr["qp"] = sinfo[0]
     if not raw_out:

@@ -128,7 +128,7 @@ static int plan_device_locked(po_handle h, const po_plan_in *in, const po_plan_o
     const int N = in->N;
     const size_t bM = (size_t)B * M, bP = (size_t)B * P, bL = (size_t)B * Lc, bN = (size_t)B * N;
     size_t need = sizeof(double) * (3 * bM + 8 * bP + 7 * bL + 13 * bN + 5 * bN + 16 * (size_t)B) + sizeof(po_info) * 3 * (size_t)B + sizeof(int) * 16 * (size_t)B + 4096;
-    need += sizeof(double) * (18 * bN + 8 * (size_t)B) + sizeof(po_info) * (size_t)B;  // group staging (worst case: one group of everything)
+    need += sizeof(double) * (20 * bN + 8 * (size_t)B) + sizeof(po_info) * (size_t)B;  // group staging + KPC limits (worst case: one group of everything)
     const bool raw_out = prm->enable_raw_output != 0;
     if (!raw_out) need += sizeof(double) * 5 * bN + 64;  // QP states before the densifying output branch
     Arena A;
@@ -150,6 +150,7 @@ static int plan_device_locked(po_handle h, const po_plan_in *in, const po_plan_o
     double *g_x = A.take<double>(bN), *g_y = A.take<double>(bN), *g_z = A.take<double>(bN), *g_k = A.take<double>(bN), *g_s = A.take<double>(bN);
     double *g_b = A.take<double>(8 * bN), *g_x0 = A.take<double>(3 * (size_t)B), *g_goal = A.take<double>(B), *g_states = A.take<double>(5 * bN);
     po_info *g_info = A.take<po_info>(B);
+    double *lim_k = A.take<double>(bN), *lim_kp = A.take<double>(bN);
     double *qp_states = raw_out ? out->states : A.take<double>(5 * bN);  // optimizePath's two output branches (path_optimizer.cpp:191 / :201)
     if (A.off > A.cap) return PO_ERR_NOMEM;
 
@@ -162,7 +163,8 @@ static int plan_device_locked(po_handle h, const po_plan_in *in, const po_plan_o
     po_spline_in raw{B, M, bs_s, bs_x, bs_y, n_bs, nullptr};
     PO_TRY(po_segment_raw_batch_device(h, &raw, P, rw_x, rw_y, rw_s, rw_a, rw_k, n_raw));
     // 3. TensionSmoother2::osqpSmooth
-    po_smooth_in s1{PO_SMOOTH_TENSION2, B, P, n_raw, rw_x, rw_y, rw_a, rw_k, rw_s, nullptr, nullptr, nullptr};
+    const int smoother = prm->smoothing_method == PO_SMOOTH_TENSION ? PO_SMOOTH_TENSION : PO_SMOOTH_TENSION2;  // ReferencePathSmoother::create
+    po_smooth_in s1{smoother, B, P, n_raw, rw_x, rw_y, rw_a, rw_k, rw_s, nullptr, nullptr, nullptr};
     po_smooth_out o1{t2_x, t2_y, t2_s, info1, nullptr};
     PO_TRY(po_smooth_batch_device(h, &s1, &o1));
     G.mode = 1; G.cnt = n_raw; G.cnt2 = n_bs; G.info = info1; G.s = t2_s; G.stride = P; G.length = len1;
@@ -198,11 +200,18 @@ static int plan_device_locked(po_handle h, const po_plan_in *in, const po_plan_o
     HIP_TRY(hipMemcpyAsync(h_nval.data(), n_val, sizeof(int) * B, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(h_nref.data(), n_ref, sizeof(int) * B, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    const int form = prm->optimization_method == PO_K ? PO_K : (prm->optimization_method == PO_KPC ? PO_KPC : PO_KP);
     std::map<int, std::vector<int>> groups;
     bool capacity = false;
     for (int b = 0; b < B; ++b) {
         if (h_nref[b] == -2 && h_stage[b] == 6) { h_stage[b] = 9; capacity = true; }  // N too small for the re-sampled reference
-        if (h_stage[b] == 0) groups[h_keep[b]].push_back(b);
+        if (h_stage[b] == 0) groups[form == PO_KP ? h_keep[b] : (form == PO_KPC ? 4 : 1)].push_back(b);  // K has no held control, KPC fixes keep = 4
+    }
+    if (form == PO_KPC) {
+        std::vector<double> hk((size_t)bN, std::tan(prm->max_steer) / prm->wheel_base), hkp((size_t)bN, 1.7976931348623157e308);
+        HIP_TRY(hipMemcpyAsync(lim_k, hk.data(), sizeof(double) * bN, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(lim_kp, hkp.data(), sizeof(double) * bN, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
     }
     for (auto &kv : groups) {
         const std::vector<int> &ids = kv.second;
@@ -216,7 +225,9 @@ static int plan_device_locked(po_handle h, const po_plan_in *in, const po_plan_o
         R.g_x = g_x; R.g_y = g_y; R.g_z = g_z; R.g_k = g_k; R.g_s = g_s; R.g_bounds = g_b; R.g_x0 = g_x0; R.g_goal = g_goal; R.g_n = g_n;
         R.g_states = g_states; R.g_info = g_info; R.states = qp_states; R.info = info3;
         HIP_TRY(po_launch_plan_gather(&R, st));
-        po_batch_in qi{PO_KP, Gn, Ng, kv.first, g_x, g_y, g_z, g_k, g_s, g_b, g_x0, g_goal, nullptr, nullptr, g_n};
+        // KPC with a spline-built reference: updateLimits() has no speed profile ("Reference states must be given directly!") and falls back to
+        // max_k = tan(max_steering_angle) / wheel_base, max_kp = DBL_MAX (reference_path_impl.cpp:214-222)
+        po_batch_in qi{form, Gn, Ng, kv.first, g_x, g_y, g_z, g_k, g_s, g_b, g_x0, g_goal, form == PO_KPC ? lim_k : nullptr, form == PO_KPC ? lim_kp : nullptr, g_n};
         po_batch_out qo{g_states, g_info, nullptr};
         const int rc = po_solve_batch_device(h, &qi, &qo);
         if (rc == PO_ERR_UNSUPPORTED) {  // does not fit the on-chip tile: flagged per instance, the others go on
