@@ -32,7 +32,7 @@ extern "C" size_t po_smooth_scratch_doubles(int kind, int P);
 extern "C" hipError_t po_launch_resample(const po::DevSpline *in, const po::DevResample *r, hipStream_t st);
 extern "C" hipError_t po_launch_limits(int B, int N, const int *n_points, const double *v, const double *a, double *max_k, double *max_kp, double mu, double rate, hipStream_t st);
 extern "C" hipError_t po_launch_dp_search(const po::DevMap *m, const po::DevSpline *in, const po::DevSearch *q, hipStream_t st);
-extern "C" size_t po_dp_lds_bytes(int K);
+extern "C" size_t po_dp_lds_bytes(int K, int L);
 extern "C" size_t po_spline_lds_bytes(int K);
 extern "C" hipError_t po_launch_map_sample(const po::DevMap *m, int n, const double *xy, double *dist, int *inside, hipStream_t st);
 
@@ -713,7 +713,7 @@ int po_dp_search_batch_device(po_handle h, const po_spline_in *in, const double 
     std::lock_guard<std::mutex> g(h->mu);
     if (!h->map.d) return PO_ERR_INVALID;  // po_set_map first
     if (in->B == 0) return PO_OK;
-    if (po_dp_lds_bytes(in->K) > 160 * 1024) return PO_ERR_UNSUPPORTED;
+    if (po_dp_lds_bytes(in->K, L) > 160 * 1024) return PO_ERR_UNSUPPORTED;
     HIP_TRY(hipSetDevice(h->device));
     po::DevSpline D{};
     if (int rc = make_dev_spline(h, in, &D)) return rc;

@@ -303,12 +303,13 @@ __global__ __launch_bounds__(64) void dp_search_kernel(DevMap m, DevSpline in, D
         return;
     }
     const Spl2 S = stage_spline(in, b, lds);
-    double *ls = lds + 9 * S.K;                // [kDpMaxLayers] layer arc lengths
-    double *nx = ls + kDpMaxLayers;            // node x, y, dir, cost of the previous / current layer (2 x 4 x 64)
+    const int LM = q.L < kDpMaxLayers ? q.L : kDpMaxLayers;  // layer tables are sized by the caller's capacity (LDS decides the occupancy)
+    double *ls = lds + 9 * S.K;                // [LM] layer arc lengths
+    double *nx = ls + LM;                      // node x, y, dir, cost of the previous / current layer (2 x 4 x 64)
     double *lat = nx + 2 * 4 * kDpMaxLat;      // [kDpMaxLat] lateral offsets
-    unsigned long long *fmask = reinterpret_cast<unsigned long long *>(lat + kDpMaxLat);  // [kDpMaxLayers] feasibility bits
-    unsigned char *parent = reinterpret_cast<unsigned char *>(fmask + kDpMaxLayers);             // [kDpMaxLayers][64]
-    unsigned char *chosen = parent + kDpMaxLayers * kDpMaxLat;                                    // [kDpMaxLayers]
+    unsigned long long *fmask = reinterpret_cast<unsigned long long *>(lat + kDpMaxLat);  // [LM] feasibility bits
+    unsigned char *parent = reinterpret_cast<unsigned char *>(fmask + LM);             // [LM][64]
+    unsigned char *chosen = parent + LM * kDpMaxLat;                                    // [LM]
     __shared__ int s_L, s_rc;
     const double length = in.length[b], sx = q.start[3 * b], sy = q.start[3 * b + 1], sz = q.start[3 * b + 2];
     const double search_threshold = 1.45;
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(64) void dp_search_kernel(DevMap m, DevSpline in, D
     // ---- layers (running sum, like the reference) ----
     if (lane == 0) {
         const double search_ds = length > 6 ? q.long_spacing : 0.5;
-        const int cap = q.L < kDpMaxLayers ? q.L : kDpMaxLayers;
+        const int cap = LM;
         double t = tmp_s0;
         int L = 0, rc = 0;
         while (t < length) {
@@ -810,8 +811,9 @@ extern "C" hipError_t po_launch_bounds(const po::DevMap *m, const po::DevBounds 
 }
 
 extern "C" size_t po_spline_lds_bytes(int K) { return sizeof(double) * 9 * (size_t)K; }
-extern "C" size_t po_dp_lds_bytes(int K) {
-    return sizeof(double) * (9 * (size_t)K + po::kDpMaxLayers + 2 * 4 * po::kDpMaxLat + po::kDpMaxLat) + 8 * (size_t)po::kDpMaxLayers + (size_t)po::kDpMaxLayers * po::kDpMaxLat + po::kDpMaxLayers;
+extern "C" size_t po_dp_lds_bytes(int K, int L) {
+    const size_t LM = (size_t)(L < po::kDpMaxLayers ? L : po::kDpMaxLayers);
+    return sizeof(double) * (9 * (size_t)K + LM + 2 * 4 * po::kDpMaxLat + po::kDpMaxLat) + 8 * LM + LM * po::kDpMaxLat + LM + 16;
 }
 extern "C" hipError_t po_launch_resample(const po::DevSpline *in, const po::DevResample *r, hipStream_t st) {
     hipLaunchKernelGGL(po::spline2_fit_kernel, dim3(in->B), dim3(64), 0, st, *in);
@@ -825,7 +827,7 @@ extern "C" hipError_t po_launch_limits(int B, int N, const int *n_points, const 
     return hipGetLastError();
 }
 extern "C" hipError_t po_launch_dp_search(const po::DevMap *m, const po::DevSpline *in, const po::DevSearch *q, hipStream_t st) {
-    const size_t lds = po_dp_lds_bytes(in->K);
+    const size_t lds = po_dp_lds_bytes(in->K, q->L);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&po::dp_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(po::spline2_fit_kernel, dim3(in->B), dim3(64), 0, st, *in);
