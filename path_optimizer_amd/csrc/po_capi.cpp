@@ -673,9 +673,9 @@ static int spline_args_ok(const po_spline_in *in) {
     return in && in->B >= 0 && in->K >= 3 && (in->B == 0 || (in->knot_s && in->knot_x && in->knot_y && in->length));
 }
 static int make_dev_spline(po_handle h, const po_spline_in *in, po::DevSpline *D) {
-    if (int rc = h->plan_coef.ensure(sizeof(double) * (size_t)in->B * 2 * 6 * in->K)) return rc;
+    (void)h;  // the spline coefficients are fitted in LDS by each consumer kernel
     D->B = in->B; D->K = in->K; D->knot_s = in->knot_s; D->knot_x = in->knot_x; D->knot_y = in->knot_y; D->n_knots = in->n_knots;
-    D->length = in->length; D->coef = static_cast<double *>(h->plan_coef.p);
+    D->length = in->length; D->coef = nullptr;
     return PO_OK;
 }
 

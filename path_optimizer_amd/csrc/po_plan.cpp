@@ -51,10 +51,9 @@ namespace {
 int dev_spline(po_handle h, const po_spline_in *in, po::DevSpline *D) {
     if (!in || in->B < 0 || in->K < 3 || (in->B > 0 && (!in->knot_s || !in->knot_x || !in->knot_y))) return PO_ERR_INVALID;
     if (po_spline_lds_bytes(in->K) > 64 * 1024) return PO_ERR_UNSUPPORTED;
-    void *co = po_internal_plan_coef(h, sizeof(double) * (size_t)std::max(in->B, 1) * 2 * 6 * in->K);
-    if (!co) return PO_ERR_NOMEM;
+    (void)h;  // the spline coefficients are fitted in LDS by each consumer kernel
     D->B = in->B; D->K = in->K; D->knot_s = in->knot_s; D->knot_x = in->knot_x; D->knot_y = in->knot_y; D->n_knots = in->n_knots; D->length = in->length;
-    D->coef = static_cast<double *>(co);
+    D->coef = nullptr;
     return PO_OK;
 }
 struct Arena {  // bump allocator over the handle's plan arena

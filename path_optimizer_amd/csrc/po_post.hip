@@ -212,27 +212,25 @@ struct Spl2 {
         return (x1 * y2 - y1 * x2) / pow(x1 * x1 + y1 * y1, 1.5);
     }
 };
+// Knots into LDS, then the two natural-spline fits (x(s) and y(s)) by lanes 0 and 1 right there: 15 K doubles of LDS
+// (s, x, y | a, b, c + 3 K scratch for each spline).  No separate fit kernel, no coefficient round trip through HBM.
 __device__ __forceinline__ Spl2 stage_spline(const DevSpline &in, int b, double *lds) {
     int K = in.n_knots ? in.n_knots[b] : in.K;
     K = K < 3 ? 3 : (K > in.K ? in.K : K);
-    const double *co = in.coef + (size_t)b * 2 * 6 * in.K;
     for (int i = threadIdx.x; i < K; i += blockDim.x) {
         lds[i] = in.knot_s[(size_t)b * in.K + i];
         lds[K + i] = in.knot_x[(size_t)b * in.K + i];
         lds[2 * K + i] = in.knot_y[(size_t)b * in.K + i];
-        for (int w = 0; w < 3; ++w) { lds[(3 + w) * K + i] = co[w * in.K + i]; lds[(6 + w) * K + i] = co[(6 + w) * in.K + i]; }
     }
     __syncthreads();
-    Spl2 S{K, lds, lds + K, lds + 2 * K, lds + 3 * K, lds + 4 * K, lds + 5 * K, lds + 6 * K, lds + 7 * K, lds + 8 * K};
+    double *cx = lds + 3 * K, *cy = lds + 9 * K;
+    if (threadIdx.x < 2) {
+        double *co = threadIdx.x ? cy : cx;
+        spline_fit(K, lds, threadIdx.x ? lds + 2 * K : lds + K, co, co + K, co + 2 * K, co + 3 * K);
+    }
+    __syncthreads();
+    Spl2 S{K, lds, lds + K, lds + 2 * K, cx, cx + K, cx + 2 * K, cy, cy + K, cy + 2 * K};
     return S;
-}
-__global__ void spline2_fit_kernel(DevSpline in) {  // same fit as spline_fit_kernel, for the DevSpline argument block
-    const int b = blockIdx.x, which = threadIdx.x;
-    if (which > 1) return;
-    int K = in.n_knots ? in.n_knots[b] : in.K;
-    K = K < 3 ? 3 : (K > in.K ? in.K : K);
-    double *co = in.coef + ((size_t)b * 2 + which) * 6 * in.K;
-    spline_fit(K, in.knot_s + (size_t)b * in.K, (which ? in.knot_y : in.knot_x) + (size_t)b * in.K, co, co + in.K, co + 2 * in.K, co + 3 * in.K);
 }
 
 // ReferencePathImpl::buildReferenceFromSpline (reference_path_impl.cpp:474-499).  One block per path: lane 0 walks the arc-length
@@ -304,7 +302,7 @@ __global__ __launch_bounds__(64) void dp_search_kernel(DevMap m, DevSpline in, D
     }
     const Spl2 S = stage_spline(in, b, lds);
     const int LM = q.L < kDpMaxLayers ? q.L : kDpMaxLayers;  // layer tables are sized by the caller's capacity (LDS decides the occupancy)
-    double *ls = lds + 9 * S.K;                // [LM] layer arc lengths
+    double *ls = lds + 15 * S.K;               // [LM] layer arc lengths
     double *nx = ls + LM;                      // node x, y, dir, cost of the previous / current layer (2 x 4 x 64)
     double *lat = nx + 2 * 4 * kDpMaxLat;      // [kDpMaxLat] lateral offsets
     unsigned long long *fmask = reinterpret_cast<unsigned long long *>(lat + kDpMaxLat);  // [LM] feasibility bits
@@ -810,13 +808,12 @@ extern "C" hipError_t po_launch_bounds(const po::DevMap *m, const po::DevBounds 
     return hipGetLastError();
 }
 
-extern "C" size_t po_spline_lds_bytes(int K) { return sizeof(double) * 9 * (size_t)K; }
+extern "C" size_t po_spline_lds_bytes(int K) { return sizeof(double) * 15 * (size_t)K; }
 extern "C" size_t po_dp_lds_bytes(int K, int L) {
     const size_t LM = (size_t)(L < po::kDpMaxLayers ? L : po::kDpMaxLayers);
-    return sizeof(double) * (9 * (size_t)K + LM + 2 * 4 * po::kDpMaxLat + po::kDpMaxLat) + 8 * LM + LM * po::kDpMaxLat + LM + 16;
+    return sizeof(double) * (15 * (size_t)K + LM + 2 * 4 * po::kDpMaxLat + po::kDpMaxLat) + 8 * LM + LM * po::kDpMaxLat + LM + 16;
 }
 extern "C" hipError_t po_launch_resample(const po::DevSpline *in, const po::DevResample *r, hipStream_t st) {
-    hipLaunchKernelGGL(po::spline2_fit_kernel, dim3(in->B), dim3(64), 0, st, *in);
     hipLaunchKernelGGL(po::resample_kernel, dim3(in->B), dim3(64), po_spline_lds_bytes(in->K), st, *in, *r);
     return hipGetLastError();
 }
@@ -830,7 +827,6 @@ extern "C" hipError_t po_launch_dp_search(const po::DevMap *m, const po::DevSpli
     const size_t lds = po_dp_lds_bytes(in->K, q->L);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&po::dp_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(po::spline2_fit_kernel, dim3(in->B), dim3(64), 0, st, *in);
     hipLaunchKernelGGL(po::dp_search_kernel, dim3(in->B), dim3(64), lds, st, *m, *in, *q);
     return hipGetLastError();
 }
@@ -840,19 +836,16 @@ extern "C" hipError_t po_launch_bspline(int B, int W, const int *n_way, const do
     return hipGetLastError();
 }
 extern "C" hipError_t po_launch_segment_raw(const po::DevSpline *in, int P, double *x, double *y, double *s, double *angle, double *k, int *n_points, hipStream_t st) {
-    hipLaunchKernelGGL(po::spline2_fit_kernel, dim3(in->B), dim3(64), 0, st, *in);
     hipLaunchKernelGGL(po::segment_raw_kernel, dim3(in->B), dim3(64), po_spline_lds_bytes(in->K), st, *in, P, x, y, s, angle, k, n_points);
     return hipGetLastError();
 }
 extern "C" hipError_t po_launch_post_project(const po::DevSpline *in, int L, const int *n_layers, const double *layer_s, const double *off, double *x, double *y, double *s,
                                              double *length_out, hipStream_t st) {
-    hipLaunchKernelGGL(po::spline2_fit_kernel, dim3(in->B), dim3(64), 0, st, *in);
     hipLaunchKernelGGL(po::post_project_kernel, dim3(in->B), dim3(64), po_spline_lds_bytes(in->K), st, *in, L, n_layers, layer_s, off, x, y, s, length_out);
     return hipGetLastError();
 }
 extern "C" hipError_t po_launch_segment_init(const po::DevSpline *in, const double *start, int start_stride, const double *goal, int goal_stride, int exact, double *init,
                                              int *ok, hipStream_t st) {
-    hipLaunchKernelGGL(po::spline2_fit_kernel, dim3(in->B), dim3(64), 0, st, *in);
     hipLaunchKernelGGL(po::segment_init_kernel, dim3(in->B), dim3(64), po_spline_lds_bytes(in->K), st, *in, start, start_stride, goal, goal_stride, exact, init, ok);
     return hipGetLastError();
 }
