@@ -44,6 +44,7 @@ struct DevBatch {
     const int *n_points;    // optional [B]: ragged batch (points of each path <= N); arrays keep stride N
     const double *scale;    // [B][64] per-path equilibration block (po_scale.hpp)
     long long *dbg_cycles;  // optional [B][4] per-phase shader-clock totals (dev tool), or nullptr
+    int perm_bits;          // block -> path permutation: ceil(log2 B) bits of mixing (0 = blockIdx order), see solve_kernel_fast
     int n, m;
 };
 

@@ -14,7 +14,9 @@ scn = synth.make_planning_scenes(2, 64)
 eng = binding.Engine(0)
 eng.set_map(*scn["map"])
 rs = -(-B // 64)
-perm = np.random.default_rng(5).permutation(64 * rs)[:B] % 64  # shuffled replication: a period-64 pattern would pin scenes to XCDs
+perm = np.random.default_rng(5).permutation(64 * rs)[:B] % 64  # shuffled replication; "periodic" as 2nd argument: scene b % 64 (worst case for a round-robin XCD dispatch)
+if len(sys.argv) > 2 and sys.argv[2] == "periodic":
+    perm = np.arange(B) % 64
 tp = {k: torch.from_numpy(np.ascontiguousarray(scn[k][perm])).cuda() for k in ("way_x", "way_y", "start", "goal")}
 Np = 320
 out = dict(states=torch.zeros((B, Np, 5), dtype=torch.float64, device="cuda"), n_states=torch.zeros(B, dtype=torch.int32, device="cuda"),
