@@ -101,6 +101,8 @@ typedef struct po_params {
     /* po_plan_batch only: which smoother QP and which path formulation the chain uses */
     int    smoothing_method;            /* FLAGS_smoothing_method: PO_SMOOTH_TENSION2 (default "TENSION2") or PO_SMOOTH_TENSION ("TENSION") */
     int    optimization_method;         /* FLAGS_optimization_method: PO_KP (default "KP"), PO_K ("K") or PO_KPC */
+    int    enable_exact_position;       /* FLAGS_enable_exact_position (false): goal-trim search step 0.1 m instead of 0.5 m (path_optimizer.cpp:151) */
+    int    reserved1;
 } po_params;
 
 typedef struct po_info {

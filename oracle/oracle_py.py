@@ -400,7 +400,7 @@ def path_optimizer_solve(params, m: PoMap, px, py, start, goal, smooth_params=No
         return False, np.zeros((0, 5)), tr
     k2x, k2y, k2s = post_project(k1s, k1x, k1y, ls, off[0])
     tr["post"] = (k2s, k2x, k2y, off[0])
-    ok, e0, e1, len2 = segment_init(k2s, k2x, k2y, k2s[-1], start[:3], goal[:2])
+    ok, e0, e1, len2 = segment_init(k2s, k2x, k2y, k2s[-1], start[:3], goal[:2], exact_position=int(params.enable_exact_position))
     tr["init"] = (ok, e0, e1, len2)
     if not ok:
         return False, np.zeros((0, 5)), tr

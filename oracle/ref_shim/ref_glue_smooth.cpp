@@ -215,7 +215,9 @@ int po_ref_path_optimizer_solve(const po_map *m, int n_pts, const double *px, co
     const std::string keep_sm = FLAGS_smoothing_method, keep_om = FLAGS_optimization_method;
     FLAGS_smoothing_method = admm->smoothing_method == PO_SMOOTH_TENSION ? "TENSION" : "TENSION2";
     FLAGS_optimization_method = admm->optimization_method == PO_K ? "K" : (admm->optimization_method == PO_KPC ? "KPC" : "KP");
-    struct Restore { bool v; std::string sm, om; ~Restore() { FLAGS_enable_raw_output = v; FLAGS_smoothing_method = sm; FLAGS_optimization_method = om; } } restore{keep_raw, keep_sm, keep_om};
+    const bool keep_ex = FLAGS_enable_exact_position;
+    FLAGS_enable_exact_position = admm->enable_exact_position != 0;
+    struct Restore { bool v; std::string sm, om; bool ex; ~Restore() { FLAGS_enable_raw_output = v; FLAGS_smoothing_method = sm; FLAGS_optimization_method = om; FLAGS_enable_exact_position = ex; } } restore{keep_raw, keep_sm, keep_om, keep_ex};
     grid_map::GridMap gm(*m);
     State st(start[0], start[1], start[2], start[3]), en(goal[0], goal[1], goal[2]);
     PathOptimizer opt(st, en, gm);

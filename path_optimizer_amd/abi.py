@@ -25,7 +25,7 @@ class PoParams(C.Structure):
         ("t2_w_dev", C.c_double), ("t2_w_curv", C.c_double), ("t2_w_curv_rate", C.c_double),
         ("cart_w_curv", C.c_double), ("cart_w_curv_rate", C.c_double), ("cart_w_dev", C.c_double),
         ("mu", C.c_double), ("max_curvature_rate", C.c_double), ("search_lateral_range", C.c_double),
-        ("search_long_spacing", C.c_double), ("search_lat_spacing", C.c_double), ("enable_dynamic_segmentation", C.c_int), ("enable_raw_output", C.c_int), ("output_spacing", C.c_double), ("smoothing_method", C.c_int), ("optimization_method", C.c_int),
+        ("search_long_spacing", C.c_double), ("search_lat_spacing", C.c_double), ("enable_dynamic_segmentation", C.c_int), ("enable_raw_output", C.c_int), ("output_spacing", C.c_double), ("smoothing_method", C.c_int), ("optimization_method", C.c_int), ("enable_exact_position", C.c_int), ("reserved1", C.c_int),
     ]
 
 

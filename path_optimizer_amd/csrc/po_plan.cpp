@@ -106,7 +106,7 @@ int po_segment_init_batch_device(po_handle h, const po_spline_in *spline, const 
     PO_TRY(dev_spline(h, spline, &D));
     if (spline->B == 0) return PO_OK;
     HIP_TRY(hipSetDevice(po_internal_device(h)));
-    HIP_TRY(po_launch_segment_init(&D, start, start_stride, goal, goal_stride, /*FLAGS_enable_exact_position*/ 0, init, ok, po_internal_stream(h)));
+    HIP_TRY(po_launch_segment_init(&D, start, start_stride, goal, goal_stride, po_internal_params(h)->enable_exact_position, init, ok, po_internal_stream(h)));
     return PO_OK;
 }
 

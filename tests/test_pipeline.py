@@ -93,6 +93,26 @@ def test_oracle_densifying_output_branch(oracle, scenes):
             assert bool(rok) == bool(ook) and rpath.shape == opath.shape and (len(rpath) == 0 or np.abs(rpath - opath).max() < 1e-9)
 
 
+@pytest.mark.skipif(not HAVE_REF, reason="/root/reference not present")
+def test_oracle_exact_position_flag_vs_reference(oracle, scenes):
+    from oracle import ref_py
+
+    sc, _ = scenes
+    mp = oracle.make_map(*sc["map"])
+    p = oracle.default_params()
+    p.enable_exact_position = 1
+    gl = sc["goal"][0].copy(); gl[0], gl[1] = sc["way_x"][0][15] + 0.37, sc["way_y"][0][15] - 0.21  # a goal off the path: the 0.1 m search matters
+    rok, rpath = ref_py.path_optimizer_solve(mp, p, sc["way_x"][0], sc["way_y"][0], sc["start"][0], gl)
+    ook, opath, _ = oracle.path_optimizer_solve(p, mp, sc["way_x"][0], sc["way_y"][0], sc["start"][0], gl)
+    assert rok and ook and rpath.shape == opath.shape and np.abs(rpath - opath).max() < 1e-9
+    n, bx, by, bs = oracle.bspline(sc["way_x"][0], sc["way_y"][0])
+    differs = 0
+    for i in range(8, 20):  # the flag really changes the goal trim (0.1 m instead of 0.5 m search steps)
+        g2 = [sc["way_x"][0][i] + 0.37, sc["way_y"][0][i] - 0.21]
+        differs += oracle.segment_init(bs, bx, by, bs[-1], sc["start"][0][:3], g2, 1)[3] != oracle.segment_init(bs, bx, by, bs[-1], sc["start"][0][:3], g2, 0)[3]
+    assert differs >= 3
+
+
 def test_bspline_restatement_properties(oracle):
     """tinyspline is absent (parity unpinned): the restated clamped B-spline at least has the defining properties — end-point
     interpolation, affine invariance, partition of unity (a constant control polygon gives that constant), convex-hull containment."""
