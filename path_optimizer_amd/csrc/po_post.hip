@@ -717,12 +717,14 @@ __global__ void plan_gate_kernel(PlanGate g) {
             for (int i = 0; i < 3; ++i) g.start3[3 * b + i] = g.start[4 * b + i];
             break;
         case 1:  // after TENSION2: few points / bSpline -> 1, QP not solved -> 2; length = result_s.back() + 3 (TensionSmoother::smooth)
+            if (!st && (g.cnt2[b] == -2 || g.cnt[b] == -2)) st = 9;  // intermediate capacity (max_length too small)
             if (!st && (g.cnt2[b] < 3 || g.cnt[b] < 3)) st = 1;
             if (!st && g.info[b].status != PO_STATUS_SOLVED) st = 2;
             g.length[b] = st ? 0.0 : g.s[(size_t)b * g.stride + g.cnt[b] - 1] + 3;
             if (st) g.cnt[b] = 0;
             break;
         case 2:  // after the search: false -> 3, fewer than 4 layers ("Ref is short") -> 4
+            if (!st && g.cnt[b] == -2) st = 9;  // layer capacity
             if (!st && g.cnt[b] < 0) st = 3;
             if (!st && g.cnt[b] < 4) st = 4;
             if (st) g.cnt[b] = 0;

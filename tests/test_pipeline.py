@@ -356,3 +356,33 @@ def test_device_pipeline_other_flag_values(oracle, scenes, smoother, form):
             agree += 1
             assert np.abs(states[b, :n[b]] - opath).max() < 1e-6
     assert agree >= 7
+
+
+@pytest.mark.gpu
+def test_device_pipeline_capacity_and_argument_errors(engine, scenes):
+    from path_optimizer_amd import binding
+    from path_optimizer_amd.abi import PO_ERR_INVALID, PoPlanIn, PoPlanOut
+    import ctypes as C
+
+    sc, g = scenes
+    # N too small for the re-sampled reference: flagged per instance (stage 9), never truncated silently
+    states, n, ok, stage, info = engine.plan_batch(sc["way_x"], sc["way_y"], sc["start"], sc["goal"], N=128)
+    assert (stage == 9).all() and not ok.any() and not n.any() and not states.any()
+    # an understated max_length: the intermediate buffers are too small -> stage 9 as well
+    states, n, ok, stage, info = engine.plan_batch(sc["way_x"], sc["way_y"], sc["start"], sc["goal"], N=512, max_length=20.0)
+    assert (stage == 9).all() and not ok.any()
+    # a generous one changes nothing
+    s2, n2, ok2, st2, _ = engine.plan_batch(sc["way_x"], sc["way_y"], sc["start"], sc["goal"], N=512, max_length=150.0)
+    assert ok2.all() and np.array_equal(n2, g["n"])
+    for b in range(int(g["B"])):
+        assert np.abs(s2[b, :n2[b]] - g[f"path_{b}"]).max() < 1e-6
+    # API misuse -> error codes
+    L = binding.lib()
+    pi = PoPlanIn(4, 3, None, None, None, None, None, 0.0, 512)  # fewer than 4 waypoints per row
+    po = PoPlanOut(None, None, None, None, None)
+    assert L.po_plan_batch(engine._h, C.byref(pi), C.byref(po)) == PO_ERR_INVALID
+    nomap = binding.Engine(0)
+    with pytest.raises(binding.PoError):
+        nomap.plan_batch(sc["way_x"], sc["way_y"], sc["start"], sc["goal"], N=512)  # po_set_map first
+    e0 = engine.plan_batch(sc["way_x"][:0], sc["way_y"][:0], sc["start"][:0], sc["goal"][:0], N=512)
+    assert e0[0].shape[0] == 0
