@@ -608,6 +608,9 @@ int po_smooth_batch_device(po_handle h, const po_smooth_in *in, const po_smooth_
     if (int rc = h->smooth_buf.ensure(sizeof(double) * D.scratch_stride * (size_t)in->B)) return rc;
     D.scratch = static_cast<double *>(h->smooth_buf.p);
     D.map = h->map;
+    D.perm_bits = 0;
+    if (!std::getenv("PO_IDENTITY_ORDER") && in->B > 8)
+        while ((1 << D.perm_bits) < in->B) ++D.perm_bits;
     const bool dbg = std::getenv("PO_SMOOTH_DEBUG") != nullptr;  // dev tool: per-phase cycle totals of instance 0..B-1 printed to stderr
     if (dbg) {
         if (int rc = h->dbg_buf.ensure(sizeof(long long) * 8 * (size_t)in->B)) return rc;

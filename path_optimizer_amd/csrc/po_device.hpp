@@ -254,6 +254,19 @@ __device__ __forceinline__ bool last_of_group(int i, int N, int keep) {
     return (i == N - 2) || (keep == 4 ? (((i + 1) & 3) == 0) : ((i + 1) % keep == 0));
 }
 
+// Bit-mixing bijection of a workgroup index onto [0, B): workgroup i runs on XCD i mod 8 (a static partition of every launch), so kernels
+// whose work per instance varies take instance perm_index(blockIdx.x, ...) instead of blockIdx.x.  bits = ceil(log2 B), 0 = identity.
+__device__ __forceinline__ int perm_index(unsigned i, int bits, int B) {
+    if (bits <= 0) return (int)i;
+    const unsigned mask = (1u << bits) - 1u, h = bits > 1 ? (unsigned)bits >> 1 : 1u;
+    do {
+        i ^= i >> h; i = (i * 0x9E3779B1u) & mask;
+        i ^= i >> h; i = (i * 0x85EBCA6Bu) & mask;
+        i ^= i >> h;
+    } while (i >= (unsigned)B);
+    return (int)i;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -313,7 +313,7 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
     using T = ST<KIND>;
     constexpr int W = T::W, LS = Prob<KIND>::LS, KA = T::KA, WP = T::WP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int b = perm_index(blockIdx.x, a.perm_bits, a.B), lane = threadIdx.x;  // iteration counts vary 10x between instances (post QP)
     const int P = a.n_points ? a.n_points[b] : a.P;
     const size_t o = (size_t)b * a.P;
     po_info info{};

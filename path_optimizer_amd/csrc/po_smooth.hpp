@@ -20,6 +20,7 @@ struct DevSmooth {
     double *scratch;        // [B][scratch_stride]: scaled P band, D, E
     size_t scratch_stride;  // doubles
     DevMap map;             // TENSION only
+    int perm_bits;          // block -> instance mixing (po_device.hpp perm_index), 0 = blockIdx order
     long long *dbg_cycles;  // optional [B][8] per-phase shader-clock totals (dev tool: PO_SMOOTH_DEBUG=1), or nullptr
 };
 }  // namespace po
