@@ -14,7 +14,8 @@
 //   * per iteration: rhs (lanes over variables), forward/backward substitution (one lane, register sliding window, factor column
 //     read as 16-byte pairs), relaxation + projection + dual update in the one-number-per-row form v = z + y/rho (lanes over rows);
 //   * termination / infeasibility certificates / adaptive rho exactly as OSQP (unscaled residuals every `check_every` iterations).
-// The scaled P band, D and E (needed only at checks and refactorisations) stay in an HBM scratch block per QP.
+// The scaled P band, D and E (needed only at checks and refactorisations), the linear term q (touched by one fixed lane per entry) and
+// the per-check dy scratch stay in an HBM block per QP: LDS decides how many QPs a CU holds, and the kernel is latency-bound.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -54,7 +55,7 @@ template <int KIND> struct Lds {
     static constexpr int LS = col_stride<T::W>();
     static __host__ __device__ size_t bytes(int P) {
         const size_t n = (size_t)T::n(P), m = (size_t)T::m(P), np = n + col_pad<T::W>();
-        size_t d = np * LS + (size_t)T::KA * m + 2 * n + np + 4 * m;  // Lb, Av, x, q, wk, v, l, u, tm
+        size_t d = np * LS + (size_t)T::KA * m + n + np + 3 * m;  // Lb, Av, x, wk, v, l, u  (q and the dy / scaling scratch tm live in the HBM block)
         size_t b = d * 8 + ((size_t)T::KA * m + (size_t)kKT * n) * 2 + n * 4 + m + 8;
         return (b + 15) & ~(size_t)15;
     }
@@ -73,7 +74,7 @@ template <int KIND> struct Prob {  // views into LDS + scratch for one QP
     uint16_t *Ac, *Tl;
     int *Tc;
     uint8_t *cls;
-    double *Pb, *Dv, *Ev;  // HBM scratch: Pb[d*n + j] = P[j][j+d] (scaled), D[n], E[m]
+    double *Pb, *Dv, *Ev;  // HBM scratch: Pb[d*n + j] = P[j][j+d] (scaled), D[n], E[m], then q[n] and tm[m]
     __device__ __forceinline__ void setA(int r, int s, int col, double val) { Av[s * m + r] = val; Ac[s * m + r] = (uint16_t)col; }
     __device__ __forceinline__ void setRow(int r, double lo, double hi) { l[r] = lo; u[r] = hi; }
     __device__ __forceinline__ void setP(int j, int d, double val) { Lb[j * LS + d] = val; }  // P band parked in the factor storage during setup
@@ -334,12 +335,10 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
         pb.Lb = dp; dp += (size_t)np * LS;
         pb.Av = dp; dp += KA * m;
         pb.x = dp; dp += n;
-        pb.q = dp; dp += n;
         pb.wk = dp; dp += np;
         pb.v = dp; dp += m;
         pb.l = dp; dp += m;
         pb.u = dp; dp += m;
-        pb.tm = dp; dp += m;
         uint16_t *hp = reinterpret_cast<uint16_t *>(dp);
         pb.Ac = hp; hp += KA * m;
         pb.Tl = hp; hp += kKT * n;
@@ -347,6 +346,7 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
         pb.cls = reinterpret_cast<uint8_t *>(pb.Tc + n);
         double *sc = a.scratch + (size_t)b * a.scratch_stride;
         pb.Pb = sc; pb.Dv = sc + (size_t)(WP + 1) * T::n(a.P); pb.Ev = pb.Dv + T::n(a.P);
+        pb.q = pb.Ev + T::m(a.P); pb.tm = pb.q + T::n(a.P);  // q[j] is only ever touched by lane j % 64; tm crosses lanes behind __syncthreads
     }
     for (int i = lane; i < np * LS; i += 64) pb.Lb[i] = 0;
     for (int i = lane; i < np; i += 64) pb.wk[i] = 0;
@@ -721,9 +721,9 @@ extern "C" size_t po_smooth_lds_bytes(int kind, int P) {
 }
 extern "C" size_t po_smooth_scratch_doubles(int kind, int P) {
     switch (kind) {
-        case PO_SMOOTH_TENSION2: return (size_t)(4 + 2) * po::ST<PO_SMOOTH_TENSION2>::n(P) + po::ST<PO_SMOOTH_TENSION2>::m(P);
-        case PO_SMOOTH_TENSION: return (size_t)(9 + 2) * po::ST<PO_SMOOTH_TENSION>::n(P) + po::ST<PO_SMOOTH_TENSION>::m(P);
-        case PO_SMOOTH_POST: return (size_t)(0 + 2) * po::ST<PO_SMOOTH_POST>::n(P) + po::ST<PO_SMOOTH_POST>::m(P);
+        case PO_SMOOTH_TENSION2: return (size_t)(4 + 3) * po::ST<PO_SMOOTH_TENSION2>::n(P) + 2 * po::ST<PO_SMOOTH_TENSION2>::m(P);
+        case PO_SMOOTH_TENSION: return (size_t)(9 + 3) * po::ST<PO_SMOOTH_TENSION>::n(P) + 2 * po::ST<PO_SMOOTH_TENSION>::m(P);
+        case PO_SMOOTH_POST: return (size_t)(0 + 3) * po::ST<PO_SMOOTH_POST>::n(P) + 2 * po::ST<PO_SMOOTH_POST>::m(P);
     }
     return 0;
 }
