@@ -1174,7 +1174,7 @@ done:
 /* (the pattern repeats along the path and the data-dependent entries never attain a column's    */
 /* inf-norm), so the same iteration is run once on a one-stage template with the path's nominal */
 /* arc-length step.  The device engine implements exactly this; mode scaling<0.   */
-/* variable classes: 0 e_y, 1 e_phi, 2 c (k or delta), 3 s1, 4 s2, 5 u, 6 su, 7 dead            */
+/* variable classes: 0 e_y, 1 e_phi, 2 c (k or delta), 3 s1, 4 s2, 5 u, 6 su (K: end delta), 7 dead */
 /* ------------------------------------------------------------------------------------------ */
 #define PO_NVC 8
 #define PO_NRC 24
@@ -1234,10 +1234,14 @@ static void class_model_build(class_model_t *M, int form, const po_params *p, in
         M->a[r][3] = 1; ++r;  /* S box          */
         ROW2(d1); ROW2(d3); ROW2(d4);
         ROW2S(d2, -1); ROW2S(d2, 1);
-        M->a[r][1] = 1; M->a[r][2] = ds / p->wheel_base; M->tgt[r] = 1; ++r;  /* e_phi equation, template k = 0 */
+        M->a[r][1] = 1; M->a[r][2] = ds / p->wheel_base; M->a[r][6] = ds / p->wheel_base; M->tgt[r] = 1; ++r;  /* e_phi equation, template k = 0 */
         M->a[r][0] = 1; M->a[r][1] = ds; M->tgt[r] = 0; ++r;                   /* e_y equation */
-        const double Pm[PO_NVC] = {p->k_w_dev, 0, p->k_w_curv + 2 * p->k_w_curv_rate, p->w_slack, 0, 0, 0, 0};
-        const double cn[PO_NVC] = {N, N, N - 1, N, 0, 0, 0, 0};
+        /* The first and the last steering variable carry w_c + w_cr on the diagonal of R (solver_k_as_input.cpp:62-76), the others
+         * w_c + 2 w_cr: OSQP's Ruiz passes give those two columns - and their box rows - their own factors.  Class 6 / row 11. */
+        M->a[r][6] = 1; ++r;  /* box row of an end steering variable */
+        const int nend = N - 1 < 2 ? N - 1 : 2;
+        const double Pm[PO_NVC] = {p->k_w_dev, 0, p->k_w_curv + 2 * p->k_w_curv_rate, p->w_slack, 0, 0, p->k_w_curv + p->k_w_curv_rate, 0};
+        const double cn[PO_NVC] = {N, N, N - 1 - nend, N, 0, 0, nend, 0};
         memcpy(M->Pmax, Pm, sizeof(Pm)); memcpy(M->cnt, cn, sizeof(cn));
     }
 #undef ROW2
@@ -1322,10 +1326,11 @@ int po_oracle_class_scaling(int form, const po_params *p, int N, int keep, doubl
     } else {
         for (int i = 0; i < N; ++i) {
             D[2 * i] = Dv[1]; D[2 * i + 1] = Dv[0]; D[3 * N - 1 + i] = Dv[3];
-            if (i < N - 1) D[2 * N + i] = Dv[2];
+            const int kend = (i == 0 || i == N - 2);
+            if (i < N - 1) D[2 * N + i] = kend ? Dv[6] : Dv[2];
             E[2 * i] = Er[9]; E[2 * i + 1] = Er[10];
             E[2 * N + 2 * i] = Er[0]; E[2 * N + 2 * i + 1] = Er[1];
-            if (i < N - 1) E[4 * N + i] = Er[2];
+            if (i < N - 1) E[4 * N + i] = kend ? Er[11] : Er[2];
             E[5 * N - 1 + i] = Er[3];
             E[6 * N - 1 + 3 * i] = Er[4]; E[6 * N - 1 + 3 * i + 1] = Er[5]; E[6 * N - 1 + 3 * i + 2] = Er[6];
             E[9 * N - 1 + i] = Er[7]; E[10 * N - 1 + i] = Er[8];

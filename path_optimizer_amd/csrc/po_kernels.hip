@@ -88,7 +88,7 @@ __device__ __forceinline__ void inv3_sym(const double g[6], double gi[6]) {
 }
 
 
-struct Resid { double rp, rd, nAx, nz, nPx, nAty, rps, rds, nAxs, nzs, nPxs, nAtys; };
+struct Resid { double rp, rd, nAx, nz, nPx, nAty, rps, rds, nAxs, nzs, nPxs, nAtys, obj; };  // obj = 0.5 x'Px (q = 0)
 
 // diagnostic assembly kernel: l,u in reference row order + data-dependent A entries per transition
 template <int F> __global__ __launch_bounds__(64) void assemble_kernel(DevBatch in, DevParams P, double *l, double *u, double *dyn) {

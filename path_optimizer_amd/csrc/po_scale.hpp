@@ -12,10 +12,15 @@
 
 namespace po {
 
-constexpr int kNVC = 8;    // variable classes: 0 e_y, 1 e_phi, 2 c, 3 s1, 4 s2, 5 u, 6 su, 7 dead
+constexpr int kNVC = 8;    // variable classes: 0 e_y, 1 e_phi, 2 c, 3 s1, 4 s2, 5 u, 6 su (K: first / last steering variable), 7 dead
 constexpr int kNRC = 24;   // row classes, order: [local | dyn | ctl | end]
 constexpr int kScStride = 64;
 constexpr int kScW = 0, kScE = 24, kScSig = 48, kScCD = 56, kScC = 63;
+// K only: the first and the last steering variable carry w_c + w_cr on the diagonal of R instead of w_c + 2 w_cr
+// (solver_k_as_input.cpp:62-76), so OSQP's Ruiz passes give them — and their box rows — their own factors.  They are variable
+// class 6 and row class kKEndRow; a second copy of the stage-local W / E entries with the box row replaced sits kScAlt
+// entries further on, and the kernel points the row functors of the stages 0 and N-2 at it (Fast::Wloc(j) / Eloc(j)).
+constexpr int kKEndRow = 11, kKEndVar = 6, kScAlt = 12;
 constexpr double kMinScaling = 1e-4, kMaxScaling = 1e4;
 
 struct ClassModel {
@@ -67,9 +72,16 @@ template <int F> __device__ void class_scaling(const DevParams &P, int N, int ke
     }
     if constexpr (T::NCTL > 0) { PatCtlFn cf{&M, T::NLOC + T::NDYN}; ctl_rows<F>(0.0, cf); }
     if constexpr (T::NEND > 0) { PatFn ef{&M, T::NLOC + T::NDYN + T::NCTL}; end_rows<F>(s, P, ef); }
+    if constexpr (F == F_K) {
+        static_assert(T::NLOC + T::NDYN == kKEndRow && kScAlt + T::NLOC <= 24, "K end classes");
+        M.a[kKEndRow][kKEndVar] = M.a[2][2];                   // box row of an end steering variable
+        M.a[T::NLOC + 0][kKEndVar] = M.a[T::NLOC + 0][2];      // its entry in the e_phi equation
+        M.nr = kKEndRow + 1;
+    }
     for (int v = 0; v < kNVC; ++v) { M.Pmax[v] = 0; M.cnt[v] = 0; }
     M.Pmax[0] = P.w_dev; M.Pmax[2] = (F == F_K) ? P.w_c + 2 * P.w_cr : P.w_c; M.Pmax[3] = P.w_s1;
-    M.cnt[0] = N; M.cnt[1] = N; M.cnt[2] = (F == F_K) ? N - 1 : N; M.cnt[3] = N;
+    M.cnt[0] = N; M.cnt[1] = N; M.cnt[2] = N; M.cnt[3] = N;
+    if constexpr (F == F_K) { M.Pmax[kKEndVar] = P.w_c + P.w_cr; M.cnt[kKEndVar] = N - 1 < 2 ? N - 1 : 2; M.cnt[2] = N - 1 - M.cnt[kKEndVar]; }
     if constexpr (F == F_KP) { M.Pmax[5] = P.w_u; M.cnt[5] = C; M.Pmax[7] = P.w_s1; M.cnt[7] = N; }
     if constexpr (F == F_KPC) { M.Pmax[4] = P.w_s2; M.cnt[4] = N; M.Pmax[5] = P.w_u; M.cnt[5] = C; M.Pmax[6] = P.w_su; M.cnt[6] = C; M.cnt[7] = N - C; }
     double Dv[kNVC], Er[kNRC], c = 1.0, ntot = 0;
@@ -104,6 +116,9 @@ template <int F> __device__ void class_scaling(const DevParams &P, int N, int ke
     for (int i = 0; i < kScStride; ++i) out[i] = 0;
     for (int r = 0; r < kNRC; ++r) { out[kScW + r] = Er[r] * Er[r] / c; out[kScE + r] = Er[r]; }
     for (int v = 0; v < 7; ++v) { out[kScSig + v] = P.sigma / (c * Dv[v] * Dv[v]); out[kScCD + v] = c * Dv[v]; }
+    if constexpr (F == F_K) {
+        for (int r = 0; r < T::NLOC; ++r) { out[kScW + kScAlt + r] = out[kScW + (r == 2 ? kKEndRow : r)]; out[kScE + kScAlt + r] = out[kScE + (r == 2 ? kKEndRow : r)]; }
+    }
     out[kScC] = c;
 }
 

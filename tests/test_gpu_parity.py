@@ -86,6 +86,15 @@ def test_device_scaling_block_matches_oracle(binding, oracle, form, name):
             np.testing.assert_allclose(blk[i, 0:len(er)], er ** 2 / c, rtol=1e-13)
             np.testing.assert_allclose(blk[i, 48:52], po.sigma / (c * np.array(dv) ** 2), rtol=1e-13)
             np.testing.assert_allclose(blk[i, 56:60], c * np.array(dv), rtol=1e-13)
+            if form == T.PO_K:  # first / last steering variable and their box rows: own Ruiz factors (variable class 6, row class 11, alternate block)
+                for dend, eend in ((D[2 * N], E[4 * N]), (D[3 * N - 2], E[5 * N - 2])):
+                    np.testing.assert_allclose(blk[i, 48 + 6], po.sigma / (c * dend ** 2), rtol=1e-13)
+                    np.testing.assert_allclose(blk[i, 56 + 6], c * dend, rtol=1e-13)
+                    np.testing.assert_allclose(blk[i, 24 + 11], eend, rtol=1e-13)
+                alt = np.array(er_loc); alt[2] = E[4 * N]
+                np.testing.assert_allclose(blk[i, 24 + 12:24 + 21], alt, rtol=1e-13)
+                np.testing.assert_allclose(blk[i, 12:21], alt ** 2 / c, rtol=1e-13)
+                assert D[2 * N] != D[2 * N + 1] and E[4 * N] != E[4 * N + 1]
 
 
 @pytest.mark.parametrize("form,name", FORMS)
@@ -107,6 +116,7 @@ def test_fixed_iteration_iterates_match_oracle(binding, oracle, form, name, scal
         assert np.abs(xs - oxs).max() < 1e-8, (name, iters, np.abs(xs - oxs).max())
         np.testing.assert_allclose(info["r_prim"], oinfo["r_prim"], rtol=1e-5, atol=1e-10)
         np.testing.assert_allclose(info["r_dual"], oinfo["r_dual"], rtol=1e-5, atol=1e-10)
+        np.testing.assert_allclose(info["obj"], oinfo["obj"], rtol=1e-6, atol=1e-12)  # 0.5 x'Px at exit (OSQP's info.obj_val)
 
 
 @pytest.mark.parametrize("cfg,B", [(1, 1), (2, 24), (3, 24), (5, 6)])
@@ -123,6 +133,28 @@ def test_baseline_configs_match_oracle(binding, oracle, cfg, B):
     rms = np.sqrt((ey ** 2).mean(axis=1))
     assert rms[same].max() < 1e-6, rms  # bar: <= 1e-4 m lateral-offset RMS; measured ~1e-9
     assert np.abs(st - ost)[same].max() < 1e-6
+    np.testing.assert_allclose(info["obj"][same], oinfo["obj"][same], rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("form,name", FORMS)
+def test_device_matches_literal_ruiz(binding, oracle, form, name):
+    """The device's class-level equilibration against the oracle running OSQP's Ruiz passes LITERALLY on the assembled P and A
+    (scaling = +10, the reference's setting): same iteration counts and the same solution for every formulation — including K, whose
+    first and last steering variable get their own factors."""
+    import copy
+
+    b = copy.copy(synth.make_batch(3, B=12)); b.formulation = form
+    if form == T.PO_K:
+        b.keep = 1
+    if form == T.PO_KPC:
+        b.max_k = np.full((b.B, b.N), 0.2); b.max_kp = np.full((b.B, b.N), 0.05)
+    st, info, xs = binding.Engine(0).solve_batch(b, want_x=True)
+    po = oracle.default_params(); assert po.scaling == 10
+    ost, oinfo, oxs = oracle.solve_batch(b, po)
+    assert (info["status"] == 1).all() and np.array_equal(info["status"], oinfo["status"])
+    same = info["iters"] == oinfo["iters"]
+    assert same.mean() >= 0.9, (info["iters"], oinfo["iters"])
+    assert np.abs(xs - oxs)[same].max() < 1e-6 and np.abs(st - ost)[same].max() < 1e-6
 
 
 def test_keep_quirk_and_ragged_sizes(binding, oracle):
