@@ -261,9 +261,11 @@ def main():
         t1 = time.perf_counter()
         return t1 - t0, float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
-    for k in range(max(args.warmup, 0)):
-        engs[k % S].solve_batch_device(dbs[k % S])
+    # warm-up: issued exactly like the timed steps (round-robin over the handles) and timed per launch as well, so that the mean over
+    # ALL launches of the process is available for comparison with rocprofv3's per-kernel average (which cannot tell warm-up from timed)
+    _, warm_kernel_ms = run(args.warmup, S) if args.warmup > 0 else (0.0, None)
     elapsed, kernel_ms = run(args.steps, S)
+    kernel_ms_all = kernel_ms if warm_kernel_ms is None else (warm_kernel_ms * args.warmup + kernel_ms * args.steps) / (args.warmup + args.steps)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -329,6 +331,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "frac_of_measured_copy_ceiling": achieved / 6290.0,  # MI355X_MICROARCH.md: 6.29 TB/s measured copy
                          "traffic": traffic, "kernel": "po::solve_kernel_fast<KP,SPL=4,NT=64,two-level>", "kernel_ms": kernel_ms,
+                         "kernel_ms_all_launches": kernel_ms_all,  # warm-up launches included: the figure rocprofv3's per-kernel average corresponds to
                          "algorithmic_bytes_per_path_iter": b_iter,
                          "note": "algorithmic bytes of one launch / that launch's duration (hipEvents on its stream); launches of the "
                                  f"{S} streams overlap, so one launch's duration is longer than ms_per_step; the state is LDS-resident, so this is not HBM traffic",

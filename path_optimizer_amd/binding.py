@@ -14,7 +14,7 @@ import numpy as np
 from .abi import (INFO_DTYPE, PO_ERR_HIP, PO_OK, PoBatchIn, PoBatchOut, PoParams)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpo_hip.so")
+LIB_PATH = os.environ.get("PO_LIB") or os.path.join(_HERE, "libpo_hip.so")  # PO_LIB: dev builds (make dev), A/B experiments
 _LIB = None
 
 EXPORTS = ["po_default_params", "po_problem_dims", "po_keep_control_steps", "po_create", "po_destroy", "po_set_stream",
