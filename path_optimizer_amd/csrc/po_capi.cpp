@@ -227,6 +227,7 @@ static void fill_dev_batch(po::DevBatch *D, const po_batch_in *in, const po_batc
     D->out_info = out ? out->info : nullptr;
     D->out_x = out ? out->x : nullptr;
     D->dbg_cycles = nullptr;
+    D->only_deferred = 0;
     D->perm_bits = 0;  // block -> path permutation (PO_IDENTITY_ORDER=1: blockIdx order, dev tool)
     if (!std::getenv("PO_IDENTITY_ORDER") && in->B > 8)
         while ((1 << D->perm_bits) < in->B) ++D->perm_bits;

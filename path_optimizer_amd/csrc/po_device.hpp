@@ -45,6 +45,7 @@ struct DevBatch {
     const double *scale;    // [B][64] per-path equilibration block (po_scale.hpp)
     long long *dbg_cycles;  // optional [B][4] per-phase shader-clock totals (dev tool), or nullptr
     int perm_bits;          // block -> path permutation: ceil(log2 B) bits of mixing (0 = blockIdx order), see solve_kernel_fast
+    int only_deferred;      // set by the launcher for the second (general) launch of the two-level mapping: solve only the paths the first one deferred
     int n, m;
 };
 

@@ -51,15 +51,20 @@ template <int F> __global__ __launch_bounds__(64) void assemble_kernel(DevBatch 
 
 }  // namespace po
 
-// the solve kernels of one formulation live in their own object (po_solve_form.hip)
-extern "C" hipError_t po_launch_solve_kp(const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out);
-extern "C" hipError_t po_launch_solve_kpc(const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out);
-extern "C" hipError_t po_launch_solve_k(const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out);
+// the solve kernels of one formulation and one loop variant live in their own object (po_solve_form.hip)
+#define PO_DECL(name) extern "C" hipError_t name(const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out)
+PO_DECL(po_launch_solve_kp); PO_DECL(po_launch_solve_kp_uni);
+PO_DECL(po_launch_solve_kpc); PO_DECL(po_launch_solve_kpc_uni);
+PO_DECL(po_launch_solve_k);
+#undef PO_DECL
 
+// Two launches on the same stream for the two-level mapping: the uniform-row-class variant first (solves what it can, defers the rest),
+// then the general variant (po_fast.inc, solve_kernel_fast).
 extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out) {
     using namespace po;
-    if (form == F_KP) return po_launch_solve_kp(in, P, st, lds_out);
-    if (form == F_KPC) return po_launch_solve_kpc(in, P, st, lds_out);
+    hipError_t e;
+    if (form == F_KP) { e = po_launch_solve_kp_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kp(in, P, st, lds_out); }
+    if (form == F_KPC) { e = po_launch_solve_kpc_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kpc(in, P, st, lds_out); }
     return po_launch_solve_k(in, P, st, lds_out);
 }
 

@@ -129,13 +129,22 @@ inline bool resolve_shape(int form, int N, int C, int keep, Shape *s) {
     if (s->two && lds_of(form, N, C, *s) > 160 * 1024) return pick_shape(form, N, C, /*keep (forces the single-level candidates)*/ 0, s);
     return true;
 }
-template <int F> hipError_t launch_form(const DevBatch *in, const DevParams *P, hipStream_t st, size_t *lds_out) {
+// UNI = true: the uniform-row-class variant of the two-level kernels (no-op for shapes that use the single-level mapping, and for K, whose
+// end stages never share the pattern); UNI = false: the general variant.  po_launch_solve issues them in this order on one stream.
+template <int F> inline bool has_uni_variant(const Shape &s) { return s.two && F != F_K; }
+template <int F, bool UNI> hipError_t launch_form(const DevBatch *in_, const DevParams *P, hipStream_t st, size_t *lds_out) {
     Shape s;
-    if (!resolve_shape(F, in->N, in->C, in->keep, &s)) return hipErrorInvalidValue;
-    const size_t lds = lds_bytes_fast<F>(in->N, in->C, s.spl, s.two, s.nt);
+    if (!resolve_shape(F, in_->N, in_->C, in_->keep, &s)) return hipErrorInvalidValue;
+    const size_t lds = lds_bytes_fast<F>(in_->N, in_->C, s.spl, s.two, s.nt);
     if (lds_out) *lds_out = lds;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-#define PO_L(SPL_, NT_, TWO_) return launch1(&solve_kernel_fast<F, SPL_, NT_, TWO_>, in, P, NT_, lds, st)
+    DevBatch copy = *in_;
+    copy.only_deferred = (!UNI && has_uni_variant<F>(s)) ? 1 : 0;
+    const DevBatch *in = &copy;
+#define PO_L(SPL_, NT_, TWO_) return launch1(&solve_kernel_fast<F, SPL_, NT_, TWO_, UNI && TWO_>, in, P, NT_, lds, st)
+    if constexpr (UNI) {
+        if (!has_uni_variant<F>(s)) return hipSuccess;
+    }
 #ifdef PO_DEV_HEADLINE  // dev builds: only the BASELINE config-3 variant (seconds to compile)
     if (s.two && s.spl == 4 && s.nt == 64) PO_L(4, 64, true);
     return hipErrorInvalidValue;
@@ -157,11 +166,14 @@ template <int F> hipError_t launch_form(const DevBatch *in, const DevParams *P, 
         if (s.nt == 64) PO_L(4, 64, true);
         PO_L(4, 128, true);
     }
-    if (s.nt == 64 && s.spl == 2) PO_L(2, 64, false);
-    if (s.nt == 64) PO_L(4, 64, false);
-    if (s.nt == 128) PO_L(4, 128, false);
-    if (s.spl == 2) PO_L(2, 256, false);
-    PO_L(4, 256, false);
+    if constexpr (!UNI) {
+        if (s.nt == 64 && s.spl == 2) PO_L(2, 64, false);
+        if (s.nt == 64) PO_L(4, 64, false);
+        if (s.nt == 128) PO_L(4, 128, false);
+        if (s.spl == 2) PO_L(2, 256, false);
+        PO_L(4, 256, false);
+    }
+    return hipErrorInvalidValue;
 #endif
 #undef PO_L
 }

