@@ -330,7 +330,7 @@ def main():
                      "schedule": "termination check every 25 it, adaptive rho every 100 it (by iteration count), max_iter 4000"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "frac_of_measured_copy_ceiling": achieved / 6290.0,  # MI355X_MICROARCH.md: 6.29 TB/s measured copy
-                         "traffic": traffic, "kernel": "po::solve_kernel_fast<KP,SPL=4,NT=64,two-level>", "kernel_ms": kernel_ms,
+                         "traffic": traffic, "kernel": "po::solve_kernel_fast<KP,SPL=4,NT=64,two-level,uniform-row-classes> (the general-variant launch that follows it only picks up deferred paths: none on this workload)", "kernel_ms": kernel_ms,
                          "kernel_ms_all_launches": kernel_ms_all,  # warm-up launches included: the figure rocprofv3's per-kernel average corresponds to
                          "algorithmic_bytes_per_path_iter": b_iter,
                          "note": "algorithmic bytes of one launch / that launch's duration (hipEvents on its stream); launches of the "

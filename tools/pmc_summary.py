@@ -13,12 +13,13 @@ agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, set(
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
     for f in glob.glob(os.path.join(src, sub, "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0][:60]
+            k = r["Kernel_Name"].split("(")[0][:70]
             a = agg[k][r["Counter_Name"]]
             a[0] += float(r["Counter_Value"]); a[1].add(r["Dispatch_Id"])
 out = {k: {c: {"sum": v[0], "dispatches": len(v[1]), "per_dispatch": v[0] / max(len(v[1]), 1)} for c, v in d.items()} for k, d in agg.items()}
 json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
-solve = next((v for k, v in out.items() if "solve_kernel_fast<0, 4, 64" in k), None) or next((v for k, v in out.items() if "solve_kernel" in k), None)  # the headline kernel (KP, SPL 4, one wave), not the pipeline legs' <0, 3, 128>
+solve = (next((v for k, v in out.items() if "solve_kernel_fast<0, 4, 64, true, true" in k), None)  # uniform-row-class launch: the one that does the work
+         or next((v for k, v in out.items() if "solve_kernel_fast<0, 4, 64" in k), None) or next((v for k, v in out.items() if "solve_kernel" in k), None))  # the headline kernel (KP, SPL 4, one wave), not the pipeline legs' <0, 3, 128>
 if solve and "FETCH_SIZE" in solve and "WRITE_SIZE" in solve:
     fetch = solve["FETCH_SIZE"]["per_dispatch"] * 1024.0
     write = solve["WRITE_SIZE"]["per_dispatch"] * 1024.0
