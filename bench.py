@@ -204,7 +204,7 @@ def main():
                     "and report them under \"serial\" (off by default so that a profile of the default command sees only the timed pattern)")
     ap.add_argument("--no-stages", action="store_true", help="skip the (untimed) legs for the stages around the QP: corridor-bounds producer "
                     "and post-solve collision check (SURVEY.md §8f-1/2)")
-    ap.add_argument("--cpu-sample", type=int, default=768, help="paths timed on the CPU oracle (rank 0, N=1 only)")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="paths timed on the CPU oracle (rank 0, N=1 only)")
     args = ap.parse_args()
 
     import torch
@@ -363,7 +363,7 @@ def main():
                 from oracle import ref_py
 
                 if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libpo_ref.so")):
-                    nr = min(24, ns)
+                    nr = min(384, ns)  # ~5 s
                     rp = oracle_py.default_params()
                     inst = lambda b_: dict(ref_x=batch.ref_x[b_], ref_y=batch.ref_y[b_], ref_z=batch.ref_z[b_], ref_k=batch.ref_k[b_], ref_s=batch.ref_s[b_],
                                            bounds=batch.bounds[b_], x0=batch.x0[b_], goal_z=batch.goal_z[b_])
