@@ -55,7 +55,7 @@ template <int F> __global__ __launch_bounds__(64) void assemble_kernel(DevBatch 
 #define PO_DECL(name) extern "C" hipError_t name(const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out)
 PO_DECL(po_launch_solve_kp); PO_DECL(po_launch_solve_kp_uni);
 PO_DECL(po_launch_solve_kpc); PO_DECL(po_launch_solve_kpc_uni);
-PO_DECL(po_launch_solve_k);
+PO_DECL(po_launch_solve_k); PO_DECL(po_launch_solve_k_uni);
 #undef PO_DECL
 
 // Two launches on the same stream for the two-level mapping: the uniform-row-class variant first (solves what it can, defers the rest),
@@ -65,7 +65,8 @@ extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po
     hipError_t e;
     if (form == F_KP) { e = po_launch_solve_kp_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kp(in, P, st, lds_out); }
     if (form == F_KPC) { e = po_launch_solve_kpc_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kpc(in, P, st, lds_out); }
-    return po_launch_solve_k(in, P, st, lds_out);
+    e = po_launch_solve_k_uni(in, P, st, lds_out);
+    return e != hipSuccess ? e : po_launch_solve_k(in, P, st, lds_out);
 }
 
 extern "C" hipError_t po_launch_scale(int form, const po::DevBatch *in, const po::DevParams *P, int passes, double *sc, hipStream_t st) {

@@ -129,9 +129,8 @@ inline bool resolve_shape(int form, int N, int C, int keep, Shape *s) {
     if (s->two && lds_of(form, N, C, *s) > 160 * 1024) return pick_shape(form, N, C, /*keep (forces the single-level candidates)*/ 0, s);
     return true;
 }
-// UNI = true: the uniform-row-class variant of the two-level kernels (no-op for shapes that use the single-level mapping, and for K, whose
-// end stages never share the pattern); UNI = false: the general variant.  po_launch_solve issues them in this order on one stream.
-template <int F> inline bool has_uni_variant(const Shape &s) { return s.two && F != F_K; }
+// UNI = true: the uniform-row-class variant of the two-level kernels (no-op for shapes that use the single-level mapping and for K on multi-wave blocks); UNI = false: the general variant.  po_launch_solve issues them in this order on one stream.
+template <int F> inline bool has_uni_variant(const Shape &s) { return s.two && (F != F_K || s.nt == 64); }  // K: one-wave blocks only (Fast::classify)
 template <int F, bool UNI> hipError_t launch_form(const DevBatch *in_, const DevParams *P, hipStream_t st, size_t *lds_out) {
     Shape s;
     if (!resolve_shape(F, in_->N, in_->C, in_->keep, &s)) return hipErrorInvalidValue;
