@@ -60,7 +60,14 @@ template <> struct FormTraits<F_K> {
     static constexpr int NLOC = 9, NEND = 0, NDYN = 2, NS = 1, HAS_U = 0, NCTL = 0, HAS_SU = 0;
 };
 
-__device__ __forceinline__ double clipd(double v, double l, double u) { return fmin(fmax(v, l), u); }
+__host__ __device__ __forceinline__ double clipd(double v, double l, double u) { return fmin(fmax(v, l), u); }
+// One-sided and free rows: the generators pass these tags instead of the literal +-kInf, and the vacuous half of the clip is dropped at
+// compile time (|v| never gets near 1e30): one v_max / v_min less per soft-corridor row and pass.  Everywhere else they read as +-kInf.
+struct NegInfT { __host__ __device__ constexpr operator double() const { return -kInf; } };
+struct PosInfT { __host__ __device__ constexpr operator double() const { return kInf; } };
+__host__ __device__ __forceinline__ double clipd(double v, NegInfT, double u) { return fmin(v, u); }
+__host__ __device__ __forceinline__ double clipd(double v, double l, PosInfT) { return fmax(v, l); }
+__host__ __device__ __forceinline__ double clipd(double v, NegInfT, PosInfT) { return v; }
 
 // OSQP set_rho_vec: loose rows (both bounds infinite) get RHO_MIN, equalities (u-l < 1e-4) 1e3*rho.
 __device__ __forceinline__ double rho_of(double l, double u, double rho, double rho_eq) {
@@ -94,33 +101,33 @@ template <int F, class Fn> __device__ __forceinline__ void local_rows(const Stag
         fn.template row<M_S1>(1, 0., 0., 0., 1., 0., 0.0, P.margin);
         fn.template row<M_EY | M_EPHI>(2, 1., P.d1, 0., 0., 0., s.lb[0], s.ub[0]);
         fn.template row<M_EY | M_EPHI>(3, 1., P.d3, 0., 0., 0., s.lb[2], s.ub[2]);
-        fn.template row<M_EY | M_EPHI | M_S1>(4, 1., P.d4, 0., -1., 0., -kInf, s.ub[3] - P.margin);
-        fn.template row<M_EY | M_EPHI | M_S1>(5, 1., P.d4, 0., 1., 0., s.lb[3] + P.margin, kInf);
-        fn.template row<M_EY | M_EPHI | M_S1>(6, 1., P.d2, 0., -1., 0., -kInf, s.ub[1] - P.margin);
-        fn.template row<M_EY | M_EPHI | M_S1>(7, 1., P.d2, 0., 1., 0., s.lb[1] + P.margin, kInf);
+        fn.template row<M_EY | M_EPHI | M_S1>(4, 1., P.d4, 0., -1., 0., NegInfT{}, s.ub[3] - P.margin);
+        fn.template row<M_EY | M_EPHI | M_S1>(5, 1., P.d4, 0., 1., 0., s.lb[3] + P.margin, PosInfT{});
+        fn.template row<M_EY | M_EPHI | M_S1>(6, 1., P.d2, 0., -1., 0., NegInfT{}, s.ub[1] - P.margin);
+        fn.template row<M_EY | M_EPHI | M_S1>(7, 1., P.d2, 0., 1., 0., s.lb[1] + P.margin, PosInfT{});
     } else if constexpr (F == F_KPC) {
         // solver_kp_as_input_constrained.cpp:110-143 (rows) and :165-205 (bounds)
-        fn.template row<M_C | M_S2>(0, 0., 0., 1., 0., 1., -s.maxk, kInf);
-        fn.template row<M_C | M_S2>(1, 0., 0., 1., 0., -1., -kInf, s.maxk);
+        fn.template row<M_C | M_S2>(0, 0., 0., 1., 0., 1., -s.maxk, PosInfT{});
+        fn.template row<M_C | M_S2>(1, 0., 0., 1., 0., -1., NegInfT{}, s.maxk);
         fn.template row<M_S1>(2, 0., 0., 0., 1., 0., 0.0, P.margin);
         fn.template row<M_S2>(3, 0., 0., 0., 0., 1., 0.0, fmax(P.kmax - s.maxk, 0.0));
         fn.template row<M_EY | M_EPHI>(4, 1., P.d1, 0., 0., 0., s.lb[0], s.ub[0]);
         fn.template row<M_EY | M_EPHI>(5, 1., P.d2, 0., 0., 0., s.lb[1], s.ub[1]);
         fn.template row<M_EY | M_EPHI>(6, 1., P.d4, 0., 0., 0., s.lb[3], s.ub[3]);
-        fn.template row<M_EY | M_EPHI | M_S1>(7, 1., P.d3, 0., -1., 0., -kInf, s.ub[2] - P.margin);
-        fn.template row<M_EY | M_EPHI | M_S1>(8, 1., P.d3, 0., 1., 0., s.lb[2] + P.margin, kInf);
+        fn.template row<M_EY | M_EPHI | M_S1>(7, 1., P.d3, 0., -1., 0., NegInfT{}, s.ub[2] - P.margin);
+        fn.template row<M_EY | M_EPHI | M_S1>(8, 1., P.d3, 0., 1., 0., s.lb[2] + P.margin, PosInfT{});
     } else {
         // solver_k_as_input.cpp:123-147 (rows) and :167-206 (bounds); identity rows on every variable
         const bool win = s.last && (s.elo > -kInf);
         fn.template row<M_EPHI>(0, 0., 1., 0., 0., 0., win ? s.elo : -kInf, win ? s.ehi : kInf);
-        fn.template row<M_EY>(1, 1., 0., 0., 0., 0., -kInf, kInf);
+        fn.template row<M_EY>(1, 1., 0., 0., 0., 0., NegInfT{}, PosInfT{});
         if (!s.last) fn.template row<M_C>(2, 0., 0., 1., 0., 0., -P.max_steer, P.max_steer);
         fn.template row<M_S1>(3, 0., 0., 0., 1., 0., 0.0, P.margin);
         fn.template row<M_EY | M_EPHI>(4, 1., P.d1, 0., 0., 0., s.lb[0], s.ub[0]);
         fn.template row<M_EY | M_EPHI>(5, 1., P.d3, 0., 0., 0., s.lb[2], s.ub[2]);
         fn.template row<M_EY | M_EPHI>(6, 1., P.d4, 0., 0., 0., s.lb[3], s.ub[3]);
-        fn.template row<M_EY | M_EPHI | M_S1>(7, 1., P.d2, 0., -1., 0., -kInf, s.ub[1] - P.margin);
-        fn.template row<M_EY | M_EPHI | M_S1>(8, 1., P.d2, 0., 1., 0., s.lb[1] + P.margin, kInf);
+        fn.template row<M_EY | M_EPHI | M_S1>(7, 1., P.d2, 0., -1., 0., NegInfT{}, s.ub[1] - P.margin);
+        fn.template row<M_EY | M_EPHI | M_S1>(8, 1., P.d2, 0., 1., 0., s.lb[1] + P.margin, PosInfT{});
     }
 }
 
@@ -130,7 +137,7 @@ template <int F, class Fn> __device__ __forceinline__ void end_rows(const StageI
         fn.template row<M_EY>(0, 1., 0., 0., 0., 0., -1.0, 1.0);
         fn.template row<M_EPHI>(1, 0., 1., 0., 0., 0., s.elo, s.ehi);
     } else if constexpr (F == F_KPC) {
-        fn.template row<M_EY>(0, 1., 0., 0., 0., 0., -kInf, kInf);
+        fn.template row<M_EY>(0, 1., 0., 0., 0., 0., NegInfT{}, PosInfT{});
         fn.template row<M_EPHI>(1, 0., 1., 0., 0., 0., s.elo, s.ehi);
     }
 }
@@ -301,7 +308,7 @@ __device__ __forceinline__ double class_rho(unsigned cls, int r, double w, doubl
 struct ClassFn {  // packs the row classes of one stage / control
     unsigned cls;
     const double *E;
-    template <int MASK> __device__ __forceinline__ void row(int r, double, double, double, double, double, double l, double u) {
+    template <int MASK, class TL, class TU> __device__ __forceinline__ void row(int r, double, double, double, double, double, TL l, TU u) {
         cls |= row_class(l, u, E[r]) << (2 * r);
     }
 };
@@ -316,7 +323,7 @@ struct HessFn {  // H(5x5 sym, upper, row-major packed 15) += rho * a a'
         for (int i = 0; i < 15; ++i) H[i] = 0;
     }
     static __device__ __forceinline__ constexpr int idx(int a, int b) { return a * 5 - a * (a - 1) / 2 + (b - a); }
-    template <int MASK> __device__ __forceinline__ void row(int ri, double c0, double c1, double c2, double c3, double c4, double l, double u) {
+    template <int MASK, class TL, class TU> __device__ __forceinline__ void row(int ri, double c0, double c1, double c2, double c3, double c4, TL l, TU u) {
         const double r = class_rho(cls, ri, W[ri], rho, rho_eq);
         const double c[5] = {c0, c1, c2, c3, c4};
 #pragma unroll
@@ -336,7 +343,7 @@ struct RhsFn {
     const double *W, *E;
     unsigned cls;
     bool first;
-    template <int MASK> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, double l, double u) {
+    template <int MASK, class TL, class TU> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, TL l, TU u) {
         const double rr = class_rho(cls, r, W[r], rho, rho_eq);
         const double vv = v[r * stride];
         const double zc = first ? 0.0 : clipd(vv, l, u);
@@ -363,7 +370,7 @@ template <bool UNI, bool FIRST, int NR> struct RhsFnX {
 #pragma unroll
         for (int r = 0; r < NR; ++r) rr[r] = r < nrows ? class_rho(pat, r, W[r], rho, rho_eq) : 0.0;
     }
-    template <int MASK> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, double l, double u) {
+    template <int MASK, class TL, class TU> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, TL l, TU u) {
         const double rw = UNI ? rr[r] : class_rho(cls, r, W[r], rho, rho_eq);
         const double vv = v[r * stride];
         const double t = FIRST ? -(rw * vv) : rw * (2.0 * clipd(vv, l, u) - vv);
@@ -378,7 +385,7 @@ template <bool FIRST> struct UpdFnX {
     double *v;
     int stride;
     double alpha;
-    template <int MASK> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, double l, double u) {
+    template <int MASK, class TL, class TU> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, TL l, TU u) {
         const double c[5] = {c0, c1, c2, c3, c4};
         double zt = 0;
 #pragma unroll
@@ -396,7 +403,7 @@ struct UpdFn {
     int stride;
     double alpha;
     bool first;
-    template <int MASK> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, double l, double u) {
+    template <int MASK, class TL, class TU> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, TL l, TU u) {
         const double c[5] = {c0, c1, c2, c3, c4};
         double zt = 0;
 #pragma unroll
@@ -421,7 +428,7 @@ struct UpdCertFn {
     unsigned cls;
     double ady[5];        // A' dy contribution to the local variables
     double ndy, sup;      // max |dy| (projected), sum of u*dy+ + l*dy-
-    template <int MASK> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, double l, double u) {
+    template <int MASK, class TL, class TU> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, TL l, TU u) {
         const double c[5] = {c0, c1, c2, c3, c4};
         double zt = 0;
 #pragma unroll
@@ -455,7 +462,7 @@ struct ResFn {
     unsigned cls;
     double rp, nAx, nz;     // unscaled (termination)
     double rps, nAxs, nzs;  // scaled by E (rho estimate)
-    template <int MASK> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, double l, double u) {
+    template <int MASK, class TL, class TU> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, TL l, TU u) {
         const double rr = class_rho(cls, r, W[r], rho, rho_eq);
         const double c[5] = {c0, c1, c2, c3, c4};
         double ax = 0;
@@ -480,7 +487,7 @@ struct RescaleFn {
     int stride;
     double ratio;
     unsigned cls;
-    template <int MASK> __device__ __forceinline__ void row(int r, double, double, double, double, double, double l, double u) {
+    template <int MASK, class TL, class TU> __device__ __forceinline__ void row(int r, double, double, double, double, double, TL l, TU u) {
         const double vv = v[r * stride];
         const double zc = clipd(vv, l, u);
         const bool loose = ((cls >> (2 * r)) & 3u) == 2u;
@@ -492,7 +499,7 @@ struct RescaleFn {
 template <int F> struct AsmFn {
     double *l, *u;
     int j, N, C, kind;  // kind 0 local, 1 end, 2 ctl (j = control id)
-    template <int MASK> __device__ __forceinline__ void row(int r, double, double, double, double, double, double lo, double hi) {
+    template <int MASK, class TL, class TU> __device__ __forceinline__ void row(int r, double, double, double, double, double, TL lo, TU hi) {
         const int rr = kind == 0 ? ref_row_local<F>(r, j, N, C) : (kind == 1 ? ref_row_end<F>(r, N, C) : ref_row_ctl<F>(r, j, N, C));
         l[rr] = lo;
         u[rr] = hi;
@@ -503,11 +510,11 @@ template <int F> struct AsmFn {
 // KPC: kpl / kpu / Skp >= 0 (solver_kp_as_input_constrained.cpp:119-125,178-187).  coefficient slots: (unused,unused,u,su,unused)
 template <int F, class Fn> __device__ __forceinline__ void ctl_rows(double maxkp, Fn &fn) {
     if constexpr (F == F_KP) {
-        fn.template row<M_C>(0, 0., 0., 1., 0., 0., -kInf, kInf);
+        fn.template row<M_C>(0, 0., 0., 1., 0., 0., NegInfT{}, PosInfT{});
     } else if constexpr (F == F_KPC) {
-        fn.template row<M_C | M_S1>(0, 0., 0., 1., 1., 0., -maxkp, kInf);
-        fn.template row<M_C | M_S1>(1, 0., 0., 1., -1., 0., -kInf, maxkp);
-        fn.template row<M_S1>(2, 0., 0., 0., 1., 0., 0.0, kInf);
+        fn.template row<M_C | M_S1>(0, 0., 0., 1., 1., 0., -maxkp, PosInfT{});
+        fn.template row<M_C | M_S1>(1, 0., 0., 1., -1., 0., NegInfT{}, maxkp);
+        fn.template row<M_S1>(2, 0., 0., 0., 1., 0., 0.0, PosInfT{});
     }
 }
 

@@ -34,7 +34,7 @@ struct ClassModel {
 struct PatFn {
     ClassModel *M;
     int base;
-    template <int MASK> __host__ __device__ void row(int r, double c0, double c1, double c2, double c3, double c4, double, double) {
+    template <int MASK, class TL, class TU> __host__ __device__ void row(int r, double c0, double c1, double c2, double c3, double c4, TL, TU) {
         double *a = M->a[base + r];
         a[0] = c0; a[1] = c1; a[2] = c2; a[3] = c3; a[4] = c4;
     }
@@ -42,7 +42,7 @@ struct PatFn {
 struct PatCtlFn {  // control rows use slots (.,.,u,su,.) -> variable classes 5, 6
     ClassModel *M;
     int base;
-    template <int MASK> __host__ __device__ void row(int r, double, double, double c2, double c3, double, double, double) {
+    template <int MASK, class TL, class TU> __host__ __device__ void row(int r, double, double, double c2, double c3, double, TL, TU) {
         double *a = M->a[base + r];
         a[5] = c2; a[6] = c3;
     }
