@@ -225,6 +225,34 @@ def test_every_keep_control_steps_value(binding, oracle, keep):
         assert np.abs(xs - oxs)[ok].max() < 1e-5
 
 
+@pytest.mark.parametrize("keep", [4, 3, 2, 1])
+def test_scan_row_and_wave_boundaries(binding, oracle, keep):
+    """Path lengths that put the number of chunks just below / on / above the boundaries of the scan structure: the 16-lane DPP rows of the
+    one-wave scan (16, 32, 48 chunks), the wave (64), the 8-lane segments and the second wave of the segmented scan (65 ... 128), ragged too."""
+    ds = 1.2 / keep * 0.999
+    sizes = sorted({keep * c + d for c in (15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 72, 73, 96, 127, 128) for d in (0, 1) if keep * c + d <= 512 and keep * c + d >= 3})
+    sizes = [n for n in sizes if n <= (256 if keep == 1 else 512)]
+    for N in sizes:
+        b = _rand_batch(T.PO_KP, 2, N, ds=ds, seed=7 * N + keep)
+        b.keep = keep
+        p = binding.default_params(); p.max_iter, p.check_every, p.adapt_every = 40, 0, 25
+        po = oracle.device_equivalent_params(); po.max_iter, po.check_every, po.adapt_every = 40, 0, 25
+        st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
+        ost, oinfo, oxs = oracle.solve_batch(b, po)
+        assert np.abs(xs - oxs).max() < 1e-8, (keep, N, np.abs(xs - oxs).max())
+        assert np.array_equal(info["n_refactor"], oinfo["n_refactor"])
+    # ragged: the longest path sizes the block, the shorter ones end inside a row / a wave
+    N = keep * 66 if keep * 66 <= 256 or keep > 1 else 256
+    b = _rand_batch(T.PO_KP, 4, N, ds=ds, seed=99 + keep)
+    b.keep = keep
+    b.n_points = np.array([N, keep * 16 + 1, keep * 33, max(keep + 2, 5)], dtype=np.int32)
+    p = binding.default_params(); p.max_iter, p.check_every, p.adapt_every = 40, 0, 25
+    po = oracle.device_equivalent_params(); po.max_iter, po.check_every, po.adapt_every = 40, 0, 25
+    st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
+    ost, oinfo, oxs = oracle.solve_batch(b, po)
+    assert np.abs(xs - oxs).max() < 1e-8 and np.abs(st - ost).max() < 1e-8
+
+
 def test_api_errors_and_empty(binding):
     eng = binding.Engine(0)
     b = _rand_batch(T.PO_KP, 2, 10)
