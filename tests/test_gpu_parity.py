@@ -253,6 +253,22 @@ def test_scan_row_and_wave_boundaries(binding, oracle, keep):
     assert np.abs(xs - oxs).max() < 1e-8 and np.abs(st - ost).max() < 1e-8
 
 
+@pytest.mark.parametrize("form,name", [(T.PO_KPC, "KPC"), (T.PO_K, "K")])
+def test_scan_boundaries_other_formulations(binding, oracle, form, name):
+    """KPC / K at the same structural boundaries (uniform variants with their per-stage patches: K's end stages and final stage, KPC's
+    curvature-slack box row), fixed iteration count, incl. a rho adaption."""
+    for N in (63, 64, 65, 127, 128, 129, 130, 255, 256, 257, 300):
+        b = _rand_batch(form, 2, N, seed=31 * N + form)
+        if form == T.PO_KPC:  # make the class of the curvature-slack box row change along the path (max_k above / below kappa_max)
+            b.max_k = b.max_k.copy(); b.max_k[:, ::3] = 0.5
+        p = binding.default_params(); p.max_iter, p.check_every, p.adapt_every = 40, 0, 25
+        po = oracle.device_equivalent_params(); po.max_iter, po.check_every, po.adapt_every = 40, 0, 25
+        st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
+        ost, oinfo, oxs = oracle.solve_batch(b, po)
+        assert np.abs(xs - oxs).max() < 1e-8, (name, N, np.abs(xs - oxs).max())
+        assert np.array_equal(info["n_refactor"], oinfo["n_refactor"])
+
+
 def test_api_errors_and_empty(binding):
     eng = binding.Engine(0)
     b = _rand_batch(T.PO_KP, 2, 10)
