@@ -333,7 +333,8 @@ def main():
                          "traffic": traffic, "kernel": "po::solve_kernel_fast<KP,SPL=4,NT=64,two-level,uniform-row-classes> (the general-variant launch that follows it only picks up deferred paths: none on this workload)", "kernel_ms": kernel_ms,
                          "kernel_ms_all_launches": kernel_ms_all,  # warm-up launches included: the figure rocprofv3's per-kernel average corresponds to
                          "algorithmic_bytes_per_path_iter": b_iter,
-                         "note": "algorithmic bytes of one launch / that launch's duration (hipEvents on its stream); launches of the "
+                         "note": "algorithmic bytes of one solve call / that call's duration (hipEvents on its stream around the equilibration kernel, the uniform-variant "
+                                 "launch that does the work and the general-variant launch that follows it: rocprofv3 lists them separately); launches of the "
                                  f"{S} streams overlap, so one launch's duration is longer than ms_per_step; the state is LDS-resident, so this is not HBM traffic",
                          "aggregate_achieved": abytes * args.steps / elapsed / 1e9, "aggregate_frac": abytes * args.steps / elapsed / 1e9 / 8000.0,
                          # the bound that actually limits the kernel: fp64 VALU issue, v_fma_f64 = 8 cycles per
