@@ -266,9 +266,13 @@ def main():
     _, warm_kernel_ms = run(args.warmup, S) if args.warmup > 0 else (0.0, None)
     elapsed, kernel_ms = run(args.steps, S)
     kernel_ms_all = kernel_ms if warm_kernel_ms is None else (warm_kernel_ms * args.warmup + kernel_ms * args.steps) / (args.warmup + args.steps)
+    rank_time_max_over_mean = 1.0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tsum = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        rank_time_max_over_mean = float(t.item()) / (float(tsum.item()) / world)  # load imbalance between the shards
         elapsed = float(t.item())
     # the same K steps strictly one after the other on one stream (reported beside the headline, not as `value`)
     serial_elapsed, serial_kernel_ms = run(args.steps, 1) if (S > 1 and args.serial_leg) else ((elapsed, kernel_ms) if S == 1 else (None, None))
@@ -317,6 +321,7 @@ def main():
             "config": {"workload": f"BASELINE config {cfg}: KP, B={B} paths/GPU x {world} GPU, N={N} points, "
                                    "per-path random obstacle clearances, OSQP defaults (scaling 10, adaptive rho every 100 it) at eps_abs=eps_rel=1e-4",
                        "batch_per_gpu": B, "points": N, "formulation": "KP", "parallelism": f"batch-split x{world}",
+                       "rank_time_max_over_mean": rank_time_max_over_mean,
                        "streams_per_gpu": S},
             # the same K steps issued strictly serially on one stream (every step waits for the previous step's last straggler)
             "serial": None if serial_elapsed is None else {
