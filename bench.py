@@ -1,19 +1,22 @@
 #!/usr/bin/env python
 """bench.py — QP paths/sec of the batched solve (BASELINE.json metric) on N GPUs of one node.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (assembly + factorisation + ADMM to eps 1e-4 + output map, one fused
-kernel launch) over one batch of synthetic planning instances already resident in HBM:
+A "step" is one pass of the hot path (equilibration + assembly + factorisation + ADMM to eps 1e-4 + output map) over one batch of
+synthetic planning instances already resident in HBM:
   N=1   BASELINE config 3: B=4096 paths, N=200 points, KP, per-path random obstacle clearances
-  N>1   BASELINE config 4: the same generator, 4096 paths per GPU (contiguous shard of path ids), no
-        data-path collective (paths are independent); RCCL is used only for the barrier / max-time reduction.
-Rank 0 prints ONE JSON line.  `roofline.achieved` is ALGORITHMIC bytes (B_iter = 8*(128N+13C+9)
-bytes per path-iteration + 8*(18N+8) compulsory I/O per path) / measured kernel time — NOT HBM traffic: the
-solver state is LDS-resident, so `frac` can exceed what HBM could stream; measured HBM traffic (rocprofv3 PMC,
-profiles/) is reported beside it as `traffic`.
+  N>1   BASELINE config 4: the same generator, 4096 paths per GPU (contiguous shard of path ids), no data-path collective
+        (paths are independent); RCCL carries the barrier, the reduction of a few statistics and (--gather) the result gather.
+`value` is what SURVEY.md §8d prescribes: K single-batch solves issued one after the other on ONE stream, timed between two
+barriers (max over ranks); `single_batch` holds the per-step hipEvent figures (median of K).  The throughput of independent batches
+overlapped on 3 handles/streams is reported beside it as `pipelined_3_streams`, never as `value`.
+Rank 0 prints ONE JSON line.  `roofline` is the fp64 VALU issue roof (the solver state is LDS/register resident: HBM is not the
+binding resource); SURVEY §8d's algorithmic-bytes contract figure is kept as `roofline.algorithmic_hbm_equivalent`.
+`parity` is computed in the run: device vs the CPU oracle at identical settings on the CPU-baseline sample, and the lateral-offset
+RMS against the exact optimum (tests/golden/tight_c3.npz) with and without the opt-in polish step.
 """
 import argparse
 import json
@@ -26,6 +29,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak: 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GHz (half the 157.3 TF fp32 vector peak of MI355X_MICROARCH.md)
+FP64_VALU_MEASURED_CEILING = {"1_wave_per_simd": 36.0, "2_waves": 52.0, "4_waves": 59.0}  # tools/ubench/fp64_rate.hip on this chip
+
 
 def algorithmic_bytes(form, N, keep, iters_sum, B):
     C = (N + keep - 2) // keep if form != 2 else N - 1
@@ -33,9 +39,132 @@ def algorithmic_bytes(form, N, keep, iters_sum, B):
     return 8.0 * vals * iters_sum + 8.0 * (18 * N + 8) * B, 8.0 * vals
 
 
-def stage_legs(torch, binding, synth, eng, stream, dbatch, B, with_cpu):
-    """Stages immediately before / after the QP on the same device (reported beside the headline, never part of `value`):
-    corridor-bounds producer over a synthetic obstacle-distance map and the post-solve collision check of the solved batch."""
+def _load_json(path):
+    try:
+        return json.load(open(path))
+    except Exception:
+        return None
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# GPU legs
+# ---------------------------------------------------------------------------------------------------------------------------
+def time_serial(torch, eng, stream, db, steps, barrier):
+    """`steps` complete solves of the batch one after the other on one stream.  Returns (wall seconds between the barriers, [ms per step])."""
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record(stream)
+        eng.solve_batch_device(db)
+        e1.record(stream)
+    barrier()
+    t1 = time.perf_counter()
+    return t1 - t0, [a.elapsed_time(b) for a, b in evs]
+
+
+def time_pipelined(torch, engs, streams, dbs, steps, barrier):
+    """step k on handle k % S: the stragglers of one batch drain while the next batch fills the CUs."""
+    S = len(engs)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k, (e0, e1) in enumerate(evs):
+        i = k % S
+        e0.record(streams[i])
+        engs[i].solve_batch_device(dbs[i])
+        e1.record(streams[i])
+    barrier()
+    t1 = time.perf_counter()
+    return t1 - t0, [a.elapsed_time(b) for a, b in evs]
+
+
+def config_legs(torch, binding, synth, dev, stream, steps=3):
+    """The other BASELINE configs as quick legs: c1 (single path N=80), c2 (B=1024, N=120), c5 (KPC, B=4096, N=400) and
+    the K formulation on config-3 corridors.  Single-batch figures, median of `steps` after one warm-up."""
+    out = {}
+    for name, cfg, kw in (("c1", 1, {}), ("c2", 2, {}), ("c5", 5, {}), ("k", 3, {"formulation": 2})):
+        b = synth.make_batch(cfg, **kw)
+        db = binding.DeviceBatch(b, device=dev)
+        eng = binding.Engine(torch.cuda.current_device())
+        eng.set_stream(stream.cuda_stream)
+        eng.solve_batch_device(db)
+        torch.cuda.synchronize()
+        _, ms = time_serial(torch, eng, stream, db, steps, torch.cuda.synchronize)
+        info = db.info_numpy()
+        med = float(np.median(ms))
+        out[name] = {"workload": f"BASELINE config {cfg}" + (" corridors, K formulation" if kw else "") + f": {['KP', 'KPC', 'K'][b.formulation]}, B={b.B}, N={b.N}",
+                     "ms": med, "paths_per_s": b.B / (med * 1e-3), "path_iters_per_s": float(info["iters"].sum()) / (med * 1e-3),
+                     "iters_mean": float(info["iters"].mean()), "iters_max": int(info["iters"].max()), "unsolved": int((info["status"] != 1).sum())}
+        eng.close()
+    return out
+
+
+def accuracy_legs(torch, binding, synth, batch, dev, stream, cpu_sample):
+    """Device side of the `parity` block: (a) the first `cpu_sample` paths solved with the raw QP solution kept (compared with the oracle
+    after the GPU legs), (b) lateral-offset RMS against the exact optimum of the first 256 paths (tests/golden/tight_c3.npz) at the
+    benchmarked setting, with the opt-in polish step, and at tighter eps; each setting timed as single-batch launches of the full batch."""
+    from path_optimizer_amd.abi import PoParams
+
+    gold = None
+    gpath = os.path.join(ROOT, "tests", "golden", "tight_c3.npz")
+    if batch.formulation == 0 and batch.N == 200 and os.path.exists(gpath):
+        gold = np.load(gpath)["e_y"]
+    ns = max(min(cpu_sample, batch.B), min(256, batch.B))
+    sample = batch.slice(0, ns)
+    sdb = binding.DeviceBatch(sample, device=dev, want_x=True)
+    full = binding.DeviceBatch(batch, device=dev)
+    N = batch.N
+    res = {"x_sample": None, "info_sample": None, "settings": []}
+
+    def run(label, mutate):
+        p = binding.default_params()
+        mutate(p)
+        eng = binding.Engine(torch.cuda.current_device(), p)
+        eng.set_stream(stream.cuda_stream)
+        eng.solve_batch_device(sdb)
+        torch.cuda.synchronize()
+        x = sdb.out_x.cpu().numpy().copy()
+        info = sdb.info_numpy().copy()
+        eng.solve_batch_device(full)
+        torch.cuda.synchronize()
+        _, ms = time_serial(torch, eng, stream, full, 3, torch.cuda.synchronize)
+        finfo = full.info_numpy()
+        row = {"setting": label, "ms": float(np.median(ms)), "paths_per_s": batch.B / (float(np.median(ms)) * 1e-3),
+               "iters_mean": float(finfo["iters"].mean()), "iters_max": int(finfo["iters"].max()), "unsolved": int((finfo["status"] != 1).sum())}
+        if "reserved" in finfo.dtype.names:
+            row["polished"] = int((finfo["reserved"] == 1).sum())
+        if gold is not None:
+            ng = min(len(gold), ns)
+            rms = np.sqrt(np.mean((x[:ng, 0:3 * N:3] - gold[:ng]) ** 2, axis=1))
+            row["e_y_rms_vs_exact_optimum_m"] = {"paths": int(ng), "median": float(np.median(rms)), "p95": float(np.percentile(rms, 95)), "max": float(rms.max()),
+                                                 "frac_le_1e-4": float((rms <= 1e-4).mean())}
+        eng.close()
+        return row, x, info
+
+    row, x, info = run("eps 1e-4 (benchmarked)", lambda p: None)
+    res["settings"].append(row)
+    res["x_sample"], res["info_sample"], res["sample"] = x, info, sample
+    has_polish = any(f[0] == "polish" for f in PoParams._fields_)
+    if has_polish:
+        def pol(p, passes):
+            p.polish = 1
+            p.polish_passes = passes
+        res["settings"].append(run("eps 1e-4 + polish (OSQP: 1 pass)", lambda p: pol(p, 1))[0])
+        res["settings"].append(run("eps 1e-4 + polish (active-set passes <= 6)", lambda p: pol(p, 6))[0])
+    for eps in (1e-5, 1e-6, 1e-7):
+        def tight(p, eps=eps):
+            p.eps_abs = p.eps_rel = eps
+            p.max_iter = 20000
+            if has_polish:
+                p.polish = 1
+                p.polish_passes = 6
+        res["settings"].append(run(f"eps {eps:g}" + (" + polish (<= 6 passes)" if has_polish else "") + ", max_iter 20000", tight)[0])
+    return res
+
+
+def stage_legs_gpu(torch, binding, synth, eng, stream, dbatch, B):
+    """Stages immediately before / after the QP on the same device (reported beside the headline, never part of `value`)."""
     d, res, px, py, _ = synth.make_distance_map(seed=3, size_x=600, size_y=600, resolution=0.2, pos=(1.0, -2.0), n_obstacles=60, r_range=(0.5, 3.0))
     eng.set_map(d, res, px, py)
     nb = 256
@@ -63,7 +192,6 @@ def stage_legs(torch, binding, synth, eng, stream, dbatch, B, with_cpu):
                               "workload": f"{B} spline reference paths x 200 states x 4 circles, <= 28 bilinear samples each"},
           "post_check": {"ms": ms_c, "paths_per_s": B / (ms_c * 1e-3), "states_per_s": B * 200 / (ms_c * 1e-3),
                          "ok_frac": float(ok.float().mean().item())}}
-    # reference-smoothing QPs: TENSION2 (100 points) and the post-smoothing QP (60 layers), 4096 instances each
     from path_optimizer_amd.abi import INFO_DTYPE
     sm = {}
     sm_inputs = {}
@@ -79,7 +207,6 @@ def stage_legs(torch, binding, synth, eng, stream, dbatch, B, with_cpu):
         sm[name] = {"ms": ms_s, "qps_per_s": B / (ms_s * 1e-3), "qp_iters_per_s": float(inf["iters"].sum()) / (ms_s * 1e-3), "iters_mean": float(inf["iters"].mean()),
                     "iters_max": int(inf["iters"].max()), "unsolved": int((inf["status"] != 1).sum()), "points": npts, "n": n_q, "m": m_q}
     st["smoothing_qps"] = sm
-    # DP lattice search and curvature-adaptive re-sampling on 4096 spline references
     spn, length, start = synth.make_search_inputs(9, nb)
     rp = lambda a: torch.from_numpy(np.ascontiguousarray(np.concatenate([a] * reps, axis=0)[:B])).cuda()
     ts = {k: rp(spn[k]) for k in ("knot_s", "knot_x", "knot_y")}
@@ -101,8 +228,7 @@ def stage_legs(torch, binding, synth, eng, stream, dbatch, B, with_cpu):
     scn = synth.make_planning_scenes(2, 64)
     eng.set_map(*scn["map"])
     rs = -(-B // 64)
-    # replicate the 64 scenes in a shuffled order: blocks go to the 8 XCDs round-robin, a period-64 pattern would pin scenes to XCDs
-    perm = np.random.default_rng(5).permutation(64 * rs)[:B] % 64
+    perm = np.random.default_rng(5).permutation(64 * rs)[:B] % 64  # shuffled replication: a period-64 pattern would pin scenes to XCDs
     tp = {k: torch.from_numpy(np.ascontiguousarray(scn[k][perm])).cuda() for k in ("way_x", "way_y", "start", "goal")}
     Np = 320
     po_ = dict(states=torch.zeros((B, Np, 5), dtype=torch.float64, device="cuda"), n_states=torch.zeros(B, dtype=torch.int32, device="cuda"),
@@ -119,24 +245,7 @@ def stage_legs(torch, binding, synth, eng, stream, dbatch, B, with_cpu):
                            "states_mean": float(po_["n_states"].double().mean().item()), "qp_iters_mean": float(pinf["iters"].mean()),
                            "workload": f"{B} planning instances (24 waypoints over ~70 m, 60-disc map 700 x 700 cells): bSpline -> TENSION2 QP -> DP search -> post QP -> "
                                        "re-sampling (0.15..0.3 m) -> bounds -> KP QP -> collision check"}
-    # serving pattern: consecutive batches from 3 host threads, one handle (= stream) each; the QP tail of one batch drains under the next
-    import threading
-    engs3, outs3 = [], []
-    for _ in range(3):
-        e3 = binding.Engine(torch.cuda.current_device()); e3.set_map(*scn["map"]); engs3.append(e3)
-        outs3.append({k: torch.zeros_like(v) for k, v in po_.items()})
-        e3.plan_batch_device(tp, outs3[-1], Np, way_len)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=lambda i=i: [engs3[i].plan_batch_device(tp, outs3[i], Np, way_len) for _ in range(2)]) for i in range(3)]
-    [t.start() for t in th]; [t.join() for t in th]
-    torch.cuda.synchronize()
-    ms_p3 = (time.perf_counter() - t0) / 6 * 1e3
-    st["full_pipeline"]["pipelined_3_handles"] = {"ms_per_batch": ms_p3, "instances_per_s": B / (ms_p3 * 1e-3)}
-    for e3 in engs3:
-        e3.close()
-    # the same at the reference's own stopping point: it never touches OSQP's eps (default 1e-3); 1e-4 above is this project's metric
-    p3 = binding.default_params(); p3.eps_abs = p3.eps_rel = 1e-3
+    p3 = binding.default_params(); p3.eps_abs = p3.eps_rel = 1e-3  # the reference's own stopping point: it never touches OSQP's eps (default 1e-3)
     e4 = binding.Engine(torch.cuda.current_device(), p3); e4.set_map(*scn["map"])
     e4.plan_batch_device(tp, po_, Np, way_len); torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -149,46 +258,152 @@ def stage_legs(torch, binding, synth, eng, stream, dbatch, B, with_cpu):
                                                        "qp_iters_mean": float(pinf4["iters"].mean())}
     e4.close()
     eng.set_map(d, res, px, py)
-    if with_cpu:
-        from oracle import oracle_py
-
-        m = oracle_py.make_map(d, res, px, py); p = oracle_py.default_params()
-        ms_ = oracle_py.make_map(*scn["map"])
-        c6 = time.perf_counter()
-        for b in range(16):
-            oracle_py.path_optimizer_solve(p, ms_, scn["way_x"][b], scn["way_y"][b], scn["start"][b], scn["goal"][b])
-        cpu_pipeline = 16 / (time.perf_counter() - c6)
-        c0 = time.perf_counter()
-        for b in range(64):
-            oracle_py.bounds_path(p, m, *[P[k][b] for k in keys])
-        c1 = time.perf_counter()
-        states = dbatch.out_states[:64].cpu().numpy(); info = dbatch.info_numpy()[:64]
-        oracle_py.postcheck_batch(p, m, states, info)
-        c2 = time.perf_counter()
-        st["cpu_port"] = {"bounds_paths_per_s": 64 / (c1 - c0), "post_check_paths_per_s": 64 / (c2 - c1), "cores": 1, "sample": "64 paths each, oracle (C)"}
-        for name, (kind, si) in sm_inputs.items():
-            c3 = time.perf_counter()
-            oracle_py.smooth_batch(kind, p, {k: (None if v is None else v[:64]) for k, v in si.items()})
-            st["cpu_port"][f"smoothing_{name}_qps_per_s"] = 64 / (time.perf_counter() - c3)
-        c4 = time.perf_counter()
-        for b in range(64):
-            oracle_py.dp_search(p, m, spn["knot_s"][b], spn["knot_x"][b], spn["knot_y"][b], length[b], start[b], cap=Lc)
-        c5 = time.perf_counter()
-        for b in range(64):
-            oracle_py.resample(p, spn["knot_s"][b], spn["knot_x"][b], spn["knot_y"][b], length[b], 0.15, 0.3, cap=256)
-        st["cpu_port"]["full_pipeline_instances_per_s"] = cpu_pipeline
-        st["cpu_port"]["dp_search_paths_per_s"] = 64 / (c5 - c4)
-        st["cpu_port"]["resample_paths_per_s"] = 64 / (time.perf_counter() - c5)
-    return st
+    ctx = dict(map=(d, res, px, py), scn=scn, P=P, keys=keys, sm_inputs=sm_inputs, spn=spn, length=length, start=start, Lc=Lc,
+               states64=dbatch.out_states[:64].cpu().numpy(), info64=dbatch.info_numpy()[:64])
+    return st, ctx
 
 
+def stage_legs_cpu(st, ctx):
+    """The same stages on one host core through the oracle (test infrastructure; CPU baseline legs only)."""
+    from oracle import oracle_py
+
+    d, res, px, py = ctx["map"]
+    scn, P, keys = ctx["scn"], ctx["P"], ctx["keys"]
+    m = oracle_py.make_map(d, res, px, py); p = oracle_py.default_params()
+    ms_ = oracle_py.make_map(*scn["map"])
+    c6 = time.perf_counter()
+    for b in range(16):
+        oracle_py.path_optimizer_solve(p, ms_, scn["way_x"][b], scn["way_y"][b], scn["start"][b], scn["goal"][b])
+    cpu_pipeline = 16 / (time.perf_counter() - c6)
+    c0 = time.perf_counter()
+    for b in range(64):
+        oracle_py.bounds_path(p, m, *[P[k][b] for k in keys])
+    c1 = time.perf_counter()
+    oracle_py.postcheck_batch(p, m, ctx["states64"], ctx["info64"])
+    c2 = time.perf_counter()
+    st["cpu_port"] = {"bounds_paths_per_s": 64 / (c1 - c0), "post_check_paths_per_s": 64 / (c2 - c1), "cores": 1, "sample": "64 paths each, oracle (C)"}
+    for name, (kind, si) in ctx["sm_inputs"].items():
+        c3 = time.perf_counter()
+        oracle_py.smooth_batch(kind, p, {k: (None if v is None else v[:64]) for k, v in si.items()})
+        st["cpu_port"][f"smoothing_{name}_qps_per_s"] = 64 / (time.perf_counter() - c3)
+    spn, length, start, Lc = ctx["spn"], ctx["length"], ctx["start"], ctx["Lc"]
+    c4 = time.perf_counter()
+    for b in range(64):
+        oracle_py.dp_search(p, m, spn["knot_s"][b], spn["knot_x"][b], spn["knot_y"][b], length[b], start[b], cap=Lc)
+    c5 = time.perf_counter()
+    for b in range(64):
+        oracle_py.resample(p, spn["knot_s"][b], spn["knot_x"][b], spn["knot_y"][b], length[b], 0.15, 0.3, cap=256)
+    st["cpu_port"]["full_pipeline_instances_per_s"] = cpu_pipeline
+    st["cpu_port"]["dp_search_paths_per_s"] = 64 / (c5 - c4)
+    st["cpu_port"]["resample_paths_per_s"] = 64 / (time.perf_counter() - c5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# CPU legs (after the GPU legs: `gpu_done_s` marks the boundary for the driver's gpu_busy sampling)
+# ---------------------------------------------------------------------------------------------------------------------------
 def _cpu_slice(arg):
     """Worker of the all-cores CPU baseline leg (oracle, test infrastructure)."""
     from oracle import oracle_py
 
-    batch, _ = arg
+    batch, native = arg
+    if native:
+        oracle_py.use_native()
     oracle_py.solve_batch(batch, oracle_py.device_equivalent_params(), want_x=False)
     return batch.B
+
+
+def cpu_legs(out, batch, acc, cpu_sample):
+    from oracle import oracle_py  # CPU baseline / checker legs only
+
+    native = oracle_py.use_native()  # gcc -O3 -march=native build of the same source on THIS box (SURVEY §8d); False: portable build
+    B = batch.B
+    ns = min(cpu_sample, B)
+    sample = batch.slice(0, ns)
+    oracle_py.solve_batch(sample.slice(0, 2), oracle_py.device_equivalent_params())  # warm the ordering cache
+    c0 = time.perf_counter()
+    _, oinfo, oxs = oracle_py.solve_batch(sample, oracle_py.device_equivalent_params(), want_x=True)
+    c1 = time.perf_counter()
+    out["cpu_baseline"] = {"value": ns / (c1 - c0), "unit": "paths/s", "cores": 1, "kind": "port",
+                           "sample": f"first {ns} paths of the same batch, oracle (OSQP-style ADMM, sparse LDL', gcc -O3"
+                                     f"{' -march=native, built on this box' if native else ', portable x86-64 build'}), {c1 - c0:.1f} s, mean iters {float(oinfo['iters'].mean()):.1f}",
+                           "host_cpus": os.cpu_count()}
+    # ---- parity (i): device vs oracle at identical settings on that sample ----
+    if acc is not None and acc.get("x_sample") is not None:
+        n_ = min(ns, len(acc["x_sample"]))
+        dx, dinfo = acc["x_sample"][:n_], acc["info_sample"][:n_]
+        same = dinfo["iters"] == oinfo["iters"][:n_]
+        err = np.abs(dx - oxs[:n_]).max(axis=1)
+        eps = 1e-4
+        par = out.setdefault("parity", {})
+        par["device_vs_oracle"] = {
+            "paths": int(n_), "settings": "identical (OSQP defaults, eps 1e-4, class-level Ruiz, adaptive rho every 100 it)",
+            "status_equal": int((dinfo["status"] == oinfo["status"][:n_]).sum()),
+            "iteration_count_equal": int(same.sum()), "iteration_count_mismatch": int((~same).sum()),
+            "max_abs_dx_same_count": float(err[same].max()) if same.any() else None,
+            "max_abs_dx_mismatching_paths": float(err[~same].max()) if (~same).any() else 0.0,
+            "mismatching_paths_within_10_eps": int((err[~same] <= 10 * eps).sum()) if (~same).any() else 0,
+            "note": "a residual within round-off of eps flips one termination check (25 iterations); those paths are compared at 10 x eps instead of being dropped"}
+    # the reference's OWN solver classes (oracle/_ref/libpo_ref.so = src/solver/*.cpp compiled where they lie; OSQP itself stood in by the oracle's ADMM)
+    try:
+        from oracle import ref_py
+
+        if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libpo_ref.so")):
+            nr = min(384, ns)  # ~5 s
+            rp = oracle_py.default_params()
+            inst = lambda b_: dict(ref_x=batch.ref_x[b_], ref_y=batch.ref_y[b_], ref_z=batch.ref_z[b_], ref_k=batch.ref_k[b_], ref_s=batch.ref_s[b_],
+                                   bounds=batch.bounds[b_], x0=batch.x0[b_], goal_z=batch.goal_z[b_])
+            ref_py.solve("KP", inst(0), rp)
+            r0 = time.perf_counter()
+            for b_ in range(nr):
+                ref_py.solve("KP", inst(b_), rp)
+            r1 = time.perf_counter()
+            out["cpu_baseline_reference_code"] = {"value": nr / (r1 - r0), "unit": "paths/s", "cores": 1, "kind": "reference",
+                                                  "sample": f"first {nr} paths through the reference's OsqpSolver::create(\"KP\")->solve() compiled from its own sources "
+                                                            f"(18.9 MB dense scratch per solve) with the oracle's ADMM in place of OSQP, {r1 - r0:.1f} s"}
+    except Exception as e:
+        out["cpu_baseline_reference_code"] = {"error": repr(e)}
+    try:  # the same sample on every host core, one path slice per process (the reference itself is single-threaded)
+        import multiprocessing as mp
+
+        nproc = max(1, min(os.cpu_count() or 1, 64))
+        nmt = min(B, 48 * nproc)
+        sample = batch.slice(0, nmt)
+        parts = [(lo_, min(nmt, lo_ + -(-nmt // nproc))) for lo_ in range(0, nmt, -(-nmt // nproc))]
+        with mp.get_context("spawn").Pool(len(parts)) as pool:  # spawn (not fork): the parent holds a live HIP context
+            pool.map_async(_cpu_slice, [(sample.slice(a, a + 2), native) for a, _ in parts], chunksize=1).get(timeout=180)  # warm
+            m0 = time.perf_counter()
+            pool.map_async(_cpu_slice, [(sample.slice(a, b_), native) for a, b_ in parts], chunksize=1).get(timeout=180)
+            m1 = time.perf_counter()
+        out["cpu_baseline_all_cores"] = {"value": nmt / (m1 - m0), "unit": "paths/s", "cores": len(parts), "kind": "port",
+                                         "sample": f"first {nmt} paths of the batch split over {len(parts)} processes "
+                                                   f"(one oracle instance per host core, capped at 64), {m1 - m0:.2f} s"}
+    except Exception as e:  # never let the optional leg break the bench line
+        out["cpu_baseline_all_cores"] = {"error": repr(e)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# dry run of the N>1 plumbing (no GPU: gloo, faked device times) — executed by tests/test_multi_process.py
+# ---------------------------------------------------------------------------------------------------------------------------
+class _DryEngine:
+    """Stands in for binding.Engine + DeviceBatch where no GPU exists: produces deterministic per-path statistics so that the shard
+    split, the reductions, the gather and the JSON assembly of the N>1 branch run for real."""
+
+    def __init__(self, lo, hi, N):
+        import torch
+
+        ids = np.arange(lo, hi)
+        self.iters = (25 * (1 + (ids * 2654435761 % 61))).astype(np.int32)  # multiples of 25 in [25, 1525], a function of the GLOBAL path id
+        self.out_states = torch.from_numpy(np.repeat(ids.astype(np.float64)[:, None, None], N, axis=1).repeat(5, axis=2).copy())
+        self.B = hi - lo
+
+    def info_numpy(self):
+        from path_optimizer_amd.abi import INFO_DTYPE
+
+        info = np.zeros(self.B, dtype=INFO_DTYPE)
+        info["status"] = 1
+        info["iters"] = self.iters
+        info["n_refactor"] = self.iters // 400
+        return info
 
 
 def main():
@@ -198,13 +413,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="paths per GPU")
     ap.add_argument("--config", type=int, default=0, help="BASELINE config id (default: 3 at N=1, 4 at N>1)")
-    ap.add_argument("--streams", type=int, default=3, help="handles/HIP streams the consecutive steps are issued on round-robin "
-                    "(independent batches: the stragglers of step k drain while step k+1 fills the CUs); 1 = strictly serial steps")
-    ap.add_argument("--serial-leg", action="store_true", help="additionally time the same K steps strictly serially on one stream "
-                    "and report them under \"serial\" (off by default so that a profile of the default command sees only the timed pattern)")
-    ap.add_argument("--no-stages", action="store_true", help="skip the (untimed) legs for the stages around the QP: corridor-bounds producer "
-                    "and post-solve collision check (SURVEY.md §8f-1/2)")
-    ap.add_argument("--cpu-sample", type=int, default=2048, help="paths timed on the CPU oracle (rank 0, N=1 only)")
+    ap.add_argument("--streams", type=int, default=3, help="handles/HIP streams of the secondary `pipelined` leg (0 = skip it)")
+    ap.add_argument("--no-stages", action="store_true", help="skip the legs for the stages around the QP (SURVEY.md §8f)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the quick legs for BASELINE configs 1, 2, 5 and the K formulation")
+    ap.add_argument("--no-parity", action="store_true", help="skip the accuracy / parity legs")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="paths timed on the CPU oracle (rank 0, N=1 only; 0 = no CPU legs)")
+    ap.add_argument("--gather", action="store_true", help="N>1: gather every rank's states and info on rank 0 (SURVEY §8e collective 1) and report its time")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: gloo backend, faked device times; exercises the shard split, reductions, gather and JSON "
+                    "assembly of the N>1 branch (tests/test_multi_process.py)")
     args = ap.parse_args()
 
     import torch
@@ -212,99 +428,107 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    dry = args.dry_run
+    if not dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = f"cuda:{local_rank}"
+    dev = "cpu" if dry else f"cuda:{local_rank}"
+    if not dry:
+        torch.cuda.set_device(local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))  # RCCL; used for the barrier and 4 scalars only
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))  # RCCL: barrier, 2 small reductions, optional gather
 
-    from path_optimizer_amd import binding, synth
+    from path_optimizer_amd import synth
+    from path_optimizer_amd.shard import gather_to_root, reduce_stats, shard_range
 
     cfg = args.config or (3 if world == 1 else 4)
     B = args.batch
-    from path_optimizer_amd.shard import shard_range
-
     lo, hi = shard_range(world * B, world, rank)  # weak scaling: fixed work per GPU, contiguous path ids
-    batch = synth.make_batch(cfg, B=hi - lo, first_path=lo)
-    dbatch = binding.DeviceBatch(batch, device=dev)
-    # S independent handles, each with its own HIP stream and its own output buffers (inputs are shared, read-only)
-    S = max(1, min(args.streams, max(args.steps, 1)))
-    engs, streams, dbs = [], [], []
-    for i in range(S):
-        e = binding.Engine(local_rank)
-        st = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream shared by torch events and the engine
-        e.set_stream(st.cuda_stream)
-        engs.append(e); streams.append(st)
-        dbs.append(dbatch if i == 0 else dbatch.clone_outputs())
 
     def barrier():
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
-    def run(steps, n_streams):
-        """`steps` complete solves of the batch, step k on handle k % n_streams; returns (wall seconds, per-launch ms)."""
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    if dry:
+        _, _, N0, _ = synth.CONFIGS[cfg]
+        batch = None
+        dbatch = _DryEngine(lo, hi, N0)
         barrier()
-        t0 = time.perf_counter()
-        for k, (e0, e1) in enumerate(evs):
-            i = k % n_streams
-            e0.record(streams[i])
-            engs[i].solve_batch_device(dbs[i])
-            e1.record(streams[i])
+        elapsed = 0.010 * args.steps * (1.0 + 0.25 * rank)  # faked: rank r is 25 r % slower
+        step_ms = [elapsed / args.steps * 1e3] * args.steps
         barrier()
-        t1 = time.perf_counter()
-        return t1 - t0, float(np.mean([a.elapsed_time(b) for a, b in evs]))
-
-    # warm-up: issued exactly like the timed steps (round-robin over the handles) and timed per launch as well, so that the mean over
-    # ALL launches of the process is available for comparison with rocprofv3's per-kernel average (which cannot tell warm-up from timed)
-    _, warm_kernel_ms = run(args.warmup, S) if args.warmup > 0 else (0.0, None)
-    elapsed, kernel_ms = run(args.steps, S)
-    kernel_ms_all = kernel_ms if warm_kernel_ms is None else (warm_kernel_ms * args.warmup + kernel_ms * args.steps) / (args.warmup + args.steps)
-    rank_time_max_over_mean = 1.0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        tsum = t.clone()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        rank_time_max_over_mean = float(t.item()) / (float(tsum.item()) / world)  # load imbalance between the shards (SURVEY §8e)
-        elapsed = float(t.item())
-    # the same K steps strictly one after the other on one stream (reported beside the headline, not as `value`)
-    serial_elapsed, serial_kernel_ms = run(args.steps, 1) if (S > 1 and args.serial_leg) else ((elapsed, kernel_ms) if S == 1 else (None, None))
-    if world > 1 and serial_elapsed is not None:
-        t = torch.tensor([serial_elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        serial_elapsed = float(t.item())
-    info = dbatch.info_numpy()
-    stats = torch.tensor([float(info["iters"].sum()), float((info["status"] != 1).sum()), float(info["iters"].max()),
-                          float(info["n_refactor"].sum())], dtype=torch.float64, device=dev)
-    if world > 1:
-        tot = stats.clone()
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        mx = stats.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        iters_sum_all, unsolved_all, iters_max, refac_all = float(tot[0]), float(tot[1]), float(mx[2]), float(tot[3])
+        form, N, keep = 0, N0, 4
     else:
-        iters_sum_all, unsolved_all, iters_max, refac_all = float(stats[0]), float(stats[1]), float(stats[2]), float(stats[3])
+        from path_optimizer_amd import binding
 
+        batch = synth.make_batch(cfg, B=hi - lo, first_path=lo)
+        form, N, keep = batch.formulation, batch.N, batch.keep
+        dbatch = binding.DeviceBatch(batch, device=dev)
+        S = max(1, args.streams)
+        engs, streams, dbs = [], [], []
+        for i in range(S):
+            e = binding.Engine(local_rank)
+            st = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream shared by torch events and the engine
+            e.set_stream(st.cuda_stream)
+            engs.append(e); streams.append(st)
+            dbs.append(dbatch if i == 0 else dbatch.clone_outputs())
+        if args.warmup > 0:
+            time_serial(torch, engs[0], streams[0], dbatch, args.warmup, barrier)
+        # ---- THE timed region: exactly K single-batch solves, one after the other on one stream, barrier + synchronize on both sides ----
+        elapsed, step_ms = time_serial(torch, engs[0], streams[0], dbatch, args.steps, barrier)
+
+    info = dbatch.info_numpy()
+    iters_sum_all, unsolved_all, iters_max, elapsed_max = reduce_stats(float(info["iters"].sum()), float((info["status"] != 1).sum()),
+                                                                       float(info["iters"].max()), elapsed, device=None if dry else dev)
+    elapsed_sum = elapsed
+    refac_all = float(info["n_refactor"].sum())
+    if world > 1:
+        t = torch.tensor([elapsed, refac_all], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed_sum, refac_all = float(t[0]), float(t[1])
+    rank_time_max_over_mean = elapsed_max / (elapsed_sum / world)  # load imbalance between the shards
+
+    gather = None
+    if world > 1 and args.gather:
+        # SURVEY §8e collective (1): a single consumer of the whole batch — [B/G][N][5] states + po_info per rank -> rank 0
+        info_t = torch.from_numpy(info.view(np.uint8).reshape(len(info), -1).copy()).to(dev) if dry else dbatch.out_info
+        barrier()
+        g0 = time.perf_counter()
+        all_states = gather_to_root(dbatch.out_states, world, rank)
+        all_info = gather_to_root(info_t, world, rank)
+        barrier()
+        g1 = time.perf_counter()
+        gather = {"ms": (g1 - g0) * 1e3, "bytes_per_rank": int(dbatch.out_states.numel() * 8 + info_t.numel())}
+        if rank == 0:
+            from path_optimizer_amd.abi import INFO_DTYPE
+
+            gi = all_info.cpu().numpy().view(INFO_DTYPE).reshape(-1)
+            gather["paths_on_root"] = int(all_states.shape[0])
+            gather["iters_sum_on_root"] = float(gi["iters"].sum())  # must equal the all-reduced sum
+            if dry:
+                gather["path_ids_in_order"] = bool((all_states[:, 0, 0].numpy() == np.arange(world * B)).all())
+
+    out = None
     if rank == 0:
-        N, keep, form = batch.N, batch.keep, batch.formulation
-        paths_per_s = world * B * args.steps / elapsed
-        abytes, b_iter = algorithmic_bytes(form, N, keep, float(info["iters"].sum()), B)
-        achieved = abytes / (kernel_ms * 1e-3) / 1e9  # GB/s, this rank's kernel (per-launch duration: launches of different streams overlap)
-        serial_achieved = None if serial_kernel_ms is None else abytes / (serial_kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        paths_per_s = world * B * args.steps / elapsed_max
+        it_rank = float(info["iters"].sum())
+        med_ms = float(np.median(step_ms))
+        abytes, b_iter = algorithmic_bytes(form, N, keep, it_rank, B)
+        valu = _load_json(os.path.join(ROOT, "profiles", "valu_latest.json")) or {}
+        fp64_per_it = valu.get("fp64_wave_instr_per_path_iter")
+        path_it_s = it_rank / (med_ms * 1e-3)
+        achieved_tf = None if fp64_per_it is None else path_it_s * fp64_per_it * 128.0 / 1e12
+        traffic = (_load_json(os.path.join(ROOT, "profiles", "traffic_latest.json")) or {}).get("hbm_bytes_per_launch")
         out = {
             "metric": "QP paths/sec at N=200 pts, batch=4096; ADMM iters to 1e-4",
             "value": paths_per_s,
@@ -312,97 +536,76 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": elapsed_max / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" + (" (DRY RUN: no GPU, faked device times)" if dry else ""),
             "config": {"workload": f"BASELINE config {cfg}: KP, B={B} paths/GPU x {world} GPU, N={N} points, "
-                                   "per-path random obstacle clearances, OSQP defaults (scaling 10, adaptive rho every 100 it) at eps_abs=eps_rel=1e-4",
+                                   "per-path random obstacle clearances, OSQP defaults (scaling 10, adaptive rho every 100 it) at eps_abs=eps_rel=1e-4; "
+                                   "one batch after the other on one stream",
                        "batch_per_gpu": B, "points": N, "formulation": "KP", "parallelism": f"batch-split x{world}",
-                       "rank_time_max_over_mean": rank_time_max_over_mean,
-                       "streams_per_gpu": S},
-            # the same K steps issued strictly serially on one stream (every step waits for the previous step's last straggler)
-            "serial": None if serial_elapsed is None else {
-                "value": world * B * args.steps / serial_elapsed, "ms_per_step": serial_elapsed / args.steps * 1e3,
-                "kernel_ms": serial_kernel_ms, "roofline_achieved": serial_achieved, "roofline_frac": serial_achieved / 8000.0},
+                       "rank_time_max_over_mean": rank_time_max_over_mean},
+            "single_batch": {"median_ms": med_ms, "min_ms": float(np.min(step_ms)), "max_ms": float(np.max(step_ms)), "paths_per_s": B / (med_ms * 1e-3),
+                             "note": "hipEvents on the engine's stream around each step (equilibration kernel + uniform-variant launch + general-variant launch), rank 0"},
             "admm": {"iters_mean": iters_sum_all / (world * B), "iters_max": iters_max, "unsolved": int(unsolved_all),
-                     "refactorisations": int(refac_all), "path_iters_per_s": iters_sum_all * args.steps / elapsed,
-                     # distribution on rank 0's shard
+                     "refactorisations": int(refac_all), "path_iters_per_s": iters_sum_all * args.steps / elapsed_max,
                      "iters_min": int(info["iters"].min()), "iters_median": float(np.median(info["iters"])),
                      "iters_p95": float(np.percentile(info["iters"], 95)),
                      "schedule": "termination check every 25 it, adaptive rho every 100 it (by iteration count), max_iter 4000"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "frac_of_measured_copy_ceiling": achieved / 6290.0,  # MI355X_MICROARCH.md: 6.29 TB/s measured copy
-                         "traffic": traffic, "kernel": "po::solve_kernel_fast<KP,SPL=4,NT=64,two-level,uniform-row-classes> (the general-variant launch that follows it only picks up deferred paths: none on this workload)", "kernel_ms": kernel_ms,
-                         "kernel_ms_all_launches": kernel_ms_all,  # warm-up launches included: the figure rocprofv3's per-kernel average corresponds to
-                         "algorithmic_bytes_per_path_iter": b_iter,
-                         "note": "algorithmic bytes of one solve call / that call's duration (hipEvents on its stream around the equilibration kernel, the uniform-variant "
-                                 "launch that does the work and the general-variant launch that follows it: rocprofv3 lists them separately); launches of the "
-                                 f"{S} streams overlap, so one launch's duration is longer than ms_per_step; the state is LDS-resident, so this is not HBM traffic",
-                         "aggregate_achieved": abytes * args.steps / elapsed / 1e9, "aggregate_frac": abytes * args.steps / elapsed / 1e9 / 8000.0,
-                         # the bound that actually limits the kernel: fp64 VALU issue, v_fma_f64 = 8 cycles per
-                         # wave-instruction measured (tools/ubench) -> 1024 SIMDs x 2.4 GHz x 64 lanes x 2 / 8 = 39.3 TFLOP/s
-                         "secondary": {"bound": "fp64_valu", "unit": "TFLOP/s", "peak": 39.3,
-                                       "achieved": float(info["iters"].sum()) * 1.0e5 * args.steps / elapsed / 1e12,
-                                       "note": "0.1 MFLOP per path-iteration (SURVEY.md §8a10)"}},
+            "roofline": {
+                "bound": "fp64_valu", "unit": "TFLOP/s", "peak": FP64_VALU_PEAK_TFLOPS,
+                "achieved": achieved_tf, "frac": None if achieved_tf is None else achieved_tf / FP64_VALU_PEAK_TFLOPS,
+                "achieved_def": "issued fp64 VALU wave-instructions x 128 flop (64 lanes x FMA) / single-batch time: fp64 wave-instructions per path-iteration "
+                                "from profiles/valu_latest.json (ISA histogram of the hot loop weighted by SQ_INSTS_VALU of the rocprofv3 PMC pass of this tree) "
+                                "x path-iterations/s measured in this run",
+                "peak_source": "MI355X fp64 vector peak = 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GHz (half the 157.3 TF fp32 vector peak in MI355X_MICROARCH.md)",
+                "fp64_wave_instr_per_path_iter": fp64_per_it, "valu_wave_instr_per_path_iter": valu.get("valu_wave_instr_per_path_iter"),
+                "occupancy_waves_per_simd": valu.get("occupancy_waves_per_simd"),
+                "frac_of_measured_issue_ceiling": None if achieved_tf is None else {k: achieved_tf / v for k, v in FP64_VALU_MEASURED_CEILING.items()},
+                "useful_flop_basis": {"achieved": path_it_s * 1.0e5 / 1e12, "note": "0.1 MFLOP per path-iteration (SURVEY.md §8a10)"},
+                "kernel": "po::solve_kernel_fast<KP,SPL=4,NT=64,two-level,uniform-row-classes>", "kernel_ms": med_ms,
+                "traffic": traffic,
+                "traffic_note": "HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from the rocprofv3 PMC passes committed under profiles/ (traffic_latest.json); "
+                                "not re-measured inside this run",
+                "algorithmic_hbm_equivalent": {"GB_per_s": abytes / (med_ms * 1e-3) / 1e9, "frac_of_8TBps": abytes / (med_ms * 1e-3) / 1e9 / 8000.0,
+                                               "algorithmic_bytes_per_path_iter": b_iter,
+                                               "note": "SURVEY.md §8d contract figure (8 (128N+13C+9) B per path-iteration + compulsory I/O); NOT a roofline: the state is "
+                                                       "LDS/register resident and never moves through HBM"}},
         }
-        if world == 1 and not args.no_stages:
-            out["stages"] = stage_legs(torch, binding, synth, engs[0], streams[0], dbatch, B, args.cpu_sample > 0)
-        if world == 1 and args.cpu_sample > 0:
-            from oracle import oracle_py  # CPU baseline leg only
+        if gather is not None:
+            out["gather"] = gather
 
-            ns = min(args.cpu_sample, B)
-            sample = batch.slice(0, ns)
-            oracle_py.solve_batch(sample.slice(0, 2), oracle_py.device_equivalent_params())  # warm the ordering cache
-            c0 = time.perf_counter()
-            _, oinfo, _ = oracle_py.solve_batch(sample, oracle_py.device_equivalent_params(), want_x=False)
-            c1 = time.perf_counter()
-            out["cpu_baseline"] = {"value": ns / (c1 - c0), "unit": "paths/s", "cores": 1, "kind": "port",
-                                   "sample": f"first {ns} paths of the same batch, oracle/libpo_oracle.so (OSQP-style ADMM, "
-                                             f"sparse LDL', gcc -O3), {c1 - c0:.1f} s, mean iters {float(oinfo['iters'].mean()):.1f}",
-                                   "host_cpus": os.cpu_count()}
-            # the reference's OWN solver classes (oracle/_ref/libpo_ref.so = src/solver/*.cpp compiled where they lie: dense-scratch
-            # setHessianMatrix / setConstraintMatrix + getOptimizedPath; OSQP itself stood in by the oracle's ADMM), when that library was built
-            try:
-                from oracle import ref_py
-
-                if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libpo_ref.so")):
-                    nr = min(384, ns)  # ~5 s
-                    rp = oracle_py.default_params()
-                    inst = lambda b_: dict(ref_x=batch.ref_x[b_], ref_y=batch.ref_y[b_], ref_z=batch.ref_z[b_], ref_k=batch.ref_k[b_], ref_s=batch.ref_s[b_],
-                                           bounds=batch.bounds[b_], x0=batch.x0[b_], goal_z=batch.goal_z[b_])
-                    ref_py.solve("KP", inst(0), rp)
-                    r0 = time.perf_counter()
-                    for b_ in range(nr):
-                        ref_py.solve("KP", inst(b_), rp)
-                    r1 = time.perf_counter()
-                    out["cpu_baseline_reference_code"] = {"value": nr / (r1 - r0), "unit": "paths/s", "cores": 1, "kind": "reference",
-                                                          "sample": f"first {nr} paths through the reference's OsqpSolver::create(\"KP\")->solve() compiled from its own sources "
-                                                                    f"(18.9 MB dense scratch per solve) with the oracle's ADMM in place of OSQP, {r1 - r0:.1f} s"}
-            except Exception as e:
-                out["cpu_baseline_reference_code"] = {"error": repr(e)}
-            # the same sample on every host core, one path slice per process (the reference itself is single-threaded)
-            try:
-                import multiprocessing as mp
-
-                nproc = max(1, min(os.cpu_count() or 1, 64))
-                nmt = min(B, 48 * nproc)  # ~48 paths per core
-                sample = batch.slice(0, nmt)
-                ns = nmt
-                parts = [(lo_, min(ns, lo_ + -(-ns // nproc))) for lo_ in range(0, ns, -(-ns // nproc))]
-                # spawn (not fork): the parent holds a live HIP context; workers import numpy + the oracle only
-                with mp.get_context("spawn").Pool(len(parts)) as pool:
-                    pool.map_async(_cpu_slice, [(sample.slice(a, a + 2), None) for a, _ in parts], chunksize=1).get(timeout=180)  # warm
-                    m0 = time.perf_counter()
-                    pool.map_async(_cpu_slice, [(sample.slice(a, b_), None) for a, b_ in parts], chunksize=1).get(timeout=180)
-                    m1 = time.perf_counter()
-                out["cpu_baseline_all_cores"] = {"value": ns / (m1 - m0), "unit": "paths/s", "cores": len(parts), "kind": "port",
-                                                 "sample": f"first {ns} paths of the batch split over {len(parts)} processes "
-                                                           f"(one oracle instance per host core, capped at 64), {m1 - m0:.2f} s"}
-            except Exception as e:  # never let the optional leg break the bench line
-                out["cpu_baseline_all_cores"] = {"error": repr(e)}
+    # ---- secondary GPU legs (rank 0, N = 1) ----
+    acc = None
+    if not dry and world == 1:
+        if args.streams > 1:
+            time_pipelined(torch, engs, streams, dbs, min(args.steps, 3), barrier)
+            pel, pms = time_pipelined(torch, engs, streams, dbs, args.steps, barrier)
+            out["pipelined_3_streams" if S == 3 else f"pipelined_{S}_streams"] = {
+                "paths_per_s": B * args.steps / pel, "ms_per_step": pel / args.steps * 1e3, "launch_ms_mean": float(np.mean(pms)),
+                "note": f"the same K steps issued round-robin on {S} handles/streams (independent batches overlap: the stragglers of one drain under the next); NOT `value`"}
+        if not args.no_configs:
+            out["configs"] = config_legs(torch, binding, synth, dev, streams[0])
+        if not args.no_parity:
+            acc = accuracy_legs(torch, binding, synth, batch, dev, streams[0], args.cpu_sample)
+            out["parity"] = {"accuracy": acc["settings"],
+                             "accuracy_note": "lateral offset e_y of the first 256 paths vs their exact optimum (tests/golden/tight_c3.npz: active-set solution, KKT residuals "
+                                              "<= 1e-13); north-star bar: RMS <= 1e-4 m"}
+            ok99 = [s for s in acc["settings"] if s.get("e_y_rms_vs_exact_optimum_m", {}).get("frac_le_1e-4", 0) >= 0.99]
+            out["parity"]["first_setting_with_99pct_within_1e-4_m"] = ok99[0]["setting"] if ok99 else None
+            out["parity"]["paths_per_s_at_that_setting"] = ok99[0]["paths_per_s"] if ok99 else None
+        stage_ctx = None
+        if not args.no_stages:
+            out["stages"], stage_ctx = stage_legs_gpu(torch, binding, synth, engs[0], streams[0], dbatch, B)
+        torch.cuda.synchronize()
+        out["gpu_done_s"] = time.time()  # everything after this timestamp is host-only (CPU baseline / checker legs)
+        if args.cpu_sample > 0:
+            cpu_legs(out, batch, acc, args.cpu_sample)
+            if stage_ctx is not None:
+                stage_legs_cpu(out["stages"], stage_ctx)
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

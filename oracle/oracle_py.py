@@ -34,6 +34,23 @@ def lib():
     return _LIB
 
 
+def use_native() -> bool:
+    """CPU-baseline timing only: switch this process to a `gcc -O3 -march=native` build of the same source, compiled on the box that
+    times it into oracle/_native/ (git-ignored).  Returns False (and keeps the portable build) when that build fails.
+    The portable build (no -march, no FMA contraction) stays the checker of the parity tests."""
+    global _LIB
+    so = os.path.join(_HERE, "_native", "libpo_oracle.so")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        L = C.CDLL(so)
+    except Exception:
+        return False
+    L.po_oracle_wrap_angle.restype = C.c_double
+    L.po_oracle_wrap_angle.argtypes = [C.c_double]
+    _LIB = L
+    return True
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 

@@ -23,3 +23,18 @@ def reduce_stats(iters_sum: float, unsolved: float, iters_max: float, elapsed: f
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     dist.all_reduce(m, op=dist.ReduceOp.MAX)
     return float(s[0]), float(s[1]), float(m[0]), float(m[1])
+
+
+def gather_to_root(t, world: int, rank: int):
+    """SURVEY.md §8e collective (1): every rank's [B/G, ...] block to rank 0 (torch.distributed gather = ncclGather-style point-to-point
+    sends under RCCL, plain gather under gloo), concatenated in rank order = global path order for the contiguous split.  Returns the
+    [B, ...] tensor on rank 0 and None elsewhere; identity when torch.distributed is not initialised."""
+    import torch
+    import torch.distributed as dist
+
+    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+        return t
+    t = t.contiguous()
+    parts = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+    dist.gather(t, parts, dst=0)
+    return torch.cat(parts, dim=0) if rank == 0 else None

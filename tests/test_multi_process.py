@@ -63,3 +63,29 @@ def test_two_rank_split_matches_single_process():
     assert np.array_equal(cat, xs)  # shards are bit-identical to the single-process solve: no cross-path coupling
     for g in got:
         assert g[4][0] == float(info["iters"].sum()) and g[4][2] == float(info["iters"].max()) and abs(g[4][3] - 0.2) < 1e-12
+
+
+def test_bench_n_gt_1_branch_dry_run():
+    """bench.py's N>1 branch end to end on CPU: `torch.distributed.run` with 2 ranks, gloo, --dry-run (device times faked, everything else
+    real: shard_range, the SUM / MAX reductions, the root gather of SURVEY §8e, the JSON line of rank 0)."""
+    import json
+    import subprocess
+
+    port = 29700 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "96", "--dry-run", "--gather"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout  # exactly one JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 4 and d["config"]["batch_per_gpu"] == 96
+    # faked device times: rank r takes 10 ms x steps x (1 + r/4) -> max over ranks = rank 1, imbalance = 1.25 / 1.125
+    assert abs(d["ms_per_step"] - 12.5) < 1e-9 and abs(d["value"] - 2 * 96 * 4 / 0.05) < 1e-6
+    assert abs(d["config"]["rank_time_max_over_mean"] - 1.25 / 1.125) < 1e-12
+    # statistics are functions of the GLOBAL path id: the reductions must reproduce the single-process figures
+    ids = np.arange(2 * 96)
+    it = 25 * (1 + (ids * 2654435761 % 61))
+    assert d["admm"]["iters_mean"] == it.mean() and d["admm"]["iters_max"] == it.max() and d["admm"]["refactorisations"] == int((it // 400).sum())
+    g = d["gather"]
+    assert g["paths_on_root"] == 192 and g["iters_sum_on_root"] == float(it.sum()) and g["path_ids_in_order"] is True
