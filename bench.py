@@ -132,8 +132,8 @@ def accuracy_legs(torch, binding, synth, batch, dev, stream, cpu_sample):
         finfo = full.info_numpy()
         row = {"setting": label, "ms": float(np.median(ms)), "paths_per_s": batch.B / (float(np.median(ms)) * 1e-3),
                "iters_mean": float(finfo["iters"].mean()), "iters_max": int(finfo["iters"].max()), "unsolved": int((finfo["status"] != 1).sum())}
-        if "reserved" in finfo.dtype.names:
-            row["polished"] = int((finfo["reserved"] == 1).sum())
+        row["polished"] = int((finfo["status_polish"] == 1).sum())
+        row["polish_unsuccessful"] = int((finfo["status_polish"] == -1).sum())
         if gold is not None:
             ng = min(len(gold), ns)
             rms = np.sqrt(np.mean((x[:ng, 0:3 * N:3] - gold[:ng]) ** 2, axis=1))

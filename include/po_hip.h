@@ -43,6 +43,7 @@ enum {
     PO_STATUS_MAX_ITER          = -2,
     PO_STATUS_PRIMAL_INFEASIBLE = -3,
     PO_STATUS_DUAL_INFEASIBLE   = -4,
+    PO_STATUS_NON_FINITE        = -8, /* not an OSQP value: a NaN / Inf appeared in the iterate (non-finite inputs); never reported as solved */
     PO_STATUS_UNSOLVED          = -10
 };
 
@@ -102,14 +103,20 @@ typedef struct po_params {
     int    smoothing_method;            /* FLAGS_smoothing_method: PO_SMOOTH_TENSION2 (default "TENSION2") or PO_SMOOTH_TENSION ("TENSION") */
     int    optimization_method;         /* FLAGS_optimization_method: PO_KP (default "KP"), PO_K ("K") or PO_KPC */
     int    enable_exact_position;       /* FLAGS_enable_exact_position (false): goal-trim search step 0.1 m instead of 0.5 m (path_optimizer.cpp:151) */
-    int    reserved1;
+    int    polish;                      /* OSQP `polish` (0 = off: OSQP's default, which the reference never changes).  1: after a path is solved, the reduced
+                                           KKT system on the active set is solved with the regularisation `polish_delta` and `polish_refine_iter` steps of
+                                           iterative refinement (OSQP polish.c); the result replaces the ADMM solution when OSQP's acceptance rule holds */
+    double polish_delta;                /* OSQP `delta` (1e-6) */
+    int    polish_refine_iter;          /* OSQP `polish_refine_iter` (3) */
+    int    polish_passes;               /* 1 = OSQP's polish.  > 1 (extension): the active set is re-derived from the polished point and the solve repeated, up
+                                           to this many times, until it reproduces itself (then the point satisfies the KKT conditions exactly) */
 } po_params;
 
 typedef struct po_info {
     int    status;      /* PO_STATUS_*                                  */
     int    iters;       /* ADMM iterations run                          */
     int    n_refactor;  /* numeric refactorisations after the first     */
-    int    reserved;
+    int    status_polish; /* OSQP info.status_polish: 0 not attempted, 1 polished solution adopted, -1 polish unsuccessful (ADMM solution kept) */
     double r_prim;      /* ||Ax - z||_inf   at exit (unscaled)          */
     double r_dual;      /* ||Px + q + A'y||_inf at exit                 */
     double rho;         /* final rho                                    */

@@ -78,6 +78,7 @@ void po_oracle_default_params(po_params *p) {
     p->mu = 0.4; p->max_curvature_rate = 0.1; p->search_lateral_range = 10.0; p->search_long_spacing = 1.5; p->search_lat_spacing = 0.6;
     p->enable_dynamic_segmentation = 1;
     p->enable_raw_output = 1; p->output_spacing = 0.3; /* planning_flags.cpp:127-129 */
+    p->polish = 0; p->polish_delta = 1e-6; p->polish_refine_iter = 3; p->polish_passes = 1; /* OSQP defaults (polish off) */
 }
 
 /* tools.hpp:24-35 — recursive in the reference; same fixed point as this loop */
@@ -1145,6 +1146,107 @@ int po_oracle_qp_solve_ext(int n, int m, const int *Pp0, const int *Pi0, const d
     info->r_prim = pri_res;
     info->r_dual = dua_res;
     info->rho = rho;
+    /* ---- polish (OSQP polish.c, on the scaled problem like OSQP): reduced KKT system on the active set with the regularisation
+     * +-delta, polish_refine_iter steps of iterative refinement, normal-cone projection, OSQP's acceptance rule.  polish_passes > 1
+     * (extension, not OSQP): the active set is re-derived from the polished point and the solve repeated until it reproduces itself. ---- */
+    if (prm->polish && info->status == PO_STATUS_SOLVED) {
+        const double delta = prm->polish_delta;
+        const int passes = prm->polish_passes > 1 ? prm->polish_passes : 1;
+        int *act = (int *)malloc(sizeof(int) * (size_t)(m + 1)), *act_new = (int *)malloc(sizeof(int) * (size_t)(m + 1));
+        int *ridx = (int *)malloc(sizeof(int) * (size_t)(m + 1));
+        int *Rp = (int *)malloc(sizeof(int) * (size_t)(n + 1)), *Ri = (int *)malloc(sizeof(int) * (size_t)(anz + 1));
+        double *Rx = (double *)malloc(sizeof(double) * (size_t)(anz + 1));
+        double *px = (double *)malloc(sizeof(double) * (size_t)n), *py = (double *)calloc((size_t)(m + 1), sizeof(double)), *pz = (double *)malloc(sizeof(double) * (size_t)(m + 1));
+        double *sol = (double *)malloc(sizeof(double) * (size_t)(n + m)), *res = (double *)malloc(sizeof(double) * (size_t)(n + m));
+        double *bred = (double *)malloc(sizeof(double) * (size_t)(m + 1)), *dlt = (double *)malloc(sizeof(double) * (size_t)(m + 1));
+        int *prm2 = (int *)malloc(sizeof(int) * (size_t)(n + m)), *pin2 = (int *)malloc(sizeof(int) * (size_t)(n + m));
+        int adopted = 0, self_consistent = 0;
+        double pol_pri = 0, pol_dua = 0;
+        /* form_Ared: 1 = active at the lower bound, 2 = at the upper bound */
+        for (int i = 0; i < m; ++i) act[i] = (z[i] - l[i] < -y[i]) ? 1 : ((u[i] - z[i] < y[i]) ? 2 : 0);
+        for (int pass = 0; pass < passes; ++pass) {
+            int mred = 0;
+            for (int i = 0; i < m; ++i) {
+                ridx[i] = act[i] ? mred : -1;
+                if (act[i]) { bred[mred] = act[i] == 1 ? l[i] : u[i]; dlt[mred] = delta; ++mred; }
+            }
+            int rz = 0;
+            for (int c = 0; c < n; ++c) {
+                Rp[c] = rz;
+                for (int k = Ap0[c]; k < Ap0[c + 1]; ++k)
+                    if (ridx[Ai0[k]] >= 0) { Ri[rz] = ridx[Ai0[k]]; Rx[rz] = Ax[k]; ++rz; }
+            }
+            Rp[n] = rz;
+            kkt_t K0, K2;
+            ldl_t F2;
+            memset(&K0, 0, sizeof(K0)); memset(&K2, 0, sizeof(K2)); memset(&F2, 0, sizeof(F2));
+            const int nk2 = n + mred;
+            int bad = kkt_build(&K0, n, mred, Pp0, Pi0, Px, Rp, Ri, Rx, delta, dlt, NULL) || min_degree_order(K0.nk, K0.Kp, K0.Ki, prm2);
+            kkt_free(&K0);
+            if (!bad) {
+                for (int i = 0; i < nk2; ++i) pin2[prm2[i]] = i;
+                bad = kkt_build(&K2, n, mred, Pp0, Pi0, Px, Rp, Ri, Rx, delta, dlt, prm2) || ldl_symbolic(&F2, K2.nk, K2.Kp, K2.Ki) || ldl_numeric(&F2, K2.Kp, K2.Ki, K2.Kx);
+            }
+            if (bad) { ldl_free(&F2); kkt_free(&K2); break; }
+            /* (K + dK) sol = [-q; b], then sol += (K + dK)^-1 ([-q; b] - K sol), polish_refine_iter times */
+            for (int i = 0; i < n; ++i) res[pin2[i]] = -q[i];
+            for (int i = 0; i < mred; ++i) res[pin2[n + i]] = bred[i];
+            ldl_solve(&F2, res);
+            for (int i = 0; i < nk2; ++i) sol[i] = res[pin2[i]];
+            for (int it = 0; it < prm->polish_refine_iter; ++it) {
+                sym_mv(n, Pp0, Pi0, Px, sol, tn);            /* P x */
+                csc_mtv(n, Rp, Ri, Rx, sol + n, tn2);        /* Ared' y */
+                for (int i = 0; i < mred; ++i) tm[i] = 0;
+                csc_mv(n, mred, Rp, Ri, Rx, sol, tm);        /* Ared x */
+                for (int i = 0; i < n; ++i) res[pin2[i]] = -q[i] - tn[i] - tn2[i];
+                for (int i = 0; i < mred; ++i) res[pin2[n + i]] = bred[i] - tm[i];
+                ldl_solve(&F2, res);
+                for (int i = 0; i < nk2; ++i) sol[i] += res[pin2[i]];
+            }
+            ldl_free(&F2); kkt_free(&K2);
+            for (int i = 0; i < n; ++i) px[i] = sol[i];
+            for (int i = 0; i < m; ++i) py[i] = ridx[i] >= 0 ? sol[n + ridx[i]] : 0.0;
+            for (int i = 0; i < m; ++i) pz[i] = 0;
+            csc_mv(n, m, Ap0, Ai0, Ax, px, pz);              /* z = A x */
+            /* the active set this point implies */
+            int changes = 0;
+            for (int i = 0; i < m; ++i) {
+                act_new[i] = (pz[i] - l[i] < -py[i]) ? 1 : ((u[i] - pz[i] < py[i]) ? 2 : 0);
+                if (u[i] - l[i] < OSQP_RHO_TOL && act_new[i]) act_new[i] = act[i] ? act[i] : act_new[i]; /* equalities: either label is the same row */
+                changes += act_new[i] != act[i];
+            }
+            /* project_normalcone + residuals of the polished point (unscaled, like update_info with scaled_termination = 0) */
+            memcpy(Axv, pz, sizeof(double) * (size_t)m);
+            for (int i = 0; i < m; ++i) {
+                const double t = pz[i] + py[i];
+                pz[i] = t < l[i] ? l[i] : (t > u[i] ? u[i] : t);
+                py[i] = t - pz[i];
+                tm[i] = Axv[i] - pz[i];
+            }
+            sym_mv(n, Pp0, Pi0, Px, px, Pxv);
+            csc_mtv(n, Ap0, Ai0, Ax, py, Aty);
+            for (int i = 0; i < n; ++i) tn[i] = Pxv[i] + q[i] + Aty[i];
+            pol_pri = vnorm_inf_scaled(Einv, tm, m);
+            pol_dua = cinv * vnorm_inf_scaled(Dinv, tn, n);
+            if (changes == 0) { self_consistent = 1; break; }
+            if (pass + 1 < passes) memcpy(act, act_new, sizeof(int) * (size_t)m);
+        }
+        /* polish_successful (polish.c) — or, with the extension, a self-consistent active set whose point is feasible to round-off */
+        adopted = (pol_pri < pri_res && pol_dua < dua_res) || (pol_pri < pri_res && dua_res < 1e-10) || (pol_dua < dua_res && pri_res < 1e-10);
+        (void)self_consistent;
+        if (adopted) {
+            memcpy(x, px, sizeof(double) * (size_t)n);
+            memcpy(y, py, sizeof(double) * (size_t)m);
+            memcpy(z, pz, sizeof(double) * (size_t)m);
+            info->r_prim = pol_pri;
+            info->r_dual = pol_dua;
+            info->status_polish = 1;
+        } else {
+            info->status_polish = -1;
+        }
+        free(act); free(act_new); free(ridx); free(Rp); free(Ri); free(Rx); free(px); free(py); free(pz); free(sol); free(res); free(bred); free(dlt);
+        free(prm2); free(pin2);
+    }
     /* unscale solution */
     for (int i = 0; i < n; ++i) x[i] *= D[i];
     for (int i = 0; i < m; ++i) {

@@ -5,6 +5,7 @@ PO_KP, PO_KPC, PO_K = 0, 1, 2
 PO_OK, PO_ERR_INVALID, PO_ERR_HIP, PO_ERR_UNSUPPORTED, PO_ERR_NOMEM = 0, -1, -2, -3, -4
 PO_STATUS_SOLVED, PO_STATUS_MAX_ITER = 1, -2
 PO_STATUS_PRIMAL_INFEASIBLE, PO_STATUS_DUAL_INFEASIBLE, PO_STATUS_UNSOLVED = -3, -4, -10
+PO_STATUS_NON_FINITE = -8
 FORM_BY_NAME = {"KP": PO_KP, "KPC": PO_KPC, "K": PO_K}  # OsqpSolver::create strings (solver.cpp:34-38)
 
 _dp = C.POINTER(C.c_double)
@@ -25,7 +26,8 @@ class PoParams(C.Structure):
         ("t2_w_dev", C.c_double), ("t2_w_curv", C.c_double), ("t2_w_curv_rate", C.c_double),
         ("cart_w_curv", C.c_double), ("cart_w_curv_rate", C.c_double), ("cart_w_dev", C.c_double),
         ("mu", C.c_double), ("max_curvature_rate", C.c_double), ("search_lateral_range", C.c_double),
-        ("search_long_spacing", C.c_double), ("search_lat_spacing", C.c_double), ("enable_dynamic_segmentation", C.c_int), ("enable_raw_output", C.c_int), ("output_spacing", C.c_double), ("smoothing_method", C.c_int), ("optimization_method", C.c_int), ("enable_exact_position", C.c_int), ("reserved1", C.c_int),
+        ("search_long_spacing", C.c_double), ("search_lat_spacing", C.c_double), ("enable_dynamic_segmentation", C.c_int), ("enable_raw_output", C.c_int), ("output_spacing", C.c_double), ("smoothing_method", C.c_int), ("optimization_method", C.c_int), ("enable_exact_position", C.c_int), ("polish", C.c_int),
+        ("polish_delta", C.c_double), ("polish_refine_iter", C.c_int), ("polish_passes", C.c_int),
     ]
 
 
@@ -35,7 +37,7 @@ class PoMap(C.Structure):
 
 
 class PoInfo(C.Structure):
-    _fields_ = [("status", C.c_int), ("iters", C.c_int), ("n_refactor", C.c_int), ("reserved", C.c_int),
+    _fields_ = [("status", C.c_int), ("iters", C.c_int), ("n_refactor", C.c_int), ("status_polish", C.c_int),
                 ("r_prim", C.c_double), ("r_dual", C.c_double), ("rho", C.c_double), ("obj", C.c_double)]
 
 
@@ -50,7 +52,7 @@ class PoBatchOut(C.Structure):
     _fields_ = [("states", C.c_void_p), ("info", C.c_void_p), ("x", C.c_void_p)]
 
 
-INFO_DTYPE = [("status", "<i4"), ("iters", "<i4"), ("n_refactor", "<i4"), ("reserved", "<i4"),
+INFO_DTYPE = [("status", "<i4"), ("iters", "<i4"), ("n_refactor", "<i4"), ("status_polish", "<i4"),
               ("r_prim", "<f8"), ("r_dual", "<f8"), ("rho", "<f8"), ("obj", "<f8")]
 
 

@@ -18,6 +18,8 @@
 #include "po_smooth.hpp"
 
 extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out);
+extern "C" hipError_t po_launch_polish(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
+extern "C" int po_polish_state_doubles(int form, int N, int C, int keep);
 extern "C" hipError_t po_launch_scale(int form, const po::DevBatch *in, const po::DevParams *P, int passes, double *sc, hipStream_t st);
 extern "C" hipError_t po_launch_assemble(int form, const po::DevBatch *in, const po::DevParams *P, double *l, double *u, double *dyn, hipStream_t st);
 extern "C" size_t po_lds_bytes(int form, int N, int C, int keep);
@@ -74,6 +76,7 @@ struct po_handle_s {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    DevBuf pol_buf;  // per-lane ADMM state handed from the solve kernels to the polish kernel (po_params.polish)
     DevBuf in_buf, out_buf, asm_buf, scale_buf, dbg_buf, map_buf, post_buf, coef_buf, bnd_buf, smooth_buf, smooth_io, plan_coef, plan_io, plan_arena, plan_host;
     po::DevMap map{};  // obstacle-distance layer (po_set_map); map.d == nullptr until set
     std::mutex mu;
@@ -111,6 +114,7 @@ void po_default_params(po_params *p) {
     p->mu = 0.4; p->max_curvature_rate = 0.1; p->search_lateral_range = 10.0; p->search_long_spacing = 1.5; p->search_lat_spacing = 0.6;
     p->enable_dynamic_segmentation = 1;
     p->enable_raw_output = 1; p->output_spacing = 0.3; /* planning_flags.cpp:127-129 */
+    p->polish = 0; p->polish_delta = 1e-6; p->polish_refine_iter = 3; p->polish_passes = 1;  /* OSQP defaults (polish off) */
 }
 
 int po_problem_dims(int form, int N, int keep, int *n, int *m, int *C) {
@@ -170,6 +174,7 @@ int po_destroy(po_handle h) {
     if (!h) return PO_ERR_INVALID;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    h->pol_buf.release();
     h->in_buf.release(); h->out_buf.release(); h->asm_buf.release(); h->scale_buf.release(); h->dbg_buf.release(); h->map_buf.release(); h->post_buf.release(); h->coef_buf.release(); h->bnd_buf.release(); h->smooth_buf.release(); h->smooth_io.release(); h->plan_coef.release(); h->plan_io.release(); h->plan_arena.release(); h->plan_host.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -204,6 +209,8 @@ static int make_dev_params(const po_handle_s *h, int form, int keep, po::DevPara
     D->eps_pinf = p.eps_prim_inf; D->adapt_tol = p.adapt_tol;
     D->max_iter = p.max_iter; D->check_every = p.check_every; D->adapt_every = p.adapt_every;
     D->end_heading = p.constraint_end_heading;
+    D->polish = p.polish; D->pol_delta = p.polish_delta > 0 ? p.polish_delta : 1e-6; D->pol_refine = p.polish_refine_iter < 0 ? 0 : p.polish_refine_iter;
+    D->pol_passes = p.polish_passes;
     return PO_OK;
 }
 
@@ -232,6 +239,7 @@ static void fill_dev_batch(po::DevBatch *D, const po_batch_in *in, const po_batc
     if (!std::getenv("PO_IDENTITY_ORDER") && in->B > 8)
         while ((1 << D->perm_bits) < in->B) ++D->perm_bits;
     D->scale = nullptr;
+    D->pol_state = nullptr; D->pol_stride = 0;
     D->n = n; D->m = m;
 }
 
@@ -254,10 +262,21 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     }
     if ((rc = h->scale_buf.ensure(sizeof(double) * 64 * (size_t)in->B))) return rc;
     D.scale = static_cast<double *>(h->scale_buf.p);
+    bool polish = false;
+    if (h->params.polish) {  // OSQP's polish, opt-in: the solve kernels leave their ADMM state in pol_buf, polish_kernel picks it up
+        const int sd = po_polish_state_doubles(in->formulation, in->N, C, in->keep);
+        if (sd > 0) {  // (shapes on the single-level mapping have no polish kernel: status_polish stays 0 = not attempted)
+            if ((rc = h->pol_buf.ensure(sizeof(double) * (size_t)sd * (size_t)in->B))) return rc;
+            D.pol_state = static_cast<double *>(h->pol_buf.p);
+            D.pol_stride = sd;
+            polish = true;
+        }
+    }
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     // per-path equilibration (h->params.scaling class-level Ruiz passes; 0 -> identity), then the fused solve
     HIP_TRY(po_launch_scale(in->formulation, &D, &P, h->params.scaling, static_cast<double *>(h->scale_buf.p), h->stream));
     HIP_TRY(po_launch_solve(in->formulation, &D, &P, h->stream, nullptr));
+    if (polish) HIP_TRY(po_launch_polish(in->formulation, &D, &P, h->stream));
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     if (dbg) {

@@ -32,6 +32,8 @@ struct DevParams {
     double margin, kmax, max_steer, wheel_base;
     double sigma, alpha, rho0, eps_abs, eps_rel, eps_pinf, adapt_tol;
     int max_iter, check_every, adapt_every, end_heading;
+    double pol_delta;           // OSQP delta
+    int polish, pol_refine, pol_passes;
 };
 
 struct DevBatch {
@@ -47,6 +49,8 @@ struct DevBatch {
     int perm_bits;          // block -> path permutation: ceil(log2 B) bits of mixing (0 = blockIdx order), see solve_kernel_fast
     int only_deferred;      // set by the launcher for the second (general) launch of the two-level mapping: solve only the paths the first one deferred
     int n, m;
+    double *pol_state;      // polish only: [B][pol_stride] per-lane ADMM state left by the solve kernels for polish_kernel (or nullptr)
+    int pol_stride;
 };
 
 template <int F> struct FormTraits;

@@ -69,6 +69,22 @@ extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po
     return e != hipSuccess ? e : po_launch_solve_k(in, P, st, lds_out);
 }
 
+#define PO_DECLP(name) extern "C" hipError_t name(const po::DevBatch *in, const po::DevParams *P, hipStream_t st)
+PO_DECLP(po_launch_polish_kp); PO_DECLP(po_launch_polish_kpc); PO_DECLP(po_launch_polish_k);
+#undef PO_DECLP
+extern "C" int po_polish_state_doubles_kp(int N, int C, int keep);
+extern "C" int po_polish_state_doubles_kpc(int N, int C, int keep);
+extern "C" int po_polish_state_doubles_k(int N, int C, int keep);
+// OSQP's polish (po_params.polish) on the paths the two solve launches reported solved; same stream, after them
+extern "C" hipError_t po_launch_polish(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st) {
+    using namespace po;
+    return form == F_KP ? po_launch_polish_kp(in, P, st) : (form == F_KPC ? po_launch_polish_kpc(in, P, st) : po_launch_polish_k(in, P, st));
+}
+extern "C" int po_polish_state_doubles(int form, int N, int C, int keep) {
+    using namespace po;
+    return form == F_KP ? po_polish_state_doubles_kp(N, C, keep) : (form == F_KPC ? po_polish_state_doubles_kpc(N, C, keep) : po_polish_state_doubles_k(N, form == F_K ? 0 : C, keep));
+}
+
 extern "C" hipError_t po_launch_scale(int form, const po::DevBatch *in, const po::DevParams *P, int passes, double *sc, hipStream_t st) {
     using namespace po;
     const int bs = 64, gs = (in->B + bs - 1) / bs;

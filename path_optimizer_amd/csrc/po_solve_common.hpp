@@ -82,7 +82,7 @@ __device__ __forceinline__ void inv3_sym(const double g[6], double gi[6]) {
 }
 
 
-struct Resid { double rp, rd, nAx, nz, nPx, nAty, rps, rds, nAxs, nzs, nPxs, nAtys, obj; };  // obj = 0.5 x'Px (q = 0)
+struct Resid { double rp, rd, nAx, nz, nPx, nAty, rps, rds, nAxs, nzs, nPxs, nAtys, obj; int bad; };  // obj = 0.5 x'Px (q = 0)
 
 
 #include "po_fast.inc"
@@ -175,6 +175,44 @@ template <int F, bool UNI> hipError_t launch_form(const DevBatch *in_, const Dev
     return hipErrorInvalidValue;
 #endif
 #undef PO_L
+}
+// ---- polish (po_params.polish): same shape as the solve launch; two-level shapes only (every case the reference produces) ----
+template <int F, int SPL_, int NT_> inline int state_doubles_of() { return Fast<F, SPL_, NT_, true>::kStateDoubles * NT_; }
+#define PO_POLISH_SHAPES(X)                                                                          \
+    if constexpr (F == F_KP) {                                                                       \
+        if (s.spl == 1 && s.nt == 64) X(1, 64); if (s.spl == 1 && s.nt == 128) X(1, 128); if (s.spl == 1) X(1, 256); \
+        if (s.spl == 5) X(5, 64); if (s.spl == 6) X(6, 64); if (s.spl == 7) X(7, 64); if (s.spl == 8) X(8, 64);       \
+    }                                                                                                \
+    if (s.spl == 2 && s.nt == 64) X(2, 64); if (s.spl == 2) X(2, 128);                               \
+    if (s.spl == 3 && s.nt == 64) X(3, 64); if (s.spl == 3) X(3, 128);                               \
+    if (s.nt == 64) X(4, 64); X(4, 128);
+// doubles per path of the state block the solve kernels leave for the polish (0: shape without a polish kernel)
+template <int F> inline int polish_state_doubles(int N, int C, int keep) {
+    Shape s;
+    if (!resolve_shape(F, N, C, keep, &s) || !s.two) return 0;
+#ifdef PO_DEV_HEADLINE
+    return (s.spl == 4 && s.nt == 64) ? state_doubles_of<F, 4, 64>() : 0;
+#else
+#define PO_X(SPL_, NT_) return state_doubles_of<F, SPL_, NT_>()
+    PO_POLISH_SHAPES(PO_X)
+#undef PO_X
+    return 0;
+#endif
+}
+template <int F> hipError_t launch_polish(const DevBatch *in, const DevParams *P, hipStream_t st) {
+    Shape s;
+    if (!resolve_shape(F, in->N, in->C, in->keep, &s) || !s.two) return hipErrorInvalidValue;
+    const size_t lds = lds_bytes_fast<F>(in->N, in->C, s.spl, s.two, s.nt);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+#ifdef PO_DEV_HEADLINE
+    if (s.spl == 4 && s.nt == 64) return launch1(&polish_kernel<F, 4, 64>, in, P, 64, lds, st);
+    return hipErrorInvalidValue;
+#else
+#define PO_X(SPL_, NT_) return launch1(&polish_kernel<F, SPL_, NT_>, in, P, NT_, lds, st)
+    PO_POLISH_SHAPES(PO_X)
+#undef PO_X
+    return hipErrorInvalidValue;
+#endif
 }
 }  // namespace po
 

@@ -23,3 +23,18 @@
 extern "C" hipError_t PO_ENTRY(const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out) {
     return po::launch_form<PO_FORM, PO_UNI != 0>(in, P, st, lds_out);
 }
+
+#if !PO_UNI  // the polish kernels of this formulation build with the general-variant object
+#if PO_FORM == 0
+#define PO_POLISH_ENTRY po_launch_polish_kp
+#define PO_POLISH_SIZE po_polish_state_doubles_kp
+#elif PO_FORM == 1
+#define PO_POLISH_ENTRY po_launch_polish_kpc
+#define PO_POLISH_SIZE po_polish_state_doubles_kpc
+#else
+#define PO_POLISH_ENTRY po_launch_polish_k
+#define PO_POLISH_SIZE po_polish_state_doubles_k
+#endif
+extern "C" hipError_t PO_POLISH_ENTRY(const po::DevBatch *in, const po::DevParams *P, hipStream_t st) { return po::launch_polish<PO_FORM>(in, P, st); }
+extern "C" int PO_POLISH_SIZE(int N, int C, int keep) { return po::polish_state_doubles<PO_FORM>(N, C, keep); }
+#endif
