@@ -97,6 +97,29 @@ def config_legs(torch, binding, synth, dev, stream, steps=3):
                      "ms": med, "paths_per_s": b.B / (med * 1e-3), "path_iters_per_s": float(info["iters"].sum()) / (med * 1e-3),
                      "iters_mean": float(info["iters"].mean()), "iters_max": int(info["iters"].max()), "unsolved": int((info["status"] != 1).sum())}
         eng.close()
+    # BASELINE config 1 as the reference itself runs it: its REAL benchmark scene (src/test/path_optimizer_benchmark.cpp; map / way points / reference outputs
+    # in tests/golden/benchmark_scene.npz).  Single planning instance: a latency figure, B = 1 fills one CU of 256.
+    gpath = os.path.join(ROOT, "tests", "golden", "benchmark_scene.npz")
+    if os.path.exists(gpath):
+        g = np.load(gpath)
+        rows = {}
+        for tag, eps in (("eps_1e-3_reference_default", 1e-3), ("eps_1e-4", 1e-4)):
+            p = binding.default_params(); p.eps_abs = p.eps_rel = eps
+            eng = binding.Engine(torch.cuda.current_device(), p)
+            eng.set_map(g["distance"], float(g["resolution"]), float(g["pos"][0]), float(g["pos"][1]))
+            args = (g["way_x"][None], g["way_y"][None], g["start"][None], g["goal"][None])
+            states, n, ok, stage, info = eng.plan_batch(*args, N=512)
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter(); eng.plan_batch(*args, N=512); ts.append((time.perf_counter() - t0) * 1e3)
+            ref = g["path1_e3" if eps == 1e-3 else "path1_e4"]
+            rows[tag] = {"solve_ms_host_to_host": float(np.median(ts)), "ok": int(ok[0]), "states": int(n[0]), "qp_iters": int(info["iters"][0]),
+                         "max_abs_diff_vs_reference_compiled_PathOptimizer": float(np.abs(states[0, :n[0]] - ref).max()) if n[0] == len(ref) else None}
+            eng.close()
+        out["c1_real_scene"] = {"workload": "the reference's benchmark scene: obstacles_for_benchmark.png (495 x 497 cells at 0.2 m), 100 way points, PathOptimizer::solve "
+                                            "(bSpline -> TENSION2 QP -> DP search -> post QP -> re-sampling -> bounds -> KP QP, 132 states -> collision check), B = 1, "
+                                            "host pointers in and out (po_plan_batch)", **rows,
+                                "reference_note": "the reference-compiled PathOptimizer (test build, -O0, OSQP stood in by the oracle's ADMM) takes ~44 ms for the same call"}
     return out
 
 

@@ -253,3 +253,21 @@ def path_optimizer_solve_without_smoothing(m_map, params, ref, ks, kx, ky, start
     ok = lib_smooth().po_ref_path_optimizer_solve_without_smoothing(C.byref(m_map), len(rx), _p(rx), _p(ry), _p(rz), _p(rk), _p(rs), len(ks), _p(ks), _p(kx), _p(ky),
                                                                     _p(start), _p(goal), C.byref(params), cap, _p(path), C.byref(n))
     return ok, path[:n.value]
+
+
+def benchmark_scene(m_map, params, px, py, start, goal, cap=4096, kcap=4096):
+    """The reference's benchmark on one PathOptimizer object: solve(points) then solveWithoutSmoothing(result) (path_optimizer_benchmark.cpp).
+    Returns dict(ok1, ok2, path1, path2, knot_s, knot_x, knot_y, max_s, qp1, qp2) — qp* = po_info of the path QP of each call."""
+    from path_optimizer_amd.abi import PoInfo
+
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    px, py, start, goal = map(f, (px, py, start, goal))
+    p1 = np.zeros((cap, 5)); p2 = np.zeros((cap, 5)); n1 = C.c_int(0); n2 = C.c_int(0)
+    ks = np.zeros(kcap); kx = np.zeros(kcap); ky = np.zeros(kcap); K = C.c_int(0); max_s = C.c_double(0)
+    q1, q2 = PoInfo(), PoInfo()
+    rc = lib_smooth().po_ref_benchmark(C.byref(m_map), len(px), _p(px), _p(py), _p(start), _p(goal), C.byref(params), cap, _p(p1), C.byref(n1), _p(p2), C.byref(n2),
+                                      kcap, _p(ks), _p(kx), _p(ky), C.byref(K), C.byref(max_s), C.byref(q1), C.byref(q2))
+    g = lambda q: {k: getattr(q, k) for k, _ in PoInfo._fields_}
+    k = K.value
+    return dict(ok1=bool(rc & 1), ok2=bool(rc & 2), path1=p1[:n1.value], path2=p2[:n2.value], knot_s=ks[:k], knot_x=kx[:k], knot_y=ky[:k], max_s=max_s.value,
+                qp1=g(q1), qp2=g(q2))

@@ -14,6 +14,7 @@
 #define protected public
 #include "path_optimizer/reference_path_smoother/tension_smoother_2.hpp"
 #include "path_optimizer/path_optimizer.hpp"
+#include "path_optimizer/tools/spline.h"
 #undef private
 #undef protected
 #include "OsqpEigen/OsqpEigen.h"
@@ -247,6 +248,38 @@ int po_ref_path_optimizer_solve_without_smoothing(const po_map *m, int N, const 
     *n_path = (int)result.size();
     for (size_t i = 0; i < result.size() && (int)i < cap; ++i) { path[5 * i] = result[i].x; path[5 * i + 1] = result[i].y; path[5 * i + 2] = result[i].z; path[5 * i + 3] = result[i].k; path[5 * i + 4] = result[i].s; }
     return ok ? 1 : 0;
+}
+
+// The reference's own benchmark, src/test/path_optimizer_benchmark.cpp: BM_optimizePath = PathOptimizer(start, goal, map).solve(points, &path1)
+// (:84-100) and BM_optimizePathWithoutSmoothing = solveWithoutSmoothing(path1, &path2) ON THE SAME OBJECT (:153-158: it reads the spline the first
+// solve left in reference_path_).  Also returns that spline's knots and length, and the iteration count / status of the path QP of each call.
+// Return value: bit 0 = solve() returned true, bit 1 = solveWithoutSmoothing() returned true.
+int po_ref_benchmark(const po_map *m, int n_pts, const double *px, const double *py, const double *start /*x,y,z,k*/, const double *goal /*x,y,z*/,
+                     const po_params *admm, int cap, double *path1, int *n1, double *path2, int *n2, int kcap, double *ks, double *kx, double *ky, int *K,
+                     double *max_s, po_info *qp1, po_info *qp2) {
+    using namespace PathOptimizationNS;
+    updateConfig();
+    OsqpEigen::g_params = *admm;
+    grid_map::GridMap gm(*m);
+    State st(start[0], start[1], start[2], start[3]), en(goal[0], goal[1], goal[2]);
+    PathOptimizer opt(st, en, gm);
+    std::vector<State> pts, r1, r2;
+    for (int i = 0; i < n_pts; ++i) pts.emplace_back(px[i], py[i]);
+    const bool ok1 = opt.solve(pts, &r1);
+    *qp1 = OsqpEigen::g_cap.info;
+    auto put = [cap](const std::vector<State> &r, double *path, int *n) {
+        *n = (int)r.size();
+        for (size_t i = 0; i < r.size() && (int)i < cap; ++i) { path[5 * i] = r[i].x; path[5 * i + 1] = r[i].y; path[5 * i + 2] = r[i].z; path[5 * i + 3] = r[i].k; path[5 * i + 4] = r[i].s; }
+    };
+    put(r1, path1, n1);
+    const tk::spline &xs = opt.reference_path_->getXS(), &ys = opt.reference_path_->getYS();
+    *K = (int)xs.m_x.size();
+    for (int i = 0; i < *K && i < kcap; ++i) { ks[i] = xs.m_x[i]; kx[i] = xs.m_y[i]; ky[i] = ys.m_y[i]; }
+    *max_s = opt.reference_path_->getLength();
+    bool ok2 = false;
+    *n2 = 0;
+    if (ok1) { ok2 = opt.solveWithoutSmoothing(r1, &r2); *qp2 = OsqpEigen::g_cap.info; put(r2, path2, n2); }
+    return (ok1 ? 1 : 0) | (ok2 ? 2 : 0);
 }
 
 void po_ref_smooth_get_dims(int *n, int *m, int *pnz, int *anz) {

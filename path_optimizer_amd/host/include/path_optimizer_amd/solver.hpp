@@ -16,7 +16,15 @@
 #include <vector>
 
 #include "po_hip.h"  // repo-root include/ on the include path
+#ifdef PO_USE_REFERENCE_TYPES
+// drop-in build (host/dropin/path_optimizer/solver/solver.hpp): State, CoveringCircleBounds, ReferencePath and VehicleState are the REFERENCE's own
+// classes; this header only reads them through the getters the reference's solver reads them through
+#include "path_optimizer/data_struct/data_struct.hpp"
+#include "path_optimizer/data_struct/reference_path.hpp"
+#include "path_optimizer/data_struct/vehicle_state_frenet.hpp"
+#else
 #include "data_struct.hpp"
+#endif
 
 namespace PathOptimizationNS {
 
