@@ -93,11 +93,13 @@ def test_device_bounds_match_oracle_and_fixture(binding, oracle, scene):
         eng.bounds_batch(scene["P"])  # no map yet
     eng.set_map(scene["d"], scene["res"], scene["px"], scene["py"])
     bd, nv = eng.bounds_batch(scene["P"])
-    f_nv, f_ok = _close(bd, g["bounds"], nv, g["n_valid"])
-    assert f_nv >= 0.95 and f_ok >= 0.999, (f_nv, f_ok)
+    # index output (first blocked state) identical on EVERY path, against the reference-generated fixture and against the oracle; the bound values
+    # agree to round-off everywhere (device sin / cos differ from glibc in the last ulp: measured 99.5 % of the entries bit-identical, max 8e-15)
+    assert np.array_equal(nv, g["n_valid"])
+    assert np.abs(bd - g["bounds"]).max() < 1e-9
     ob, onv = _oracle_bounds(oracle, scene)
-    f_nv, f_ok = _close(bd, ob, nv, onv)
-    assert f_nv >= 0.95 and f_ok >= 0.999
+    assert np.array_equal(nv, onv)
+    assert np.abs(bd - ob).max() < 1e-9 and np.mean(bd == ob) >= 0.99
     for b in range(bd.shape[0]):
         assert (bd[b, nv[b]:] == 0).all()
     # ragged: fewer states / fewer knots per path
@@ -148,6 +150,8 @@ def test_device_pipeline_bounds_solve_check(binding, oracle, scene):
     assert np.array_equal(info["status"], oinfo["status"]) and (info["status"] == 1).mean() > 0.5  # (corridors squeezed by the random discs can be infeasible: -3 on both)
     same = info["iters"] == oinfo["iters"]
     assert same.mean() >= 0.9 and np.abs(states - ost)[same].max() < 1e-6
+    if (~same).any():  # one termination check earlier / later: compared at 10 x eps instead of dropped
+        assert np.abs(states - ost)[~same].max() < 1e-3
     onk, ook = oracle.postcheck_batch(oracle.default_params(), scene["m"], states, info, batch.n_points)
-    assert (nkeep.cpu().numpy() == onk).mean() >= 0.95 and (ok.cpu().numpy() == ook).mean() >= 0.95
+    assert np.array_equal(nkeep.cpu().numpy(), onk) and np.array_equal(ok.cpu().numpy(), ook)  # index outputs: identical on every path
     assert ook[info["status"] == 1].mean() > 0.5  # corridors from the map keep most optimised paths collision-free

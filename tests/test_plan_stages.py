@@ -123,7 +123,7 @@ def test_device_dp_search_matches_oracle(engine, oracle, omap):
         ident += ok
         assert not ls[b, max(nl[b], 0):].any() and not lb[b, max(nl[b], 0):].any()
     assert nl[5] == -1
-    assert ident >= 0.95 * (B - 1), ident  # device sin/cos/atan2 differ from glibc in the last ulp: a threshold or a tie can flip
+    assert ident == B - 1, ident  # same layer count and the same corridor on EVERY path (values to round-off: device sin/cos/atan2 differ from glibc in the last ulp)
     assert engine.dp_search_batch(sp, length, start, 8)[4].min() == -2  # cap too small is flagged, not truncated
 
 
@@ -169,3 +169,5 @@ def test_device_chain_search_to_post_smoothing(engine, oracle, omap):
     assert np.array_equal(info["status"], oinfo["status"])
     same = info["iters"] == oinfo["iters"]
     assert same.mean() >= 0.9 and np.abs(dx[same] - ox[same]).max() < 1e-7
+    if (~same).any():
+        assert np.abs(dx[~same] - ox[~same]).max() < 1e-2

@@ -174,6 +174,9 @@ def _compare(kind, dev, orc, inp, tol=1e-7, frac=0.9):
         assert np.abs(dy[same] - oy[same]).max() < tol and np.abs(ds[same] - os_[same]).max() < 10 * tol
     assert np.allclose(dinfo["rho"][same], oinfo["rho"][same], rtol=1e-4)  # the estimate is a ratio of small residuals
     assert np.allclose(dinfo["obj"][same], oinfo["obj"][same], rtol=1e-6, atol=1e-8)
+    if (~same).any():  # a residual within round-off of eps flipped one termination check: those instances are compared at 10 x eps, not dropped
+        assert (np.abs(dinfo["iters"].astype(int) - oinfo["iters"].astype(int))[~same] == 25).all()
+        assert np.abs(dx[~same] - ox[~same]).max() < 1e-2 and np.abs(draw[~same] - oraw[~same]).max() < 1e-2
     return err
 
 
