@@ -359,8 +359,9 @@ int po_assemble_batch(po_handle h, const po_batch_in *in, double *l, double *u, 
  * (layout in csrc/po_scale.hpp: W = E^2/c per row class, E, sigma/(c D^2) and c*D per variable class, c). */
 int po_scaling_batch(po_handle h, const po_batch_in *in, double *out);
 
-/* Kernel time (ms) of the last po_solve_batch* on this handle, measured with hipEvents on the
- * handle's stream (valid after the stream has been synchronised). */
+/* Kernel time (ms) of the last timed launch sequence on this handle, measured with hipEvents on the handle's stream (valid after the
+ * stream has been synchronised): po_solve_batch* (equilibration + solve launches + polish) or po_smooth_batch*.  After po_plan_batch*, which
+ * issues several of them, it is the LAST such sequence of the chain (the path QP of the last keep-group), not the whole call. */
 int po_last_kernel_ms(po_handle h, float *ms);
 
 const char *po_strerror(int code);

@@ -758,6 +758,8 @@ __global__ void plan_gate_kernel(PlanGate g) {
             if (st) g.cnt[b] = 0;
             break;
         case 7:  // after the collision check: cnt = n_kept, ok = optimizePath's value
+            if (!st && g.cnt[b] == -2) st = 9;  // densifying branch (ok is 0 already): output capacity too small (po_densify_batch's n_out = -2) is a capacity
+                                                                 // problem (stage 9, no states), not a failed collision check
             if (!st && !g.ok[b]) st = 8;
             if (st && st != 8) g.cnt[b] = 0;
             break;

@@ -55,7 +55,15 @@ class PathOptimizer {
         updateBounds(ref, knots, map_);  // reference_path_->updateBounds(*grid_map_); updateLimits() is a no-op for "KP"
         VehicleState vs(start_, end_, 0, 0);  // vehicle_state_->setInitError(0, 0)
         if (ref.getSize() < 2) return false;
-        OsqpSolver solver(PO_KP, ref, vs, ref.getSize(), map_.engine());  // OsqpSolver::create(FLAGS_optimization_method = "KP", ...)
+        // OsqpSolver::create(FLAGS_optimization_method, ...): the formulation comes from the engine's parameter block, as in po_plan_batch.  KPC needs
+        // ReferencePath::updateLimits' lists; for a reference given directly without a speed profile they are kappa_max / DBL_MAX (reference_path_impl.cpp:214-222)
+        const po_params &pp = map_.engine()->params();
+        const int form = pp.optimization_method == PO_K ? PO_K : (pp.optimization_method == PO_KPC ? PO_KPC : PO_KP);
+        if (form == PO_KPC) {
+            const double kmax = std::tan(pp.max_steer) / pp.wheel_base;
+            ref.setLimits(std::vector<double>(ref.getSize(), kmax), std::vector<double>(ref.getSize(), 1.7976931348623157e308));
+        }
+        OsqpSolver solver(form, ref, vs, ref.getSize(), map_.engine());
         std::vector<State> path;
         if (!solver.solve(&path)) return false;  // "QP failed."
         std::vector<std::vector<State>> one{path};
