@@ -140,6 +140,10 @@ typedef struct po_batch_in {
     const double *max_kp;   /* [B][N] KPC only; indexed by CONTROL id like the reference (:179-183) */
     const int    *n_points; /* optional [B]: points of each path, 2 <= n_points[b] <= N (ragged batch); NULL = all N.
                                Every array keeps its stride N; outputs beyond n_points[b] are zero.              */
+    const int    *order;    /* optional [B]: a PERMUTATION of 0..B-1; workgroup i solves path order[i] (workgroups start in index order).  A scheduling
+                               hint only — results do not depend on it: a launch ends with its longest path, so a caller that re-solves similar
+                               problems every planning cycle passes the paths sorted by the previous cycle's po_info.iters, longest first.
+                               NULL = the engine's own XCD-aware mixing of the path order. */
 } po_batch_in;
 
 typedef struct po_batch_out {

@@ -45,7 +45,7 @@ class PoBatchIn(C.Structure):
     _fields_ = [("formulation", C.c_int), ("B", C.c_int), ("N", C.c_int), ("keep", C.c_int),
                 ("ref_x", C.c_void_p), ("ref_y", C.c_void_p), ("ref_z", C.c_void_p), ("ref_k", C.c_void_p),
                 ("ref_s", C.c_void_p), ("bounds", C.c_void_p), ("x0", C.c_void_p), ("goal_z", C.c_void_p),
-                ("max_k", C.c_void_p), ("max_kp", C.c_void_p), ("n_points", C.c_void_p)]
+                ("max_k", C.c_void_p), ("max_kp", C.c_void_p), ("n_points", C.c_void_p), ("order", C.c_void_p)]
 
 
 class PoBatchOut(C.Structure):

@@ -130,10 +130,12 @@ class Engine:
         _check(lib().po_set_stream(self._h, C.c_void_p(raw_stream or 0)))
 
     # ---- host-pointer path (H2D + solve + D2H) ----
-    def solve_batch(self, batch, want_x: bool = False):
+    def solve_batch(self, batch, want_x: bool = False, order=None):
+        """order: optional permutation of range(B) — scheduling hint (po_batch_in.order), results do not depend on it."""
         n, m, _ = problem_dims(batch.formulation, batch.N, batch.keep)
         bi = PoBatchIn(batch.formulation, batch.B, batch.N, batch.keep, _np(batch.ref_x), _np(batch.ref_y), _np(batch.ref_z),
-                       _np(batch.ref_k), _np(batch.ref_s), _np(batch.bounds), _np(batch.x0), _np(batch.goal_z), _np(batch.max_k), _np(batch.max_kp), _np(_i32(getattr(batch, 'n_points', None))))
+                       _np(batch.ref_k), _np(batch.ref_s), _np(batch.bounds), _np(batch.x0), _np(batch.goal_z), _np(batch.max_k), _np(batch.max_kp), _np(_i32(getattr(batch, 'n_points', None))),
+                       _np(_i32(order)))
         states = np.zeros((batch.B, batch.N, 5))
         info = np.zeros(batch.B, dtype=INFO_DTYPE)
         xs = np.zeros((batch.B, n)) if want_x else None
@@ -159,7 +161,8 @@ class Engine:
     # ---- device-pointer path: tensors are torch CUDA(=HIP) tensors already resident in HBM ----
     def solve_batch_device(self, dev: "DeviceBatch"):
         bi = PoBatchIn(dev.formulation, dev.B, dev.N, dev.keep, *(None if t is None else t.data_ptr() for t in
-                       (dev.ref_x, dev.ref_y, dev.ref_z, dev.ref_k, dev.ref_s, dev.bounds, dev.x0, dev.goal_z, dev.max_k, dev.max_kp, dev.n_points)))
+                       (dev.ref_x, dev.ref_y, dev.ref_z, dev.ref_k, dev.ref_s, dev.bounds, dev.x0, dev.goal_z, dev.max_k, dev.max_kp, dev.n_points,
+                        getattr(dev, "order", None))))
         bo = PoBatchOut(dev.out_states.data_ptr(), dev.out_info.data_ptr(), None if dev.out_x is None else dev.out_x.data_ptr())
         _check(lib().po_solve_batch_device(self._h, C.byref(bi), C.byref(bo)))
 
@@ -359,6 +362,14 @@ class DeviceBatch:
         self.out_states = torch.zeros((batch.B, batch.N, 5), dtype=torch.float64, device=device)
         self.out_info = torch.zeros((batch.B, 48), dtype=torch.uint8, device=device)  # sizeof(po_info) == 48
         self.out_x = torch.zeros((batch.B, n), dtype=torch.float64, device=device) if want_x else None
+        self.order = None  # optional int32 [B] device tensor: scheduling hint (po_batch_in.order), see set_order()
+
+    def set_order(self, order):
+        """Scheduling hint for the next solves of this batch: a permutation of range(B), e.g. np.argsort(-previous_info["iters"], kind="stable")
+        (longest path first).  None: the engine's own mixing."""
+        import torch
+
+        self.order = None if order is None else torch.from_numpy(np.ascontiguousarray(order, dtype=np.int32)).to(self.out_states.device)
 
     def clone_outputs(self):
         """Same (shared, read-only) inputs, fresh output buffers: lets several handles solve the batch concurrently."""

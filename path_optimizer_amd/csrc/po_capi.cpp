@@ -230,6 +230,7 @@ static void fill_dev_batch(po::DevBatch *D, const po_batch_in *in, const po_batc
     D->ref_x = in->ref_x; D->ref_y = in->ref_y; D->ref_z = in->ref_z; D->ref_k = in->ref_k; D->ref_s = in->ref_s;
     D->bounds = in->bounds; D->x0 = in->x0; D->goal_z = in->goal_z; D->max_k = in->max_k; D->max_kp = in->max_kp;
     D->n_points = in->n_points;
+    D->order = in->order;
     D->out_states = out ? out->states : nullptr;
     D->out_info = out ? out->info : nullptr;
     D->out_x = out ? out->x : nullptr;
@@ -303,7 +304,7 @@ int po_solve_batch(po_handle h, const po_batch_in *in, const po_batch_out *out) 
     if (in->n_points)
         for (size_t b = 0; b < B; ++b)
             if (in->n_points[b] < 2 || in->n_points[b] > in->N) return PO_ERR_INVALID;
-    const size_t in_bytes = sizeof(double) * (B * N * per_pt + B * 4 + (B + 1) / 2 + 1);
+    const size_t in_bytes = sizeof(double) * (B * N * per_pt + B * 4 + 2 * ((B + 1) / 2 + 1));
     const size_t out_bytes = sizeof(double) * (B * N * 5 + (out->x ? B * (size_t)n : 0)) + sizeof(po_info) * B;
     {
         std::lock_guard<std::mutex> g(h->mu);
@@ -327,6 +328,17 @@ int po_solve_batch(po_handle h, const po_batch_in *in, const po_batch_out *out) 
         int *dn = reinterpret_cast<int *>(d + o);
         HIP_TRY(hipMemcpyAsync(dn, in->n_points, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
         din.n_points = dn;
+    }
+    if (in->order) {  // scheduling hint: must be a permutation (checked here; the device-pointer entry trusts its caller)
+        std::vector<char> seen(B, 0);
+        for (size_t b = 0; b < B; ++b) {
+            const int v = in->order[b];
+            if (v < 0 || (size_t)v >= B || seen[(size_t)v]) return PO_ERR_INVALID;
+            seen[(size_t)v] = 1;
+        }
+        int *dord = reinterpret_cast<int *>(d + o) + ((B + 1) / 2) * 2;
+        HIP_TRY(hipMemcpyAsync(dord, in->order, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+        din.order = dord;
     }
     po_batch_out dout;
     char *ob = static_cast<char *>(h->out_buf.p);

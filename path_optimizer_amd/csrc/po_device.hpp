@@ -44,6 +44,7 @@ struct DevBatch {
     po_info *out_info;
     double *out_x;
     const int *n_points;    // optional [B]: ragged batch (points of each path <= N); arrays keep stride N
+    const int *order;       // optional [B]: workgroup -> path permutation supplied by the caller (po_batch_in.order), overrides perm_bits
     const double *scale;    // [B][64] per-path equilibration block (po_scale.hpp)
     long long *dbg_cycles;  // optional [B][4] per-phase shader-clock totals (dev tool), or nullptr
     int perm_bits;          // block -> path permutation: ceil(log2 B) bits of mixing (0 = blockIdx order), see solve_kernel_fast

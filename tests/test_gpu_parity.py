@@ -448,3 +448,20 @@ def test_non_finite_inputs_are_never_reported_solved(binding):
         bb.ref_k[1, 7] = np.nan
         _, inf2, _ = binding.Engine(0).solve_batch(bb)
         assert inf2["status"][1] == -8 and inf2["status"][0] == PO_STATUS_SOLVED and inf2["status"][2] == PO_STATUS_SOLVED
+
+
+def test_order_hint_changes_scheduling_only(binding):
+    """po_batch_in.order (workgroup i solves path order[i]) is a scheduling hint: bit-identical results; a non-permutation is rejected."""
+    b = synth.make_batch(3, B=40)
+    eng = binding.Engine(0)
+    st0, info0, x0 = eng.solve_batch(b, want_x=True)
+    order = np.argsort(-info0["iters"].astype(np.int64), kind="stable")
+    st1, info1, x1 = eng.solve_batch(b, want_x=True, order=order)
+    assert np.array_equal(x0, x1) and np.array_equal(st0, st1) and np.array_equal(info0["iters"], info1["iters"])
+    bad = order.copy(); bad[3] = bad[4]
+    with pytest.raises(binding.PoError):
+        eng.solve_batch(b, order=bad)
+    p = binding.default_params(); p.polish = 1
+    st2, info2, x2 = binding.Engine(0, p).solve_batch(b, want_x=True, order=order[::-1].copy())
+    st3, info3, x3 = binding.Engine(0, p).solve_batch(b, want_x=True)
+    assert np.array_equal(x2, x3) and np.array_equal(info2["status_polish"], info3["status_polish"])
