@@ -30,6 +30,17 @@ if solve and "FETCH_SIZE" in solve and "WRITE_SIZE" in solve:
          "compulsory_io_bytes": 4096 * 8 * (18 * 200 + 8)}
     json.dump(t, open(os.path.join(os.path.dirname(dst.rstrip("/")), "traffic_latest.json"), "w"), indent=1)
     print(t)
+if solve and "SQ_INSTS_VALU" in solve:
+    # VALU wave-instructions per path-iteration: BASELINE config 3 = 4096 paths x 339.734 iterations per launch (po_info.iters, deterministic).
+    # fp64 wave-instructions per path-iteration: static count of one plain iteration of the headline kernel (tools/isa_phase_hist.py; argv[3] if given).
+    it_sum = 4096 * 339.73388671875
+    v = {"valu_wave_instr_per_path_iter": solve["SQ_INSTS_VALU"]["per_dispatch"] / it_sum,
+         "fp64_wave_instr_per_path_iter": float(sys.argv[3]) if len(sys.argv) > 3 else None,
+         "occupancy_waves_per_simd": 1,
+         "sq_wave_cycles_per_path_iter": solve.get("SQ_WAVE_CYCLES", {}).get("per_dispatch", 0) * 4 / it_sum,
+         "source": f"{dst}/pmc_summary.json (rocprofv3 --pmc SQ_INSTS_VALU ...) and the ISA histogram of the same tree (profiles/<tag>/phase_breakdown.txt)"}
+    json.dump(v, open(os.path.join(os.path.dirname(dst.rstrip("/")), "valu_latest.json"), "w"), indent=1)
+    print(v)
 for k, d in out.items():
     if "solve_kernel" in k and "SQ_INSTS_VALU" in d:
         print("VALU wave-instr per launch", d["SQ_INSTS_VALU"]["per_dispatch"], "LDS instr", d["SQ_INSTS_LDS"]["per_dispatch"],
