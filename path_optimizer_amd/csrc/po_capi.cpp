@@ -241,6 +241,7 @@ static void fill_dev_batch(po::DevBatch *D, const po_batch_in *in, const po_batc
         while ((1 << D->perm_bits) < in->B) ++D->perm_bits;
     D->scale = nullptr;
     D->pol_state = nullptr; D->pol_stride = 0;
+    D->use_split = 0;
     D->n = n; D->m = m;
 }
 
@@ -272,6 +273,11 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
             D.pol_stride = sd;
             polish = true;
         }
+    }
+    {   // EXPERIMENTAL, off by default: the stage-split two-wave mapping of the keep-4 kernel (two waves per SIMD; DESIGN.md §9: correct, but measured 30 % slower
+        // than the one-wave mapping — seven LDS hand-offs per iteration).  PO_SPLIT=1 selects it (A/B runs, tests); never together with the polish (state layout).
+        const char *e = std::getenv("PO_SPLIT");
+        D.use_split = (e && e[0] == '1' && !polish) ? 1 : 0;
     }
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     // per-path equilibration (h->params.scaling class-level Ruiz passes; 0 -> identity), then the fused solve

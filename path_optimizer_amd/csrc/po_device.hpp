@@ -50,6 +50,7 @@ struct DevBatch {
     int perm_bits;          // block -> path permutation: ceil(log2 B) bits of mixing (0 = blockIdx order), see solve_kernel_fast
     int only_deferred;      // set by the launcher for the second (general) launch of the two-level mapping: solve only the paths the first one deferred
     int n, m;
+    int use_split;          // launcher hint: take the stage-split two-wave mapping where it exists (keep 4, one-wave shapes; not with polish)
     double *pol_state;      // polish only: [B][pol_stride] per-lane ADMM state left by the solve kernels for polish_kernel (or nullptr)
     int pol_stride;
 };

@@ -144,6 +144,14 @@ template <int F, bool UNI> hipError_t launch_form(const DevBatch *in_, const Dev
     if constexpr (UNI) {
         if (!has_uni_variant<F>(s)) return hipSuccess;
     }
+    if constexpr (UNI && F != F_K) {
+        // keep == 4 on one-wave blocks (BASELINE configs 1-3): the stage-split two-wave mapping (Fast<..., NW = 2>): 2 stages per lane, <= 256 registers, two waves per SIMD
+        if (in->use_split && s.two && s.spl == 4 && s.nt == 64 && in->keep == 4) {
+            const size_t lds2 = lds_bytes_fast<F>(in->N, in->C, 2, true, 128, 2);
+            if (lds_out) *lds_out = lds2;
+            if (lds2 <= 160 * 1024) return launch1(&solve_kernel_split<F>, in, P, 128, lds2, st);
+        }
+    }
 #ifdef PO_DEV_HEADLINE  // dev builds: only the BASELINE config-3 variant (seconds to compile)
     if (s.two && s.spl == 4 && s.nt == 64) PO_L(4, 64, true);
     return hipErrorInvalidValue;
