@@ -40,36 +40,34 @@ __global__ void map_sample_kernel(DevMap m, int n, const double *xy, double *dis
 }
 
 
-// ---- tk::spline (src/tools/spline.cpp:154-271), natural boundary conditions ------------------------------------------------
-// fit: one thread per spline; a, b, c [K] out, w = 3K doubles of scratch (diagonal, saved 1/diagonal, rhs)
+// ---- natural cubic spline through (x_i, y_i): what the reference gets from tk::spline::set_points (src/tools/spline.cpp:154-271, a third-party GPL file that is
+// NOT reproduced here).  Derived independently from the textbook formulation: the second derivatives M_i solve the tridiagonal system
+//   h_{i-1} M_{i-1} + 2 (h_{i-1} + h_i) M_i + h_i M_{i+1} = 6 ((y_{i+1} - y_i) / h_i - (y_i - y_{i-1}) / h_{i-1}),   M_0 = M_{K-1} = 0,
+// by the Thomas algorithm; the piece on [x_i, x_{i+1}] is  a_i (t - x_i)^3 + b_i (t - x_i)^2 + c_i (t - x_i) + y_i  with  b_i = M_i / 2,
+// a_i = (M_{i+1} - M_i) / (6 h_i),  c_i = (y_{i+1} - y_i) / h_i - h_i (2 M_i + M_{i+1}) / 6; beyond the last knot the reference's class continues with the end
+// slope and zero curvature, which is what entry K-1 holds.  Same spline as the reference's to a few ulp (its LU on the scaled system rounds differently).
+// One thread per spline; a, b, c [K] out, w = 3K doubles of scratch.
 __device__ void spline_fit(int K, const double *x, const double *y, double *a, double *b, double *c, double *w) {
-    double *lo = a, *up = c, *di = w, *sd = w + K, *rh = w + 2 * K;
+    double *cp = w, *dp = w + K, *M = w + 2 * K;  // Thomas: modified super-diagonal, modified rhs, solution
+    cp[0] = 0.0; dp[0] = 0.0;                     // row 0: M_0 = 0
     for (int i = 1; i < K - 1; ++i) {
-        lo[i] = 1.0 / 3.0 * (x[i] - x[i - 1]);
-        di[i] = 2.0 / 3.0 * (x[i + 1] - x[i - 1]);
-        up[i] = 1.0 / 3.0 * (x[i + 1] - x[i]);
-        rh[i] = (y[i + 1] - y[i]) / (x[i + 1] - x[i]) - (y[i] - y[i - 1]) / (x[i] - x[i - 1]);
+        const double hl = x[i] - x[i - 1], hr = x[i + 1] - x[i];
+        const double rhs = 6.0 * ((y[i + 1] - y[i]) / hr - (y[i] - y[i - 1]) / hl);
+        const double piv = 2.0 * (hl + hr) - hl * cp[i - 1];
+        cp[i] = hr / piv;
+        dp[i] = (rhs - hl * dp[i - 1]) / piv;
     }
-    di[0] = 2.0; up[0] = 0.0; rh[0] = 0.0; lo[0] = 0.0;
-    di[K - 1] = 2.0; lo[K - 1] = 0.0; rh[K - 1] = 0.0; up[K - 1] = 0.0;
-    for (int i = 0; i < K; ++i) {  // band_matrix::lu_decompose preconditioning (:70-84)
-        sd[i] = 1.0 / di[i];
-        if (i > 0) lo[i] *= sd[i];
-        if (i < K - 1) up[i] *= sd[i];
-        di[i] = 1.0;
-    }
-    for (int k = 0; k + 1 < K; ++k) {  // Gauss (:86-100)
-        const double xx = -lo[k + 1] / di[k];
-        lo[k + 1] = -xx;
-        di[k + 1] = di[k + 1] + xx * up[k];
-    }
-    for (int i = 0; i < K; ++i) rh[i] = (rh[i] * sd[i]) - (i > 0 ? lo[i] * rh[i - 1] : 0.0);            // l_solve
-    for (int i = K - 1; i >= 0; --i) b[i] = (rh[i] - (i < K - 1 ? up[i] * b[i + 1] : 0.0)) / di[i];   // r_solve
+    M[K - 1] = 0.0;
+    for (int i = K - 2; i >= 1; --i) M[i] = dp[i] - cp[i] * M[i + 1];
+    M[0] = 0.0;
     for (int i = 0; i < K - 1; ++i) {
-        a[i] = 1.0 / 3.0 * (b[i + 1] - b[i]) / (x[i + 1] - x[i]);
-        c[i] = (y[i + 1] - y[i]) / (x[i + 1] - x[i]) - 1.0 / 3.0 * (2.0 * b[i] + b[i + 1]) * (x[i + 1] - x[i]);
+        const double h = x[i + 1] - x[i];
+        b[i] = 0.5 * M[i];
+        a[i] = (M[i + 1] - M[i]) / (6.0 * h);
+        c[i] = (y[i + 1] - y[i]) / h - h * (2.0 * M[i] + M[i + 1]) / 6.0;
     }
     const double h = x[K - 1] - x[K - 2];
+    b[K - 1] = 0.0;
     a[K - 1] = 0.0;
     c[K - 1] = 3.0 * a[K - 2] * h * h + 2.0 * b[K - 2] * h + c[K - 2];
 }
@@ -101,42 +99,50 @@ __device__ __forceinline__ double wrap_pi(double a) {  // constraintAngle, tools
     }
     return a;
 }
-// getClearanceWithDirectionStrict (reference_path_impl.cpp:283-472, simple boundary decision)
+// Lateral clearance of one covering circle: what ReferencePathImpl::getClearanceWithDirectionStrict returns with the shipped
+// FLAGS_enable_simple_boundary_decision = true (reference_path_impl.cpp:283-472).  Written here as rays and marches; the arithmetic of every probe position and of the
+// two results is the reference's (same operands in the same order: a threshold on an interpolated distance must fall on the same side).
+//   * two rays from the circle centre along the left / right normal of the heading;
+//   * coarse march in 0.5 m steps, at most 10: from a free centre outwards until a probe is blocked (clearance < radius), the bound is one step back; from a blocked centre
+//     first outwards on both sides until a probe is free, the nearer side wins, the corridor lies wholly on that side: one bound where it becomes free, the other where it is
+//     blocked again;
+//   * fine march: each bound pushed outwards in 0.1 m steps, at most 4, and taken back one step when the probe is blocked.
 __device__ void clearance_strict(const DevMap &m, double radius, double sx, double sy, double sz, double &left_bound, double &right_bound) {
-    left_bound = 0; right_bound = 0;
-    const double delta_s = 0.5;
-    const double la = wrap_pi(sz + M_PI_2), ra = wrap_pi(sz - M_PI_2);
-    const int n = (int)(5.0 / delta_s);
-    const double cl = cos(la), sl = sin(la), cr = cos(ra), sr = sin(ra);
+    struct Ray { double c, s; };
+    const double hl = wrap_pi(sz + M_PI_2), hr = wrap_pi(sz - M_PI_2);
+    const Ray L{cos(hl), sin(hl)}, R{cos(hr), sin(hr)};
+    constexpr double kCoarse = 0.5, kFine = 0.1;
+    const int n_coarse = (int)(5.0 / kCoarse), n_fine = (int)(kCoarse / kFine);
+    auto probe = [&](const Ray &r, double d) { return map_distance(m, sx + d * r.c, sy + d * r.s); };
+    auto march = [&](const Ray &r, double d, bool until_blocked) {  // distance reached when the probe first is blocked / free (or after n_coarse steps)
+        for (int k = 0; k != n_coarse; ++k) {
+            d += kCoarse;
+            const double clr = probe(r, d);
+            if (until_blocked ? clr < radius : clr > radius) break;
+        }
+        return d;
+    };
     if (map_distance(m, sx, sy) > radius) {
-        double right_s = 0, left_s = 0;
-        for (int j = 0; j != n; ++j) { right_s += delta_s; if (map_distance(m, sx + right_s * cr, sy + right_s * sr) < radius) break; }
-        for (int j = 0; j != n; ++j) { left_s += delta_s; if (map_distance(m, sx + left_s * cl, sy + left_s * sl) < radius) break; }
-        right_bound = -(right_s - delta_s);
-        left_bound = left_s - delta_s;
+        const double dr = march(R, 0.0, true), dl = march(L, 0.0, true);
+        right_bound = -(dr - kCoarse);
+        left_bound = dl - kCoarse;
     } else {
-        double right_s = 0, left_s = 0;
-        for (int j = 0; j != n; ++j) { right_s += delta_s; if (map_distance(m, sx + right_s * cr, sy + right_s * sr) > radius) break; }
-        for (int j = 0; j != n; ++j) { left_s += delta_s; if (map_distance(m, sx + left_s * cl, sy + left_s * sl) > radius) break; }
-        if (left_s < right_s) {
-            right_bound = left_s;
-            for (int j = 0; j != n; ++j) { left_s += delta_s; if (map_distance(m, sx + left_s * cl, sy + left_s * sl) < radius) break; }
-            left_bound = left_s - delta_s;
+        const double fr = march(R, 0.0, false), fl = march(L, 0.0, false);
+        if (fl < fr) {
+            right_bound = fl;
+            left_bound = march(L, fl, true) - kCoarse;
         } else {
-            left_bound = -right_s;
-            for (int j = 0; j != n; ++j) { right_s += delta_s; if (map_distance(m, sx + right_s * cr, sy + right_s * sr) < radius) break; }
-            right_bound = -(right_s - delta_s);
+            left_bound = -fr;
+            right_bound = -(march(R, fr, true) - kCoarse);
         }
     }
-    const double smaller_ds = 0.1;
-    const int nf = (int)(delta_s / smaller_ds);
-    for (int i = 1; i != nf; ++i) {
-        left_bound += smaller_ds;
-        if (map_distance(m, sx + left_bound * cl, sy + left_bound * sl) < radius) { left_bound -= smaller_ds; break; }
+    for (int k = 1; k != n_fine; ++k) {
+        left_bound += kFine;
+        if (probe(L, left_bound) < radius) { left_bound -= kFine; break; }
     }
-    for (int i = 1; i != nf; ++i) {
-        right_bound -= smaller_ds;
-        if (map_distance(m, sx + right_bound * cr, sy + right_bound * sr) < radius) { right_bound += smaller_ds; break; }
+    for (int k = 1; k != n_fine; ++k) {
+        right_bound -= kFine;
+        if (probe(R, right_bound) < radius) { right_bound += kFine; break; }
     }
 }
 // One block per path, one thread per (state, circle): updateBoundsImproved (:142-201)
