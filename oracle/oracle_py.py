@@ -51,6 +51,24 @@ def use_native() -> bool:
     return True
 
 
+def set_portable_math(on: bool) -> None:
+    """Map stages only (bounds, DP search, re-sampling, projections, collision geometry).  False (default): glibc's sin / cos / atan2 / pow and the reference's
+    spline elimination order — the mode that is pinned bit for bit against the reference's own binaries.  True: include/po_pmath.h and the device's spline
+    derivation, i.e. the exact IEEE operation sequence of the HIP kernels — device and oracle then agree BIT FOR BIT (tests/test_pmath.py)."""
+    lib().po_oracle_set_portable_math(1 if on else 0)
+
+
+class portable_math:
+    """with oracle_py.portable_math(): ...   (restores the previous mode)"""
+
+    def __enter__(self):
+        self.prev = lib().po_oracle_get_portable_math()
+        set_portable_math(True)
+
+    def __exit__(self, *a):
+        set_portable_math(bool(self.prev))
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 

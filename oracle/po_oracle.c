@@ -14,6 +14,21 @@
  * Build with -ffp-contract=off: the reference is built without FMA contraction (x86-64 baseline).
  */
 #include "po_oracle.h"
+#include "../include/po_pmath.h"
+
+/* Portable-math mode for the map stages.  Off (default): glibc's sin / cos / atan2 / pow — what the reference's own binaries call, so the
+ * oracle stays bit-comparable with them.  On: the portable routines of include/po_pmath.h, the same IEEE operation sequence the HIP kernels execute, so that
+ * device and oracle agree BIT FOR BIT on values and indices (tests/test_pmath.py also bounds the difference between the two modes: <= 1 ulp per call). */
+static int g_portable_math = 0;
+void po_oracle_set_portable_math(int on) { g_portable_math = on != 0; }
+int po_oracle_get_portable_math(void) { return g_portable_math; }
+double po_oracle_psin(double x) { return po_psin(x); }
+double po_oracle_pcos(double x) { return po_pcos(x); }
+double po_oracle_patan2(double y, double x) { return po_patan2(y, x); }
+#define MSIN(x) (g_portable_math ? po_psin(x) : sin(x))
+#define MCOS(x) (g_portable_math ? po_pcos(x) : cos(x))
+#define MATAN2(y, x) (g_portable_math ? po_patan2((y), (x)) : atan2((y), (x)))
+#define MPOW15(x) (g_portable_math ? po_ppow15(x) : pow((x), 1.5))
 
 #include <math.h>
 #include <stdlib.h>
@@ -1677,7 +1692,7 @@ int po_oracle_collision_free(const po_params *p, const po_map *m, double x, doub
     const double cx[6] = {-back + shift, -back + shift, front - shift, front - shift, bcx + (length - width) / 4, bcx - (length - width) / 4};
     const double cy[6] = {-width / 2.0 + shift, width / 2.0 - shift, -width / 2.0 + shift, width / 2.0 - shift, 0, 0};
     const double cr[6] = {small_r, small_r, small_r, small_r, large_r, large_r};
-    const double cz = cos(z), sz = sin(z);
+    const double cz = MCOS(z), sz = MSIN(z);
     const double bx = bcx * cz - 0.0 * sz + x, by = bcx * sz + 0.0 * cz + y; /* local2Global, tools.cpp:50-55 */
     if (!po_oracle_map_inside(m, bx, by)) return 0;
     if (!(po_oracle_map_distance(m, bx, by) < bcr)) return 1;
@@ -1706,7 +1721,35 @@ int po_oracle_postcheck(const po_params *p, const po_map *m, int n, const double
  * Corridor-bounds producer.  In-tree logic pinned against reference_path_impl.cpp / spline.cpp / tools.cpp
  * compiled through oracle/ref_shim (oracle/_ref/libpo_ref_bounds.so, tests/test_bounds.py).
  * ===================================================================================================== */
+/* Portable-math mode: the device's own derivation of the same natural cubic spline (Thomas algorithm on the second derivatives, csrc/po_post.hip
+ * spline_fit), operation for operation — so that device and oracle agree bit for bit downstream.  Equal to the reference's spline to a few ulp. */
+static void spline_fit_thomas(int K, const double *x, const double *y, double *a, double *b, double *c) {
+    double *cp = (double *)malloc(sizeof(double) * (size_t)K * 3), *dp = cp + K, *M = cp + 2 * K;
+    cp[0] = 0.0; dp[0] = 0.0;
+    for (int i = 1; i < K - 1; ++i) {
+        const double hl = x[i] - x[i - 1], hr = x[i + 1] - x[i];
+        const double rhs = 6.0 * ((y[i + 1] - y[i]) / hr - (y[i] - y[i - 1]) / hl);
+        const double piv = 2.0 * (hl + hr) - hl * cp[i - 1];
+        cp[i] = hr / piv;
+        dp[i] = (rhs - hl * dp[i - 1]) / piv;
+    }
+    M[K - 1] = 0.0;
+    for (int i = K - 2; i >= 1; --i) M[i] = dp[i] - cp[i] * M[i + 1];
+    M[0] = 0.0;
+    for (int i = 0; i < K - 1; ++i) {
+        const double h = x[i + 1] - x[i];
+        b[i] = 0.5 * M[i];
+        a[i] = (M[i + 1] - M[i]) / (6.0 * h);
+        c[i] = (y[i + 1] - y[i]) / h - h * (2.0 * M[i] + M[i + 1]) / 6.0;
+    }
+    const double h = x[K - 1] - x[K - 2];
+    b[K - 1] = 0.0;
+    a[K - 1] = 0.0;
+    c[K - 1] = 3.0 * a[K - 2] * h * h + 2.0 * b[K - 2] * h + c[K - 2];
+    free(cp);
+}
 void po_oracle_spline_fit(int K, const double *x, const double *y, double *a, double *b, double *c) {
+    if (g_portable_math) { spline_fit_thomas(K, x, y, a, b, c); return; }
     /* set_points (spline.cpp:168-250): tridiagonal system for b[], rows normalised to a unit diagonal, LU without pivoting
      * (band_matrix::lu_decompose, :70-101), then l_solve / r_solve (:103-130).  Scratch: lo, di, up, sd, rhs in the outputs. */
     double *lo = a, *up = c; /* reuse: a <- lower band, c <- upper band until the solve is done */
@@ -1757,7 +1800,7 @@ static void clearance_strict(const po_map *m, double radius, double sx, double s
     const double delta_s = 0.5;
     const double la = po_oracle_wrap_angle(sz + M_PI_2), ra = po_oracle_wrap_angle(sz - M_PI_2);
     const int n = (int)(5.0 / delta_s);
-    const double cl = cos(la), sl = sin(la), cr = cos(ra), sr = sin(ra);
+    const double cl = MCOS(la), sl = MSIN(la), cr = MCOS(ra), sr = MSIN(ra);
     if (po_oracle_map_distance(m, sx, sy) > radius) { /* normal case */
         double right_s = 0, left_s = 0;
         for (int j = 0; j != n; ++j) { right_s += delta_s; if (po_oracle_map_distance(m, sx + right_s * cr, sy + right_s * sr) < radius) break; }
@@ -1800,7 +1843,7 @@ int po_oracle_bounds_path(const po_params *p, const po_map *m, int N, const doub
     const double radius = sqrt((p->car_length / 8) * (p->car_length / 8) + (p->car_width / 2) * (p->car_width / 2)) + p->safety_margin;
     int kept = 0;
     for (int i = 0; i < N; ++i) {
-        const double cz = cos(ref_z[i]), sz = sin(ref_z[i]);
+        const double cz = MCOS(ref_z[i]), sz = MSIN(ref_z[i]);
         double cl[4][2];
         int blocked = 0;
         for (int j = 0; j < 4; ++j) {
@@ -2022,10 +2065,10 @@ static double spl2_x(const spl2_t *S, double at) { return po_oracle_spline_eval(
 static double spl2_y(const spl2_t *S, double at) { return po_oracle_spline_eval(S->K, S->s, S->vy, S->ay, S->by, S->cy, at); }
 static double spl2_dx(const spl2_t *S, int o, double at) { return po_oracle_spline_deriv(S->K, S->s, S->vx, S->ax, S->bx, S->cx, o, at); }
 static double spl2_dy(const spl2_t *S, int o, double at) { return po_oracle_spline_deriv(S->K, S->s, S->vy, S->ay, S->by, S->cy, o, at); }
-static double spl2_heading(const spl2_t *S, double at) { return atan2(spl2_dy(S, 1, at), spl2_dx(S, 1, at)); } /* tools.cpp:34-38 */
+static double spl2_heading(const spl2_t *S, double at) { return MATAN2(spl2_dy(S, 1, at), spl2_dx(S, 1, at)); } /* tools.cpp:34-38 */
 static double spl2_curvature(const spl2_t *S, double at) {                                                      /* tools.cpp:40-46 */
     const double x1 = spl2_dx(S, 1, at), y1 = spl2_dy(S, 1, at), x2 = spl2_dx(S, 2, at), y2 = spl2_dy(S, 2, at);
-    return (x1 * y2 - y1 * x2) / pow(x1 * x1 + y1 * y1, 1.5);
+    return (x1 * y2 - y1 * x2) / MPOW15(x1 * x1 + y1 * y1);
 }
 /* findClosestPoint(xs, ys, x, y, max_s, start_s = 0): the arc length it settles on (tools.cpp:71-112) */
 static double spl2_closest_s(const spl2_t *S, double x, double y, double max_s) {
@@ -2105,7 +2148,7 @@ int po_oracle_dp_search(const po_params *p, const po_map *map, int K, const doub
     {
         const double vs = ls[0], pxr = spl2_x(&S, vs), pyr = spl2_y(&S, vs), pz = spl2_heading(&S, vs);
         const double dx = start[0] - pxr, dy = start[1] - pyr;
-        const double vl = -dx * sin(pz) + dy * cos(pz); /* global2Local(proj_point, start_state).y */
+        const double vl = -dx * MSIN(pz) + dy * MCOS(pz); /* global2Local(proj_point, start_state).y */
         *l0 = vl;
         if (fabs(vl) > range) { rc = -1; goto done0; }
         const int start_idx = (int)((range + vl) / spacing);
@@ -2122,7 +2165,7 @@ int po_oracle_dp_search(const po_params *p, const po_map *map, int K, const doub
             for (int j = 0; j < nlat; ++j) {
                 node_t *q = row + j;
                 const double cur_l = lat[j];
-                q->x = rx + cur_l * cos(rh + M_PI_2); q->y = ry + cur_l * sin(rh + M_PI_2);
+                q->x = rx + cur_l * MCOS(rh + M_PI_2); q->y = ry + cur_l * MSIN(rh + M_PI_2);
                 q->heading = rh; q->s = cur_s; q->l = cur_l; q->cost = DBL_MAX; q->dir = 0; q->parent = -1; q->feas = 1;
                 q->dis = po_oracle_map_inside(map, q->x, q->y) ? po_oracle_map_distance(map, q->x, q->y) : -1;
                 if ((rk < 0 && cur_l < rr) || (rk > 0 && cur_l > rr) || q->dis < search_threshold) q->feas = 0;
@@ -2149,7 +2192,7 @@ int po_oracle_dp_search(const po_params *p, const po_map *map, int K, const doub
                     const node_t *pp = prow + k;
                     if (!pp->feas) continue;
                     if (fabs(pp->l - q->l) > (q->s - pp->s)) continue;
-                    const double direction = atan2(q->y - pp->y, q->x - pp->x);
+                    const double direction = MATAN2(q->y - pp->y, q->x - pp->x);
                     const double edge = fabs(po_oracle_wrap_angle(direction - pp->dir)) / M_PI_2 * 16.0 +
                                         fabs(po_oracle_wrap_angle(direction - q->heading)) / M_PI_2 * 0.5;
                     const double total = self + edge + pp->cost;
@@ -2175,12 +2218,12 @@ int po_oracle_dp_search(const po_params *p, const po_map *map, int K, const doub
                 hi = check_s + q->rhi; lo = -check_s + q->rlo;
                 const double rx = spl2_x(&S, q->s), ry = spl2_y(&S, q->s);
                 while (hi < check_limit) {
-                    const double px2 = rx + hi * cos(q->heading + M_PI_2), py2 = ry + hi * sin(q->heading + M_PI_2);
+                    const double px2 = rx + hi * MCOS(q->heading + M_PI_2), py2 = ry + hi * MSIN(q->heading + M_PI_2);
                     if (po_oracle_map_inside(map, px2, py2) && po_oracle_map_distance(map, px2, py2) > search_threshold) hi += check_s;
                     else { hi -= check_s; break; }
                 }
                 while (lo > -check_limit) {
-                    const double px2 = rx + lo * cos(q->heading + M_PI_2), py2 = ry + lo * sin(q->heading + M_PI_2);
+                    const double px2 = rx + lo * MCOS(q->heading + M_PI_2), py2 = ry + lo * MSIN(q->heading + M_PI_2);
                     if (po_oracle_map_inside(map, px2, py2) && po_oracle_map_distance(map, px2, py2) > search_threshold) lo -= check_s;
                     else { lo += check_s; break; }
                 }
@@ -2282,15 +2325,15 @@ int po_oracle_segment_raw(int K, const double *ks, const double *kx, const doubl
     /* `if (max_s - s_list->back() > 1)` can never hold after the loop */
     for (int i = 0; i < n && !rc; ++i) {
         const double at = s[i], dx = spl2_dx(&S, 1, at), dy = spl2_dy(&S, 1, at), ddx = spl2_dx(&S, 2, at), ddy = spl2_dy(&S, 2, at);
-        angle[i] = atan2(dy, dx);
-        k[i] = (dx * ddy - dy * ddx) / pow(dx * dx + dy * dy, 1.5);
+        angle[i] = MATAN2(dy, dx);
+        k[i] = (dx * ddy - dy * ddx) / MPOW15(dx * dx + dy * dy);
         x[i] = spl2_x(&S, at); y[i] = spl2_y(&S, at);
     }
     free(S.ax);
     return rc ? rc : n;
 }
 
-/* postSmooth's tail: x = xs(s) + l cos(dir + pi/2), y = ys(s) + l sin(dir + pi/2), running chord length */
+/* postSmooth's tail: x = xs(s) + l MCOS(dir + pi/2), y = ys(s) + l MSIN(dir + pi/2), running chord length */
 int po_oracle_post_project(int K, const double *ks, const double *kx, const double *ky, int L, const double *layer_s, const double *offsets,
                            double *x, double *y, double *s) {
     spl2_t S;
@@ -2299,8 +2342,8 @@ int po_oracle_post_project(int K, const double *ks, const double *kx, const doub
     double acc = 0;
     for (int i = 0; i < L; ++i) {
         const double ref_s = layer_s[i], ref_dir = spl2_heading(&S, ref_s);
-        x[i] = spl2_x(&S, ref_s) + offsets[i] * cos(ref_dir + M_PI_2);
-        y[i] = spl2_y(&S, ref_s) + offsets[i] * sin(ref_dir + M_PI_2);
+        x[i] = spl2_x(&S, ref_s) + offsets[i] * MCOS(ref_dir + M_PI_2);
+        y[i] = spl2_y(&S, ref_s) + offsets[i] * MSIN(ref_dir + M_PI_2);
         if (i > 0) {
             const double ddx = x[i] - x[i - 1], ddy = y[i] - y[i - 1];
             acc += sqrt(ddx * ddx + ddy * ddy);
@@ -2323,7 +2366,7 @@ int po_oracle_segment_init(int K, const double *ks, const double *kx, const doub
     int ok = 1;
     const double fx = spl2_x(&S, 0), fy = spl2_y(&S, 0), fz = spl2_heading(&S, 0);
     const double dx = fx - start[0], dy = fy - start[1];
-    const double local_y = -dx * sin(start[2]) + dy * cos(start[2]); /* global2Local(start_state, first_point).y */
+    const double local_y = -dx * MSIN(start[2]) + dy * MCOS(start[2]); /* global2Local(start_state, first_point).y */
     const double min_distance = sqrt((start[0] - fx) * (start[0] - fx) + (start[1] - fy) * (start[1] - fy));
     out[0] = local_y < 0 ? min_distance : -min_distance;
     out[1] = po_oracle_wrap_angle(start[2] - fz);

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/po_hip.h"
+#include "../../include/po_pmath.h"  // portable sin / cos / atan2: the same IEEE operation sequence as the oracle's portable-math mode (bit-exact map stages)
 
 namespace po {
 
@@ -158,7 +159,7 @@ __device__ __forceinline__ double map_distance(const DevMap &m, double x, double
 
 // CollisionChecker::isSingleStateCollisionFreeImproved (collision_checker.cpp:42-59)
 __device__ __forceinline__ bool collision_free(const DevMap &m, const DevCar &c, double x, double y, double z) {
-    const double cz = cos(z), sz = sin(z);
+    const double cz = po_pcos(z), sz = po_psin(z);
     // local2Global (tools.cpp:50-55): x = tx cos - ty sin + rx ; y = tx sin + ty cos + ry
     const double bx = __dadd_rn(__dsub_rn(__dmul_rn(c.bx, cz), __dmul_rn(0.0, sz)), x);
     const double by = __dadd_rn(__dadd_rn(__dmul_rn(c.bx, sz), __dmul_rn(0.0, cz)), y);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/po_hip.h"
+#include "../../include/po_pmath.h"  // portable sin / cos / atan2: the same IEEE operation sequence as the oracle's portable-math mode (bit-exact map stages)
 #define PO_MAP_DEVICE_CODE
 #include "po_map.hpp"
 
@@ -110,7 +111,7 @@ __device__ __forceinline__ double wrap_pi(double a) {  // constraintAngle, tools
 __device__ void clearance_strict(const DevMap &m, double radius, double sx, double sy, double sz, double &left_bound, double &right_bound) {
     struct Ray { double c, s; };
     const double hl = wrap_pi(sz + M_PI_2), hr = wrap_pi(sz - M_PI_2);
-    const Ray L{cos(hl), sin(hl)}, R{cos(hr), sin(hr)};
+    const Ray L{po_pcos(hl), po_psin(hl)}, R{po_pcos(hr), po_psin(hr)};
     constexpr double kCoarse = 0.5, kFine = 0.1;
     const int n_coarse = (int)(5.0 / kCoarse), n_fine = (int)(kCoarse / kFine);
     auto probe = [&](const Ray &r, double d) { return map_distance(m, sx + d * r.c, sy + d * r.s); };
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void bounds_kernel(DevMap m, DevBounds in, dou
         if (i < n) {
             const size_t o = (size_t)b * in.N + i;
             const double x = in.ref_x[o], y = in.ref_y[o], z = in.ref_z[o], s = in.ref_s[o];
-            const double cz = cos(z), sz = sin(z), len = in.d[j];
+            const double cz = po_pcos(z), sz = po_psin(z), len = in.d[j];
             const double ccx = x + len * cz, ccy = y + len * sz;
             // getApproxState (:121-140)
             const double px = spline_eval(K, ks, kx, cx_, cx_ + in.K, cx_ + 2 * in.K, s + len);
@@ -212,10 +213,10 @@ struct Spl2 {
     __device__ __forceinline__ double y(double at) const { return spline_eval(K, s, vy, ay, by, cy, at); }
     __device__ __forceinline__ double dx(int o, double at) const { return spline_deriv(K, s, ax, bx, cx, o, at); }
     __device__ __forceinline__ double dy(int o, double at) const { return spline_deriv(K, s, ay, by, cy, o, at); }
-    __device__ __forceinline__ double heading(double at) const { return atan2(dy(1, at), dx(1, at)); }  // getHeading, tools.cpp:34-38
+    __device__ __forceinline__ double heading(double at) const { return po_patan2(dy(1, at), dx(1, at)); }  // getHeading, tools.cpp:34-38
     __device__ __forceinline__ double curvature(double at) const {                                     // getCurvature, tools.cpp:40-46
         const double x1 = dx(1, at), y1 = dy(1, at), x2 = dx(2, at), y2 = dy(2, at);
-        return (x1 * y2 - y1 * x2) / pow(x1 * x1 + y1 * y1, 1.5);
+        return (x1 * y2 - y1 * x2) / po_ppow15(x1 * x1 + y1 * y1);
     }
 };
 // Knots into LDS, then the two natural-spline fits (x(s) and y(s)) by lanes 0 and 1 right there: 15 K doubles of LDS
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(64) void dp_search_kernel(DevMap m, DevSpline in, D
     if (!rc) {
         const double vs = ls[0], pxr = S.x(vs), pyr = S.y(vs), pz = S.heading(vs);
         const double dx = sx - pxr, dy = sy - pyr;
-        vl = -dx * sin(pz) + dy * cos(pz);  // global2Local(proj_point, start_state).y
+        vl = -dx * po_psin(pz) + dy * po_pcos(pz);  // global2Local(proj_point, start_state).y
         if (fabs(vl) > q.range) rc = -1;
         start_idx = (int)((q.range + vl) / q.lat_spacing);
     }
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(64) void dp_search_kernel(DevMap m, DevSpline in, D
         const double cur_s = ls[i];
         const double rx = S.x(cur_s), ry = S.y(cur_s), rh = S.heading(cur_s), rk = S.curvature(cur_s), rr = 1 / rk;
         double *cur = nx + (i & 1) * 4 * kDpMaxLat, *prv = nx + ((i & 1) ^ 1) * 4 * kDpMaxLat;
-        const double x = rx + my_l * cos(rh + M_PI_2), y = ry + my_l * sin(rh + M_PI_2);
+        const double x = rx + my_l * po_pcos(rh + M_PI_2), y = ry + my_l * po_psin(rh + M_PI_2);
         const double dis = map_inside(m, x, y) ? map_distance(m, x, y) : -1;
         bool feas = act && !((rk < 0 && my_l < rr) || (rk > 0 && my_l > rr) || dis < search_threshold);
         double cost = 1.7976931348623157e308, dir = 0;
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(64) void dp_search_kernel(DevMap m, DevSpline in, D
             for (int k = 0; k < nlat; ++k) {
                 if (!((pm >> k) & 1ull)) continue;
                 if (fabs(lat[k] - my_l) > (cur_s - ps)) continue;
-                const double direction = atan2(y - prv[kDpMaxLat + k], x - prv[k]);
+                const double direction = po_patan2(y - prv[kDpMaxLat + k], x - prv[k]);
                 const double edge = fabs(wrap_pi(direction - prv[2 * kDpMaxLat + k])) / M_PI_2 * 16.0 + fabs(wrap_pi(direction - rh)) / M_PI_2 * 0.5;
                 const double total = self + edge + prv[3 * kDpMaxLat + k];
                 if (total < min_cost) { min_cost = total; par = k; dir = direction; }
@@ -452,12 +453,12 @@ __global__ __launch_bounds__(64) void dp_search_kernel(DevMap m, DevSpline in, D
                 hi = check_s + lat[jb]; lo = -check_s + lat[ja];
                 const double rx = S.x(sv), ry = S.y(sv), rh = S.heading(sv);
                 while (hi < check_limit) {
-                    const double px2 = rx + hi * cos(rh + M_PI_2), py2 = ry + hi * sin(rh + M_PI_2);
+                    const double px2 = rx + hi * po_pcos(rh + M_PI_2), py2 = ry + hi * po_psin(rh + M_PI_2);
                     if (map_inside(m, px2, py2) && map_distance(m, px2, py2) > search_threshold) hi += check_s;
                     else { hi -= check_s; break; }
                 }
                 while (lo > -check_limit) {
-                    const double px2 = rx + lo * cos(rh + M_PI_2), py2 = ry + lo * sin(rh + M_PI_2);
+                    const double px2 = rx + lo * po_pcos(rh + M_PI_2), py2 = ry + lo * po_psin(rh + M_PI_2);
                     if (map_inside(m, px2, py2) && map_distance(m, px2, py2) > search_threshold) lo -= check_s;
                     else { lo += check_s; break; }
                 }
@@ -575,8 +576,8 @@ __global__ __launch_bounds__(64) void segment_raw_kernel(DevSpline in, int P, do
     for (int i = lane; i < P; i += 64) {
         if (i < n) {
             const double at = (double)i, dx = S.dx(1, at), dy = S.dy(1, at), ddx = S.dx(2, at), ddy = S.dy(2, at);
-            angle[o + i] = atan2(dy, dx);
-            k[o + i] = (dx * ddy - dy * ddx) / pow(dx * dx + dy * dy, 1.5);
+            angle[o + i] = po_patan2(dy, dx);
+            k[o + i] = (dx * ddy - dy * ddx) / po_ppow15(dx * dx + dy * dy);
             x[o + i] = S.x(at); y[o + i] = S.y(at); s[o + i] = at;
         } else { x[o + i] = 0; y[o + i] = 0; s[o + i] = 0; angle[o + i] = 0; k[o + i] = 0; }
     }
@@ -602,8 +603,8 @@ __global__ __launch_bounds__(64) void post_project_kernel(DevSpline in, int L, c
         double ox = 0, oy = 0;
         if (i < n) {
             const double ref_s = layer_s[o + i], ref_dir = S.heading(ref_s);
-            ox = S.x(ref_s) + off[o + i] * cos(ref_dir + M_PI_2);
-            oy = S.y(ref_s) + off[o + i] * sin(ref_dir + M_PI_2);
+            ox = S.x(ref_s) + off[o + i] * po_pcos(ref_dir + M_PI_2);
+            oy = S.y(ref_s) + off[o + i] * po_psin(ref_dir + M_PI_2);
         }
         x[o + i] = ox; y[o + i] = oy;
     }
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(64) void segment_init_kernel(DevSpline in, const do
     const double gx = goal[(size_t)b * goal_stride], gy = goal[(size_t)b * goal_stride + 1];
     const double fx = S.x(0), fy = S.y(0), fz = S.heading(0);
     const double dx = fx - sx, dy = fy - sy;
-    const double local_y = -dx * sin(sz) + dy * cos(sz);
+    const double local_y = -dx * po_psin(sz) + dy * po_pcos(sz);
     const double min_distance = sqrt((sx - fx) * (sx - fx) + (sy - fy) * (sy - fy));
     const double e0 = local_y < 0 ? min_distance : -min_distance, e1 = wrap_pi(sz - fz);
     int good = !(fabs(e1) > 75 * M_PI / 180);

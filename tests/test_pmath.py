@@ -1,0 +1,126 @@
+"""Bit-exact map stages.  The corridor-bounds producer, the DP lattice search and the re-sampling take thresholds and ties on quantities that
+pass through sin / cos / atan2, and a GPU libm does not round like glibc.  include/po_pmath.h holds portable routines (IEEE +, -, *, /, sqrt only) that the HIP
+kernels always use and that the oracle uses in its portable-math mode: device and oracle then agree BIT FOR BIT on values and indices.  The oracle's default mode
+(glibc, the reference's spline elimination order) stays the one that is pinned against the reference's own binaries; here the two modes are bounded against each
+other."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from path_optimizer_amd import synth
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import make_bounds_golden as GB  # noqa: E402
+import make_post_golden as GP  # noqa: E402
+
+MAP_KW = dict(size_x=600, size_y=600, resolution=0.2, pos=(1.0, -2.0), n_obstacles=40, r_range=(0.5, 2.0))
+
+
+def _ulps(a, b):
+    return np.abs(a - b) / np.spacing(np.maximum(np.abs(b), 1e-300))
+
+
+def test_portable_trig_is_within_one_ulp_of_glibc(oracle):
+    L = oracle.lib()
+    for f in ("po_oracle_psin", "po_oracle_pcos"):
+        getattr(L, f).restype = C.c_double
+        getattr(L, f).argtypes = [C.c_double]
+    L.po_oracle_patan2.restype = C.c_double
+    L.po_oracle_patan2.argtypes = [C.c_double, C.c_double]
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.uniform(-10, 10, 40000), rng.uniform(-1e-3, 1e-3, 4000), rng.uniform(-3000, 3000, 10000),
+                         np.pi / 2 * np.arange(-60, 61) + rng.uniform(-1e-9, 1e-9, 121), [0.0, -0.0, np.pi / 4, -np.pi / 4, 0.7853981633974484, 1e-30, 2.0 ** -27]])
+    s = np.array([L.po_oracle_psin(float(x)) for x in xs])
+    c = np.array([L.po_oracle_pcos(float(x)) for x in xs])
+    assert _ulps(s, np.sin(xs)).max() <= 1.0 and _ulps(c, np.cos(xs)).max() <= 1.0
+    assert (s == np.sin(xs)).mean() > 0.95 and (c == np.cos(xs)).mean() > 0.95  # mostly the very same double
+    assert np.abs(s * s + c * c - 1).max() < 4e-16
+    ys, xx = rng.uniform(-5, 5, 40000), rng.uniform(-5, 5, 40000)
+    ys[:8] = [0.0, 0.0, 1.0, -1.0, 1e-300, 3.0, -0.0, 2.0]
+    xx[:8] = [1.0, -1.0, 0.0, 0.0, 1.0, 1.0, -2.0, 1e-300]
+    a = np.array([L.po_oracle_patan2(float(y), float(x)) for y, x in zip(ys, xx)])
+    assert _ulps(a, np.arctan2(ys, xx)).max() <= 2.0
+    assert a[0] == 0.0 and a[1] == np.pi and a[2] == np.pi / 2 and a[3] == -np.pi / 2 and a[6] == -np.pi
+
+
+def test_oracle_modes_agree_on_indices_and_to_round_off_on_values(oracle):
+    """glibc mode (pinned against the reference) vs portable mode (= the device arithmetic): same truncation points, layer counts, corridors; values to round-off."""
+    d, res, px, py, _ = synth.make_distance_map(**GP.MAP_ARGS)
+    m = oracle.make_map(d, res, px, py)
+    P = synth.make_spline_paths(GB.SEED, 16, GB.N)
+    p = oracle.default_params()
+    dm = synth.make_distance_map(3, **MAP_KW)
+    om = oracle.make_map(*dm[:4])
+    sp, length, start = synth.make_search_inputs(6, 16)
+
+    def run():
+        out = []
+        for b in range(16):
+            bd, nv = oracle.bounds_path(p, m, *[P[k][b] for k in GB.KEYS])
+            n, ls, lb, ub, l0 = oracle.dp_search(p, om, sp["knot_s"][b], sp["knot_x"][b], sp["knot_y"][b], length[b], start[b], cap=64)
+            nr, rs = oracle.resample(p, sp["knot_s"][b], sp["knot_x"][b], sp["knot_y"][b], length[b], 0.15, 0.3, cap=320)
+            out.append((bd, nv, n, ls, lb, ub, l0, nr, rs))
+        return out
+
+    a = run()
+    with oracle.portable_math():
+        assert oracle.lib().po_oracle_get_portable_math() == 1
+        c = run()
+    assert oracle.lib().po_oracle_get_portable_math() == 0
+    for (bd, nv, n, ls, lb, ub, l0, nr, rs), (bd2, nv2, n2, ls2, lb2, ub2, l02, nr2, rs2) in zip(a, c):
+        assert nv == nv2 and n == n2 and nr == nr2
+        assert np.abs(bd - bd2).max() < 1e-9
+        if n > 0:
+            assert np.abs(ls - ls2).max() < 1e-9 and np.abs(lb - lb2).max() < 1e-9 and np.abs(ub - ub2).max() < 1e-9 and abs(l0 - l02) < 1e-9
+        for u, v in zip(rs, rs2):
+            assert np.abs(np.asarray(u) - np.asarray(v)).max() < 1e-9
+    at = np.linspace(-1.0, P["knot_s"][0, -1] + 1.0, 50)
+    s1 = oracle.spline_eval(P["knot_s"][0], P["knot_x"][0], at)
+    with oracle.portable_math():
+        s2 = oracle.spline_eval(P["knot_s"][0], P["knot_x"][0], at)
+    assert _ulps(s2, s1).max() <= 16 and np.abs(s2 - s1).max() < 1e-12  # the two elimination orders of the same tridiagonal system
+
+
+@pytest.mark.gpu
+def test_device_map_stages_are_bit_identical_to_the_portable_oracle(oracle):
+    from path_optimizer_amd import binding
+
+    nb = 96
+    d, res, px, py, _ = synth.make_distance_map(**GP.MAP_ARGS)
+    m = oracle.make_map(d, res, px, py)
+    eng = binding.Engine(0)
+    eng.set_map(d, res, px, py)
+    P = synth.make_spline_paths(GB.SEED + 2, nb, GB.N)
+    p = oracle.default_params()
+    bd, nv = eng.bounds_batch(P)
+    dm = synth.make_distance_map(3, **MAP_KW)
+    om = oracle.make_map(*dm[:4])
+    sp, length, start = synth.make_search_inputs(17, nb)
+    with oracle.portable_math():
+        for b in range(nb):
+            ob, onv = oracle.bounds_path(p, m, *[P[k][b] for k in GB.KEYS])
+            assert nv[b] == onv and np.array_equal(bd[b], ob), b  # every bound of every covering circle, bit for bit
+        eng.set_map(*dm[:4])
+        ls, lb, ub, l0, nl = eng.dp_search_batch(sp, length, start, 64)
+        out = eng.resample_batch(sp, length, 0.15, 0.3, 320)
+        for b in range(nb):
+            n, ols, olb, oub, ol0 = oracle.dp_search(p, om, sp["knot_s"][b], sp["knot_x"][b], sp["knot_y"][b], length[b], start[b], cap=64)
+            assert nl[b] == n and l0[b] == ol0
+            if n > 0:
+                assert np.array_equal(ls[b, :n], ols) and np.array_equal(lb[b, :n], olb) and np.array_equal(ub[b, :n], oub), b
+            nr, oo = oracle.resample(p, sp["knot_s"][b], sp["knot_x"][b], sp["knot_y"][b], length[b], 0.15, 0.3, cap=320)
+            assert out["n_points"][b] == nr
+            for key, ov in zip(("ref_x", "ref_y", "ref_z", "ref_k", "ref_s"), oo):
+                assert np.array_equal(out[key][b, :nr], ov), (b, key)
+        # collision decisions on arbitrary states
+        rng = np.random.default_rng(4)
+        states = np.zeros((8, 64, 5))
+        states[..., 0] = rng.uniform(-40, 40, (8, 64)); states[..., 1] = rng.uniform(-40, 40, (8, 64)); states[..., 2] = rng.uniform(-np.pi, np.pi, (8, 64))
+        states[..., 4] = np.arange(64) * 0.5
+        info = np.zeros(8, dtype=binding.INFO_DTYPE); info["status"] = 1
+        nk, ok = eng.postcheck_batch(states, info)
+        onk, ook = oracle.postcheck_batch(p, om, states, info)
+        assert np.array_equal(nk, onk) and np.array_equal(ok, ook)

@@ -13,6 +13,8 @@ from oracle import oracle_py as O  # noqa: E402
 from path_optimizer_amd import binding, synth  # noqa: E402
 
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+O.set_portable_math(len(sys.argv) > 2 and sys.argv[2] == "portable")
+print("oracle portable math:", O.lib().po_oracle_get_portable_math())
 d, res, px, py, _ = synth.make_distance_map(**GP.MAP_ARGS)
 m = O.make_map(d, res, px, py)
 eng = binding.Engine(0)
@@ -40,7 +42,14 @@ for b in range(nb):
         ident += nl[b] == n
         continue
     e = max(np.abs(lb[b, :n] - olb).max(), np.abs(ub[b, :n] - oub).max(), np.abs(ls[b, :n] - ols).max())
-    bit = np.array_equal(lb[b, :n], olb) and np.array_equal(ub[b, :n], oub)
+    bit = np.array_equal(lb[b, :n], olb) and np.array_equal(ub[b, :n], oub) and np.array_equal(ls[b, :n], ols) and l0[b] == ol0
+    nbit = nbit + bit if "nbit" in dir() else int(bit)
     ident += e < 1e-9
     if e >= 1e-9: bad.append((b, float(e)))
-print(f"dp_search: paths {nb}  n_layers equal {nlsame}  corridors within 1e-9: {ident}  differing: {bad[:10]}")
+print(f"dp_search: paths {nb}  n_layers equal {nlsame}  corridors within 1e-9: {ident}  bit-identical (layers, corridor, offset): {nbit}  differing: {bad[:10]}")
+out = eng.resample_batch(sp, length, 0.15, 0.3, 320)
+rb = 0
+for b in range(nb):
+    n, oo = O.resample(p, sp["knot_s"][b], sp["knot_x"][b], sp["knot_y"][b], length[b], 0.15, 0.3, cap=320)
+    rb += out["n_points"][b] == n and all(np.array_equal(out[k][b, :n], ov) for k, ov in zip(("ref_x", "ref_y", "ref_z", "ref_k", "ref_s"), oo))
+print(f"resample: paths {nb}  bit-identical states: {rb}")
