@@ -305,6 +305,74 @@ template <int KIND> __device__ __forceinline__ void band_solve(Prob<KIND> &pb) {
     }
 }
 
+// L D L' x = wk, in place, on W + 0 cooperating lanes (lanes 0..W-1; the other lanes of the wave mirror lane 0 and store the same values).
+// The W pending right-hand sides of the sliding window live one per LANE instead of one per register of a single lane: at column j the owner lane
+// (j mod W) holds the finished y_j, every lane takes it with a v_readlane broadcast (the lane index is a compile-time constant after unrolling by W)
+// and applies ITS entry of factor column j — one FMA per lane per column instead of W on one lane; the owner then picks up the row that enters
+// the window.  The backward sweep is the same recursion on L' run column-wise from the far end (pending sums of the W rows below the current one).
+// Factor entries and the entering right-hand sides of the NEXT block of W columns are requested before the current block is processed.
+__device__ __forceinline__ double lane_bcast(double v, int k) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), k), hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+    return __hiloint2double(hi, lo);
+}
+template <int KIND> __device__ __forceinline__ void band_solve_lanes(Prob<KIND> &pb, int lane) {
+    using T = ST<KIND>;
+    constexpr int W = T::W, LS = Prob<KIND>::LS;
+    const int l = lane < W ? lane : 0;
+    const int nsteps = (pb.n + W - 1) / W * W;  // whole blocks of W columns; the zero padding (col_pad) covers the over-run
+    const double *__restrict__ Lb = pb.Lb;
+    double *__restrict__ wk = pb.wk;
+    int ent[W];  // this lane's entry of the factor column at in-block position uu: row offset d = (l - uu) mod W, d == 0 -> the entering row (offset W)
+#pragma unroll
+    for (int uu = 0; uu < W; ++uu) { const int d = (l - uu + W) % W; ent[uu] = d == 0 ? W : d; }
+    // ---- forward: L y = b, then y <- D^-1 y (stored) ----
+    double w = wk[l];
+    double cf[W], bn[W], dn[W], cf2[W], bn2[W], dn2[W];
+#pragma unroll
+    for (int uu = 0; uu < W; ++uu) { cf[uu] = Lb[uu * LS + ent[uu]]; bn[uu] = wk[uu + W]; dn[uu] = Lb[uu * LS]; }
+    for (int j0 = 0; j0 < nsteps; j0 += W) {
+#pragma unroll
+        for (int uu = 0; uu < W; ++uu) { const int j = j0 + W + uu; cf2[uu] = Lb[j * LS + ent[uu]]; bn2[uu] = wk[j + W]; dn2[uu] = Lb[j * LS]; }
+#pragma unroll
+        for (int uu = 0; uu < W; ++uu) {
+            const double yj = lane_bcast(w, uu);
+            wk[j0 + uu] = yj * dn[uu];
+            w = (l == uu ? bn[uu] : w) - cf[uu] * yj;
+        }
+#pragma unroll
+        for (int uu = 0; uu < W; ++uu) { cf[uu] = cf2[uu]; bn[uu] = bn2[uu]; dn[uu] = dn2[uu]; }
+    }
+    // ---- backward: L' x = y, column-wise from the end: lane (r mod W) holds z_r minus the contributions of the solved rows below r ----
+    // at row j the owner lane (j mod W) is final; lane l holds row j - d, d = (uu - l) mod W, and subtracts L[j][j - d] x_j = Lb[(j - d) LS + d] x_j;
+    // the owner (d == 0) then takes the row that enters the window, j - W, with its entry Lb[(j - W) LS + W].
+    int entb[W];
+#pragma unroll
+    for (int uu = 0; uu < W; ++uu) { const int d = (uu - l + W) % W; entb[uu] = d == 0 ? W : d; }
+    w = wk[nsteps - W + l];
+    auto loadb = [&](int j0, double (&c)[W], double (&zn)[W]) {
+#pragma unroll
+        for (int uu = 0; uu < W; ++uu) {
+            const int j = j0 + uu, r = j - entb[uu];
+            const bool ok = r >= 0;
+            const double cv = Lb[(ok ? r : 0) * LS + entb[uu]], zv = wk[j - W >= 0 ? j - W : 0];
+            c[uu] = ok ? cv : 0.0;
+            zn[uu] = j - W >= 0 ? zv : 0.0;
+        }
+    };
+    loadb(nsteps - W, cf, bn);
+    for (int j0 = nsteps - W; j0 >= 0; j0 -= W) {
+        loadb(j0 - W >= 0 ? j0 - W : 0, cf2, bn2);
+#pragma unroll
+        for (int uu = W - 1; uu >= 0; --uu) {
+            const double xj = lane_bcast(w, uu);
+            wk[j0 + uu] = xj;
+            w = (l == uu ? bn[uu] : w) - cf[uu] * xj;
+        }
+#pragma unroll
+        for (int uu = 0; uu < W; ++uu) { cf[uu] = cf2[uu]; bn[uu] = bn2[uu]; }
+    }
+}
+
 #define PO_TICK(slot)                                                   \
     do {                                                                \
         if (a.dbg_cycles) { const long long t_ = clock64(); acc_[slot] += t_ - tprev_; tprev_ = t_; } \
@@ -505,7 +573,10 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
         }
         __syncthreads();
         PO_TICK(2);
-        if (lane == 0) band_solve<KIND>(pb);
+        // wide bands (TENSION, W = 9): one pending row per lane, one FMA per lane and column (35 instead of 40 ms per 4096 QPs); narrow bands (W = 3, 4): the
+        // single-lane window is as fast or faster (measured: TENSION2 14.6 vs 17.2 ms) — the column-to-column latency, not the FMA count, bounds both
+        if constexpr (ST<KIND>::W >= 8) band_solve_lanes<KIND>(pb, lane);
+        else { if (lane == 0) band_solve<KIND>(pb); }
         __syncthreads();
         PO_TICK(3);
         for (int r = lane; r < m; r += 64) {  // ztilde = A xtilde ; v += alpha (ztilde - z)
