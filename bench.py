@@ -321,6 +321,41 @@ def stage_legs_cpu(st, ctx):
     st["cpu_port"]["resample_paths_per_s"] = 64 / (time.perf_counter() - c5)
 
 
+def live_traffic(batch_paths, timeout_s=150):
+    """HBM traffic of the solve kernel measured IN THIS RUN: two rocprofv3 PMC child passes (FETCH_SIZE, WRITE_SIZE — separate passes, counters only, as
+    MI355X_MICROARCH.md prescribes) over `bench.py --traffic-child` (3 solves of the same batch).  Returns None when rocprofv3 is missing, fails or times out
+    (the bench line then falls back to the committed profiles/traffic_latest.json)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="po_pmc_", dir="/tmp")
+            cmd = [exe, "--output-format", "csv", "--pmc", ctr, "-d", d, "-o", "t", "--", sys.executable, os.path.abspath(__file__), "--traffic-child", "--batch", str(batch_paths)]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            tot, disp = 0.0, set()
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "solve_kernel_fast<0, 4, 64, true, true" in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
+                        tot += float(row["Counter_Value"]); disp.add(row["Dispatch_Id"])
+            shutil.rmtree(d, ignore_errors=True)
+            if r.returncode != 0 or not disp:
+                return None
+            vals[ctr] = tot / len(disp) * 1024.0  # KB units
+        return {"hbm_bytes_per_launch": 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "fetch_bytes_raw": vals["FETCH_SIZE"], "write_bytes": vals["WRITE_SIZE"],
+                "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM section)",
+                "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes over 3 solves of the same batch"}
+    except Exception:
+        return None
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # CPU legs (after the GPU legs: `gpu_done_s` marks the boundary for the driver's gpu_busy sampling)
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -442,11 +477,23 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the accuracy / parity legs")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="paths timed on the CPU oracle (rank 0, N=1 only; 0 = no CPU legs)")
     ap.add_argument("--gather", action="store_true", help="N>1: gather every rank's states and info on rank 0 (SURVEY §8e collective 1) and report its time")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 PMC child passes that measure `roofline.traffic` in this run")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dry-run", action="store_true", help="no GPU: gloo backend, faked device times; exercises the shard split, reductions, gather and JSON "
                     "assembly of the N>1 branch (tests/test_multi_process.py)")
     args = ap.parse_args()
 
     import torch
+
+    if args.traffic_child:  # profiled by live_traffic(): three solves of the batch, nothing else
+        from path_optimizer_amd import binding, synth
+
+        db = binding.DeviceBatch(synth.make_batch(3, B=args.batch))
+        eng = binding.Engine(0)
+        for _ in range(3):
+            eng.solve_batch_device(db)
+        torch.cuda.synchronize()
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -633,6 +680,12 @@ def main():
         stage_ctx = None
         if not args.no_stages:
             out["stages"], stage_ctx = stage_legs_gpu(torch, binding, synth, engs[0], streams[0], dbatch, B)
+        if not args.no_live_traffic:
+            lt = live_traffic(B)
+            if lt is not None:
+                out["roofline"]["traffic"] = lt["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_note"] = lt["source"] + f" (FETCH_SIZE {lt['fetch_bytes_raw'] / 1e6:.1f} MB x 2 + WRITE_SIZE {lt['write_bytes'] / 1e6:.1f} MB; compulsory I/O {8 * (18 * N + 8) * B / 1e6:.1f} MB)"
+                out["roofline"]["traffic_GBps"] = lt["hbm_bytes_per_launch"] / (out["single_batch"]["median_ms"] * 1e-3) / 1e9
         torch.cuda.synchronize()
         out["gpu_done_s"] = time.time()  # everything after this timestamp is host-only (CPU baseline / checker legs)
         if args.cpu_sample > 0:
