@@ -322,7 +322,7 @@ def stage_legs_cpu(st, ctx):
 
 
 def live_traffic(batch_paths, timeout_s=150):
-    """HBM traffic of the solve kernel measured IN THIS RUN: two rocprofv3 PMC child passes (FETCH_SIZE, WRITE_SIZE — separate passes, counters only, as
+    """HBM traffic (and the VALU instruction count) of the solve kernel measured IN THIS RUN: three rocprofv3 PMC child passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU — separate passes, counters only, as
     MI355X_MICROARCH.md prescribes) over `bench.py --traffic-child` (3 solves of the same batch).  Returns None when rocprofv3 is missing, fails or times out
     (the bench line then falls back to the committed profiles/traffic_latest.json)."""
     import csv
@@ -336,7 +336,7 @@ def live_traffic(batch_paths, timeout_s=150):
         return None
     vals = {}
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
             d = tempfile.mkdtemp(prefix="po_pmc_", dir="/tmp")
             cmd = [exe, "--output-format", "csv", "--pmc", ctr, "-d", d, "-o", "t", "--", sys.executable, os.path.abspath(__file__), "--traffic-child", "--batch", str(batch_paths)]
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
@@ -348,8 +348,9 @@ def live_traffic(batch_paths, timeout_s=150):
             shutil.rmtree(d, ignore_errors=True)
             if r.returncode != 0 or not disp:
                 return None
-            vals[ctr] = tot / len(disp) * 1024.0  # KB units
+            vals[ctr] = tot / len(disp) * (1.0 if ctr.startswith("SQ_") else 1024.0)  # FETCH / WRITE in KB units
         return {"hbm_bytes_per_launch": 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "fetch_bytes_raw": vals["FETCH_SIZE"], "write_bytes": vals["WRITE_SIZE"],
+                "valu_wave_instr_per_launch": vals["SQ_INSTS_VALU"],
                 "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM section)",
                 "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes over 3 solves of the same batch"}
     except Exception:
@@ -686,6 +687,7 @@ def main():
                 out["roofline"]["traffic"] = lt["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_note"] = lt["source"] + f" (FETCH_SIZE {lt['fetch_bytes_raw'] / 1e6:.1f} MB x 2 + WRITE_SIZE {lt['write_bytes'] / 1e6:.1f} MB; compulsory I/O {8 * (18 * N + 8) * B / 1e6:.1f} MB)"
                 out["roofline"]["traffic_GBps"] = lt["hbm_bytes_per_launch"] / (out["single_batch"]["median_ms"] * 1e-3) / 1e9
+                out["roofline"]["valu_wave_instr_per_path_iter"] = lt["valu_wave_instr_per_launch"] / float(info["iters"].sum())  # SQ_INSTS_VALU of this run
         torch.cuda.synchronize()
         out["gpu_done_s"] = time.time()  # everything after this timestamp is host-only (CPU baseline / checker legs)
         if args.cpu_sample > 0:
