@@ -332,7 +332,10 @@ int po_segment_init_batch_device(po_handle h, const po_spline_in *spline, const 
  *   4 post smoothing, 5 segmentation (heading error > 75 deg), 6 reference blocked at its start, 7 path QP, 8 collision check (states
  *   hold the truncated path), 9 capacity (N / max_length too small or the QP does not fit the on-chip tile).
  *   max_length: upper bound of the waypoint polyline lengths (sizes the intermediate buffers); <= 0: computed from the waypoints
- *   (host-pointer entry only). */
+ *   (host-pointer entry only).
+ *   Limits (the reference has none): max_length up to about 540 m (the spline stages keep 120 x knots bytes in LDS, knots = ceil(max_length) + 6 <= 546;
+ *   beyond that the call returns PO_ERR_UNSUPPORTED for the whole batch); the path QP of an instance must fit the on-chip tile — at the default 0.15 ... 0.3 m
+ *   re-sampling that is a route of roughly 75 m (keep_control_steps_ <= 4: N <= 512) to 150 m; longer instances come back with stage 9, the others are unaffected. */
 typedef struct po_plan_in {
     int B, W;
     const int    *n_way;          /* optional [B] */
