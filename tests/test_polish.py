@@ -98,3 +98,28 @@ def test_device_polish_other_formulations(oracle, form, cfg, B):
     both = ok & ook & same
     assert np.abs(xs[both] - oxs[both]).max() < 1e-6
     assert (info["r_prim"][ok] < 1e-7).all()
+
+
+@pytest.mark.gpu
+def test_device_polish_on_ragged_batches_and_other_keep_values(oracle):
+    """Polish after the general (non-uniform) loop variant, on a ragged batch, and for keep_control_steps_ 2 and 3 (other chunk shapes / multi-wave blocks)."""
+    import np_twin as T
+    from path_optimizer_amd import binding
+
+    for keep, N, ds in ((4, 90, 0.25), (3, 100, 0.3), (2, 70, 0.5)):
+        rng = np.random.default_rng(keep)
+        insts = [T.random_instance(rng, N, ds=ds) for _ in range(10)]
+        stk = lambda k: np.ascontiguousarray(np.stack([i[k] for i in insts]))
+        b = synth.Batch(0, 10, N, keep, stk("ref_x"), stk("ref_y"), stk("ref_z"), stk("ref_k"), stk("ref_s"), stk("bounds"), stk("x0"), np.array([i["goal_z"] for i in insts]))
+        assert binding.keep_control_steps(0, b.ref_s[0]) == keep
+        b.n_points = np.array([N, N - 1, N - 5, N // 2, N, 7, N - 2, N, 31, N], dtype=np.int32)
+        p = binding.default_params()
+        p.polish, p.polish_passes = 1, 4
+        st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
+        ost, oinfo, oxs = oracle.solve_batch(b, oracle.device_equivalent_params(p))
+        assert np.array_equal(info["status"], oinfo["status"])
+        same = (info["iters"] == oinfo["iters"]) & (info["status"] == 1)
+        ok, ook = info["status_polish"] == 1, oinfo["status_polish"] == 1
+        assert (ok == ook)[same].mean() >= 0.8, (keep, ok, ook)
+        both = ok & ook & same
+        assert both.sum() >= 3 and np.abs(xs[both] - oxs[both]).max() < 1e-6 and np.abs(st[both] - ost[both]).max() < 1e-6, keep
