@@ -175,6 +175,16 @@ def accuracy_legs(torch, binding, synth, batch, dev, stream, cpu_sample):
             p.polish_passes = passes
         res["settings"].append(run("eps 1e-4 + polish (OSQP: 1 pass)", lambda p: pol(p, 1))[0])
         res["settings"].append(run("eps 1e-4 + polish (active-set passes <= 6)", lambda p: pol(p, 6))[0])
+    if any(f[0] == "refine" for f in PoParams._fields_):  # activity-weighted continuation of the ADMM iteration (po_params.refine), alone and before the polish
+        def ref(p, eps, passes):
+            p.eps_abs = p.eps_rel = eps
+            p.refine = 1
+            if passes:
+                p.polish, p.polish_passes = 1, passes
+        res["settings"].append(run("eps 1e-4 + refine", lambda p: ref(p, 1e-4, 0))[0])
+        res["settings"].append(run("eps 1e-4 + refine + polish (<= 6 passes)", lambda p: ref(p, 1e-4, 6))[0])
+        res["settings"].append(run("eps 3e-4 + refine", lambda p: ref(p, 3e-4, 0))[0])
+        res["settings"].append(run("eps 3e-4 + refine + polish (<= 6 passes)", lambda p: ref(p, 3e-4, 6))[0])
     for eps in (1e-5, 1e-6, 1e-7):
         def tight(p, eps=eps):
             p.eps_abs = p.eps_rel = eps

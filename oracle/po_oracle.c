@@ -94,6 +94,7 @@ void po_oracle_default_params(po_params *p) {
     p->enable_dynamic_segmentation = 1;
     p->enable_raw_output = 1; p->output_spacing = 0.3; /* planning_flags.cpp:127-129 */
     p->polish = 0; p->polish_delta = 1e-6; p->polish_refine_iter = 3; p->polish_passes = 1; /* OSQP defaults (polish off) */
+    p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 16; p->refine_rho = 10.0; p->refine_eps = 1e-6;
 }
 
 /* tools.hpp:24-35 — recursive in the reference; same fixed point as this loop */
@@ -1161,6 +1162,83 @@ int po_oracle_qp_solve_ext(int n, int m, const int *Pp0, const int *Pi0, const d
     info->r_prim = pri_res;
     info->r_dual = dua_res;
     info->rho = rho;
+    /* ---- refinement (po_params.refine; extension, not OSQP): the same ADMM iteration continued with the step vector set by activity (see po_hip.h) ---- */
+    if (prm->refine && info->status == PO_STATUS_SOLVED) {
+        const double rb = prm->refine_rho < OSQP_RHO_MIN ? OSQP_RHO_MIN : (prm->refine_rho > OSQP_RHO_MAX ? OSQP_RHO_MAX : prm->refine_rho);
+        const int every = prm->refine_every > 0 ? prm->refine_every : 10;
+        int nfac = 0, it2 = 0, frozen = 0, stop = 0;
+        double *snap = (double *)malloc(sizeof(double) * (size_t)(n + 2 * m)); /* the solved point: kept if the phase does not end at least as well */
+        const double pri0 = pri_res, dua0 = dua_res;
+        memcpy(snap, x, sizeof(double) * (size_t)n);
+        memcpy(snap + n, z, sizeof(double) * (size_t)m);
+        memcpy(snap + n + m, y, sizeof(double) * (size_t)m);
+        for (;;) {
+            /* step vector from the bound type (as set_rho_vec) and, for inequality rows, from activity: z at a bound with a multiplier of the matching sign.
+             * Once the refactorisation budget is spent (an active set that keeps flipping) the vector goes back to the type-based one and stays. */
+            int changed = 0;
+            if (!frozen) {
+                if (nfac >= prm->refine_max_refactor) frozen = 1;
+                for (int i = 0; i < m; ++i) {
+                    double r;
+                    if (ctype[i] == -1) r = OSQP_RHO_MIN;
+                    else if (ctype[i] == 1) r = OSQP_RHO_EQ_OVER_INEQ * rb;
+                    else r = (frozen || (z[i] <= l[i] && y[i] < 0) || (z[i] >= u[i] && y[i] > 0) || (2 * nfac >= prm->refine_max_refactor && rho_vec[i] == rb)) ? rb : OSQP_RHO_MIN;
+                    if (r != rho_vec[i]) { rho_vec[i] = r; changed = 1; }
+                }
+            }
+            if (changed) {
+                for (int i = 0; i < m; ++i) { rho_inv[i] = 1.0 / rho_vec[i]; K.Kx[K.rho_pos[i]] = -rho_inv[i]; }
+                if (ldl_numeric(&F, K.Kp, K.Ki, K.Kx)) { free(snap); rc = PO_ERR_INVALID; goto done; }
+                ++nfac;
+            }
+            stop = 0;
+            for (int k = 0; k < every && it2 < prm->refine_max_iter; ++k) {
+                ++it2;
+                memcpy(x_prev, x, sizeof(double) * (size_t)n);
+                memcpy(z_prev, z, sizeof(double) * (size_t)m);
+                for (int i = 0; i < n; ++i) rhs[pinv[i]] = sigma * x_prev[i] - q[i];
+                for (int i = 0; i < m; ++i) rhs[pinv[n + i]] = z_prev[i] - rho_inv[i] * y[i];
+                ldl_solve(&F, rhs);
+                for (int i = 0; i < n; ++i) x[i] = alpha * rhs[pinv[i]] + (1.0 - alpha) * x_prev[i];
+                for (int i = 0; i < m; ++i) {
+                    const double zt = z_prev[i] + rho_inv[i] * (rhs[pinv[n + i]] - y[i]);
+                    const double zr = alpha * zt + (1.0 - alpha) * z_prev[i];
+                    const double v = zr + rho_inv[i] * y[i];
+                    z[i] = v < l[i] ? l[i] : (v > u[i] ? u[i] : v);
+                    y[i] += rho_vec[i] * (zr - z[i]);
+                }
+            }
+            /* OSQP's termination test (unscaled residuals) at refine_eps */
+            csc_mv(n, m, Ap0, Ai0, Ax, x, Axv);
+            sym_mv(n, Pp0, Pi0, Px, x, Pxv);
+            csc_mtv(n, Ap0, Ai0, Ax, y, Aty);
+            for (int i = 0; i < m; ++i) tm[i] = Axv[i] - z[i];
+            for (int i = 0; i < n; ++i) tn[i] = Pxv[i] + q[i] + Aty[i];
+            pri_res = vnorm_inf_scaled(Einv, tm, m);
+            dua_res = cinv * vnorm_inf_scaled(Dinv, tn, n);
+            {
+                const double nz = vnorm_inf_scaled(Einv, z, m), nAx = vnorm_inf_scaled(Einv, Axv, m);
+                const double nAty = vnorm_inf_scaled(Dinv, Aty, n), nPx = vnorm_inf_scaled(Dinv, Pxv, n), nq = vnorm_inf_scaled(Dinv, q, n);
+                double dn = nq > nAty ? nq : nAty;
+                dn = dn > nPx ? dn : nPx;
+                stop = pri_res < prm->refine_eps + prm->refine_eps * (nz > nAx ? nz : nAx) && dua_res < prm->refine_eps + prm->refine_eps * cinv * dn;
+            }
+            if (stop || it2 >= prm->refine_max_iter) break;
+        }
+        info->iters += it2;
+        info->n_refactor += nfac;
+        if (stop || (pri_res <= pri0 && dua_res <= dua0)) {
+            info->r_prim = pri_res;
+            info->r_dual = dua_res;
+        } else { /* out of iterations and not better than the solved point: keep that one */
+            memcpy(x, snap, sizeof(double) * (size_t)n);
+            memcpy(z, snap + n, sizeof(double) * (size_t)m);
+            memcpy(y, snap + n + m, sizeof(double) * (size_t)m);
+            pri_res = pri0;
+            dua_res = dua0;
+        }
+        free(snap);
+    }
     /* ---- polish (OSQP polish.c, on the scaled problem like OSQP): reduced KKT system on the active set with the regularisation
      * +-delta, polish_refine_iter steps of iterative refinement, normal-cone projection, OSQP's acceptance rule.  polish_passes > 1
      * (extension, not OSQP): the active set is re-derived from the polished point and the solve repeated until it reproduces itself. ---- */

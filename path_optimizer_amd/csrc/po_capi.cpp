@@ -115,6 +115,7 @@ void po_default_params(po_params *p) {
     p->enable_dynamic_segmentation = 1;
     p->enable_raw_output = 1; p->output_spacing = 0.3; /* planning_flags.cpp:127-129 */
     p->polish = 0; p->polish_delta = 1e-6; p->polish_refine_iter = 3; p->polish_passes = 1;  /* OSQP defaults (polish off) */
+    p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 16; p->refine_rho = 10.0; p->refine_eps = 1e-6;
 }
 
 int po_problem_dims(int form, int N, int keep, int *n, int *m, int *C) {
@@ -211,6 +212,8 @@ static int make_dev_params(const po_handle_s *h, int form, int keep, po::DevPara
     D->end_heading = p.constraint_end_heading;
     D->polish = p.polish; D->pol_delta = p.polish_delta > 0 ? p.polish_delta : 1e-6; D->pol_refine = p.polish_refine_iter < 0 ? 0 : p.polish_refine_iter;
     D->pol_passes = p.polish_passes;
+    D->refine = p.refine; D->ref_every = p.refine_every > 0 ? p.refine_every : 10; D->ref_max_iter = p.refine_max_iter; D->ref_max_refactor = p.refine_max_refactor;
+    D->ref_rho = p.refine_rho; D->ref_eps = p.refine_eps;
     return PO_OK;
 }
 
@@ -265,7 +268,7 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     if ((rc = h->scale_buf.ensure(sizeof(double) * 64 * (size_t)in->B))) return rc;
     D.scale = static_cast<double *>(h->scale_buf.p);
     bool polish = false;
-    if (h->params.polish) {  // OSQP's polish, opt-in: the solve kernels leave their ADMM state in pol_buf, polish_kernel picks it up
+    if (h->params.polish || h->params.refine) {  // OSQP's polish, opt-in: the solve kernels leave their ADMM state in pol_buf, polish_kernel picks it up
         const int sd = po_polish_state_doubles(in->formulation, in->N, C, in->keep);
         if (sd > 0) {  // (shapes on the single-level mapping have no polish kernel: status_polish stays 0 = not attempted)
             if ((rc = h->pol_buf.ensure(sizeof(double) * (size_t)sd * (size_t)in->B))) return rc;
@@ -283,7 +286,7 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     // per-path equilibration (h->params.scaling class-level Ruiz passes; 0 -> identity), then the fused solve
     HIP_TRY(po_launch_scale(in->formulation, &D, &P, h->params.scaling, static_cast<double *>(h->scale_buf.p), h->stream));
     HIP_TRY(po_launch_solve(in->formulation, &D, &P, h->stream, nullptr));
-    if (polish) HIP_TRY(po_launch_polish(in->formulation, &D, &P, h->stream));
+    if (polish && h->params.polish) HIP_TRY(po_launch_polish(in->formulation, &D, &P, h->stream));
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     if (dbg) {

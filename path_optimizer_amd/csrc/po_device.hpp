@@ -34,6 +34,8 @@ struct DevParams {
     int max_iter, check_every, adapt_every, end_heading;
     double pol_delta;           // OSQP delta
     int polish, pol_refine, pol_passes;
+    int refine, ref_every, ref_max_iter, ref_max_refactor;  // po_params.refine*
+    double ref_rho, ref_eps;
 };
 
 struct DevBatch {

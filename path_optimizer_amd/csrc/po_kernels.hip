@@ -56,6 +56,7 @@ template <int F> __global__ __launch_bounds__(64) void assemble_kernel(DevBatch 
 PO_DECL(po_launch_solve_kp); PO_DECL(po_launch_solve_kp_uni);
 PO_DECL(po_launch_solve_kpc); PO_DECL(po_launch_solve_kpc_uni);
 PO_DECL(po_launch_solve_k); PO_DECL(po_launch_solve_k_uni);
+PO_DECL(po_launch_solve_kp_uni_ref); PO_DECL(po_launch_solve_kpc_uni_ref); PO_DECL(po_launch_solve_k_uni_ref);
 #undef PO_DECL
 
 // Two launches on the same stream for the two-level mapping: the uniform-row-class variant first (solves what it can, defers the rest),
@@ -63,9 +64,10 @@ PO_DECL(po_launch_solve_k); PO_DECL(po_launch_solve_k_uni);
 extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out) {
     using namespace po;
     hipError_t e;
-    if (form == F_KP) { e = po_launch_solve_kp_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kp(in, P, st, lds_out); }
-    if (form == F_KPC) { e = po_launch_solve_kpc_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kpc(in, P, st, lds_out); }
-    e = po_launch_solve_k_uni(in, P, st, lds_out);
+    const bool ref = P->refine != 0;  // the uniform variant that carries the refinement phase (the general variant always does)
+    if (form == F_KP) { e = ref ? po_launch_solve_kp_uni_ref(in, P, st, lds_out) : po_launch_solve_kp_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kp(in, P, st, lds_out); }
+    if (form == F_KPC) { e = ref ? po_launch_solve_kpc_uni_ref(in, P, st, lds_out) : po_launch_solve_kpc_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kpc(in, P, st, lds_out); }
+    e = ref ? po_launch_solve_k_uni_ref(in, P, st, lds_out) : po_launch_solve_k_uni(in, P, st, lds_out);
     return e != hipSuccess ? e : po_launch_solve_k(in, P, st, lds_out);
 }
 

@@ -131,7 +131,9 @@ inline bool resolve_shape(int form, int N, int C, int keep, Shape *s) {
 }
 // UNI = true: the uniform-row-class variant of the two-level kernels (no-op for shapes that use the single-level mapping and for K on multi-wave blocks); UNI = false: the general variant.  po_launch_solve issues them in this order on one stream.
 template <int F> inline bool has_uni_variant(const Shape &s) { return s.two && (F != F_K || s.nt == 64); }  // K: one-wave blocks only (Fast::classify)
-template <int F, bool UNI> hipError_t launch_form(const DevBatch *in_, const DevParams *P, hipStream_t st, size_t *lds_out) {
+// REF: kernels that carry the refinement phase (po_params.refine) after the loop — the uniform variant exists with and without (the phase costs the hot loop
+// ~4 % even when it is not taken), the general variant only with.
+template <int F, bool UNI, bool REF> hipError_t launch_form(const DevBatch *in_, const DevParams *P, hipStream_t st, size_t *lds_out) {
     Shape s;
     if (!resolve_shape(F, in_->N, in_->C, in_->keep, &s)) return hipErrorInvalidValue;
     const size_t lds = lds_bytes_fast<F>(in_->N, in_->C, s.spl, s.two, s.nt);
@@ -140,7 +142,7 @@ template <int F, bool UNI> hipError_t launch_form(const DevBatch *in_, const Dev
     DevBatch copy = *in_;
     copy.only_deferred = (!UNI && has_uni_variant<F>(s)) ? 1 : 0;
     const DevBatch *in = &copy;
-#define PO_L(SPL_, NT_, TWO_) return launch1(&solve_kernel_fast<F, SPL_, NT_, TWO_, UNI && TWO_>, in, P, NT_, lds, st)
+#define PO_L(SPL_, NT_, TWO_) return launch1(&solve_kernel_fast<F, SPL_, NT_, TWO_, UNI && TWO_, REF>, in, P, NT_, lds, st)
     if constexpr (UNI) {
         if (!has_uni_variant<F>(s)) return hipSuccess;
     }

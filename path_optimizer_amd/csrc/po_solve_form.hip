@@ -14,14 +14,19 @@
 #else
 #define PO_ENTRY_BASE po_launch_solve_k
 #endif
-#if PO_UNI
+#ifndef PO_REF
+#define PO_REF 0
+#endif
+#if PO_UNI && PO_REF  // the uniform variant with the refinement phase (po_params.refine): its own object
+#define PO_ENTRY PO_CAT(PO_ENTRY_BASE, _uni_ref)
+#elif PO_UNI
 #define PO_ENTRY PO_CAT(PO_ENTRY_BASE, _uni)
 #else
 #define PO_ENTRY PO_ENTRY_BASE
 #endif
 
 extern "C" hipError_t PO_ENTRY(const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out) {
-    return po::launch_form<PO_FORM, PO_UNI != 0>(in, P, st, lds_out);
+    return po::launch_form<PO_FORM, PO_UNI != 0, (PO_REF != 0) || (PO_UNI == 0)>(in, P, st, lds_out);
 }
 
 #if !PO_UNI  // the polish kernels of this formulation build with the general-variant object
