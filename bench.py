@@ -183,6 +183,7 @@ def accuracy_legs(torch, binding, synth, batch, dev, stream, cpu_sample):
                 p.polish, p.polish_passes = 1, passes
         res["settings"].append(run("eps 1e-4 + refine", lambda p: ref(p, 1e-4, 0))[0])
         res["settings"].append(run("eps 1e-4 + refine + polish (<= 6 passes)", lambda p: ref(p, 1e-4, 6))[0])
+        res["settings"].append(run("eps 1.5e-4 + refine", lambda p: ref(p, 1.5e-4, 0))[0])
         res["settings"].append(run("eps 3e-4 + refine", lambda p: ref(p, 3e-4, 0))[0])
         res["settings"].append(run("eps 3e-4 + refine + polish (<= 6 passes)", lambda p: ref(p, 3e-4, 6))[0])
     for eps in (1e-5, 1e-6, 1e-7):
@@ -688,6 +689,9 @@ def main():
             ok99 = [s for s in acc["settings"] if s.get("e_y_rms_vs_exact_optimum_m", {}).get("frac_le_1e-4", 0) >= 0.99]
             out["parity"]["first_setting_with_99pct_within_1e-4_m"] = ok99[0]["setting"] if ok99 else None
             out["parity"]["paths_per_s_at_that_setting"] = ok99[0]["paths_per_s"] if ok99 else None
+            best = max(ok99, key=lambda s: s["paths_per_s"]) if ok99 else None
+            out["parity"]["fastest_setting_with_99pct_within_1e-4_m"] = None if best is None else {
+                "setting": best["setting"], "paths_per_s": best["paths_per_s"], "cost_vs_benchmarked_setting": best["paths_per_s"] / acc["settings"][0]["paths_per_s"] - 1.0}
         stage_ctx = None
         if not args.no_stages:
             out["stages"], stage_ctx = stage_legs_gpu(torch, binding, synth, engs[0], streams[0], dbatch, B)
