@@ -1,0 +1,76 @@
+"""Randomised parity sweep (GPU): formulation, path length, spacing (-> keep_control_steps_), ragged lengths, corridor widths and the whole parameter block
+(weights, vehicle limits, sigma / alpha / rho0, scaling passes, adaption and check intervals, end-heading constraint) drawn per case from a fixed seed; the
+device against the oracle at identical settings — fixed-iteration iterates at round-off level, then the full run with every path compared."""
+import numpy as np
+import pytest
+
+import np_twin as T
+from path_optimizer_amd import synth
+from test_gpu_parity import _compare_every_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    form = int(rng.choice([T.PO_KP, T.PO_KP, T.PO_KPC, T.PO_K]))
+    ds = float(rng.choice([0.15, 0.2, 0.25, 0.3, 0.4, 0.5, 0.6, 1.0])) if form == T.PO_KP else 0.25
+    N = int(rng.integers(6, 260)) if form != T.PO_KPC else int(rng.integers(6, 200))
+    B = 5
+    narrow = bool(rng.integers(0, 2))
+    insts = [T.random_instance(rng, N, ds=ds, narrow=narrow) for _ in range(B)]
+    stk = lambda k: np.ascontiguousarray(np.stack([i[k] for i in insts]))
+    b = synth.Batch(form, B, N, 4, stk("ref_x"), stk("ref_y"), stk("ref_z"), stk("ref_k"), stk("ref_s"), stk("bounds"), stk("x0"),
+                    np.array([i["goal_z"] for i in insts]), stk("max_k") if form == T.PO_KPC else None, stk("max_kp") if form == T.PO_KPC else None)
+    if rng.integers(0, 2):
+        npts = rng.integers(max(3, N // 3), N + 1, size=B).astype(np.int32)
+        npts[0] = N
+        b.n_points = npts
+    return rng, form, b
+
+
+def _params(rng, make):
+    p = make()
+    lu = lambda lo, hi: float(np.exp(rng.uniform(np.log(lo), np.log(hi))))
+    p.w_curv, p.w_curv_rate, p.w_slack = lu(0.3, 30), lu(0.5, 50), lu(1, 100)
+    p.w_dev = float(rng.choice([0.0, 0.0, lu(0.01, 1.0)]))
+    p.k_w_curv, p.k_w_curv_rate = lu(5, 200), lu(20, 800)
+    p.k_w_dev = float(rng.choice([0.0, lu(0.01, 1.0)]))
+    p.w_k_slack, p.w_kp_slack = lu(50, 5000), lu(2500, 250000)
+    p.margin = float(rng.uniform(0.0, 0.3))
+    p.max_steer = float(rng.uniform(0.4, 0.7))
+    p.wheel_base = float(rng.uniform(2.0, 3.2))
+    p.sigma = lu(1e-7, 1e-5)
+    p.alpha = float(rng.uniform(1.2, 1.8))
+    p.rho0 = lu(0.03, 0.5)
+    p.scaling = int(rng.choice([0, 4, 10, 15]))
+    p.constraint_end_heading = int(rng.integers(0, 2))
+    return p
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_case_matches_oracle(oracle, seed):
+    from path_optimizer_amd import binding
+
+    rng, form, b = _case(seed)
+    if form == T.PO_KP:
+        b.keep = binding.keep_control_steps(form, b.ref_s[0])
+        assert b.keep == oracle.keep_steps(form, b.ref_s[0])
+    st0 = rng.bit_generator.state
+    p = _params(rng, binding.default_params)
+    rng.bit_generator.state = st0
+    po = oracle.device_equivalent_params(_params(rng, binding.default_params))
+    # fixed number of iterations, no termination / adaption: iterates at round-off level
+    for q in (p, po):
+        q.max_iter, q.check_every, q.adapt_every = 50, 0, 0
+    st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
+    ost, oinfo, oxs = oracle.solve_batch(b, po)
+    assert np.abs(xs - oxs).max() < 1e-7, (seed, form, b.N, b.keep, np.abs(xs - oxs).max())
+    # the full run
+    ce, ae = int(rng.choice([10, 25, 40])), int(rng.choice([0, 25, 50, 100]))
+    for q in (p, po):
+        q.max_iter, q.check_every, q.adapt_every = 3000, ce, ae
+    st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
+    ost, oinfo, oxs = oracle.solve_batch(b, po)
+    assert np.array_equal(info["n_refactor"][info["iters"] == oinfo["iters"]], oinfo["n_refactor"][info["iters"] == oinfo["iters"]])
+    _compare_every_path(info, oinfo, xs, oxs, st, ost, 0.6, eps=1e-4, check_every=ce)
