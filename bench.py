@@ -183,7 +183,7 @@ def accuracy_legs(torch, binding, synth, batch, dev, stream, cpu_sample):
                 p.polish, p.polish_passes = 1, passes
         res["settings"].append(run("eps 1e-4 + refine", lambda p: ref(p, 1e-4, 0))[0])
         res["settings"].append(run("eps 1e-4 + refine + polish (<= 6 passes)", lambda p: ref(p, 1e-4, 6))[0])
-        res["settings"].append(run("eps 1.5e-4 + refine", lambda p: ref(p, 1.5e-4, 0))[0])
+        res["settings"].append(run("eps 2e-4 + refine", lambda p: ref(p, 2e-4, 0))[0])
         res["settings"].append(run("eps 3e-4 + refine", lambda p: ref(p, 3e-4, 0))[0])
         res["settings"].append(run("eps 3e-4 + refine + polish (<= 6 passes)", lambda p: ref(p, 3e-4, 6))[0])
     for eps in (1e-5, 1e-6, 1e-7):

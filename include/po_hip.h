@@ -115,11 +115,11 @@ typedef struct po_params {
      * multiplier of the right sign) refine_rho, inactive rows OSQP's RHO_MIN — re-derived every refine_every iterations (numeric refactorisation when it
      * changed, at most refine_max_refactor times), until OSQP's termination test holds at refine_eps or refine_max_iter iterations are spent.  Still ADMM on
      * the same QP (any positive step vector has the same fixed point), but on these nearly flat problems it reaches in tens of iterations what the
-     * type-based vector needs thousands for; followed by the polish it puts >= 99 % of BASELINE config 3 within 1e-4 m of the exact optimum. */
+     * type-based vector needs thousands for; it puts every path of the BASELINE config-3 sample within 1e-4 m of the exact optimum (39 % without). */
     int    refine;
     int    refine_every;                /* 10 */
     int    refine_max_iter;             /* 400 */
-    int    refine_max_refactor;         /* 16: free re-derivation for the first half of this budget, then active rows stay active (the set only grows, which
+    int    refine_max_refactor;         /* 40: free re-derivation for the first half of this budget, then active rows stay active (the set only grows, which
                                            ends any flip-flopping); when it is spent the vector goes back to the bound types at refine_rho */
     double refine_rho;                  /* 10 (scaled problem, like rho0) */
     double refine_eps;                  /* 1e-6: eps_abs = eps_rel of the termination test of this phase */
