@@ -123,6 +123,11 @@ typedef struct po_params {
                                            ends any flip-flopping); when it is spent the vector goes back to the bound types at refine_rho */
     double refine_rho;                  /* 10 (scaled problem, like rho0) */
     double refine_eps;                  /* 1e-6: eps_abs = eps_rel of the termination test of this phase */
+    int    refine_rounds;               /* 1.  R > 1: the solve first stops at 10^(R-1) x (eps_abs, eps_rel) and is refined from there (budget refine_max_iter / 4);
+                                           a path the refinement does not certify at refine_eps goes back to the type-based iteration at a 10 x tighter eps and is
+                                           refined again, down to eps itself (last round: the full budget).  Every path returned satisfies OSQP's test at eps_abs /
+                                           eps_rel or at refine_eps; most never run the slow type-based iteration to the end (BASELINE config 3, R = 3: mean 159
+                                           iterations instead of 340, longest path 925 instead of 1 600) */
 } po_params;
 
 typedef struct po_info {

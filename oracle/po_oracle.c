@@ -94,7 +94,7 @@ void po_oracle_default_params(po_params *p) {
     p->enable_dynamic_segmentation = 1;
     p->enable_raw_output = 1; p->output_spacing = 0.3; /* planning_flags.cpp:127-129 */
     p->polish = 0; p->polish_delta = 1e-6; p->polish_refine_iter = 3; p->polish_passes = 1; /* OSQP defaults (polish off) */
-    p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-6;
+    p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-6; p->refine_rounds = 1;
 }
 
 /* tools.hpp:24-35 — recursive in the reference; same fixed point as this loop */
@@ -1034,7 +1034,14 @@ int po_oracle_qp_solve_ext(int n, int m, const int *Pp0, const int *Pi0, const d
     const double alpha = prm->alpha, sigma = prm->sigma;
     int iter = 0, n_refactor = 0, checked_this_iter = 0;
     double pri_res = 0, dua_res = 0;
-    for (iter = 1; iter <= prm->max_iter; ++iter) {
+    /* po_params.refine_rounds = R > 1: the type-based iteration first stops at 10^(R-1) x eps and hands over to the refinement; a path that one does not
+     * certify comes back here (resume_main) at a 10 x tighter eps, down to eps itself */
+    const int rounds = prm->refine ? (prm->refine_rounds > 1 ? prm->refine_rounds : 1) : 1;
+    int round = 0, refine_its = 0, refine_fac = 0;
+    double eps_mul = 1.0;
+    for (int r_ = 1; r_ < rounds; ++r_) eps_mul *= 10.0;
+resume_main:
+    for (iter = iter + 1; iter <= prm->max_iter; ++iter) {
         memcpy(x_prev, x, sizeof(double) * (size_t)n);
         memcpy(z_prev, z, sizeof(double) * (size_t)m);
         /* update_xz_tilde */
@@ -1080,11 +1087,11 @@ int po_oracle_qp_solve_ext(int n, int m, const int *Pp0, const int *Pi0, const d
         }
         if (can_check || iter == prm->max_iter) {
             double nz = vnorm_inf_scaled(Einv, z, m), nAx = vnorm_inf_scaled(Einv, Axv, m);
-            double eps_prim = prm->eps_abs + prm->eps_rel * (nz > nAx ? nz : nAx);
+            double eps_prim = eps_mul * (prm->eps_abs + prm->eps_rel * (nz > nAx ? nz : nAx));
             double nq = vnorm_inf_scaled(Dinv, q, n), nAty = vnorm_inf_scaled(Dinv, Aty, n), nPx = vnorm_inf_scaled(Dinv, Pxv, n);
             double dn = nq > nAty ? nq : nAty;
             dn = dn > nPx ? dn : nPx;
-            double eps_dual = prm->eps_abs + prm->eps_rel * cinv * dn;
+            double eps_dual = eps_mul * (prm->eps_abs + prm->eps_rel * cinv * dn);
             int prim_ok = pri_res < eps_prim, dual_ok = dua_res < eps_dual; /* strict, as OSQP */
             int prim_inf = 0, dual_inf = 0;
             if (!prim_ok) { /* is_primal_infeasible */
@@ -1167,6 +1174,7 @@ int po_oracle_qp_solve_ext(int n, int m, const int *Pp0, const int *Pi0, const d
         const double rb = prm->refine_rho < OSQP_RHO_MIN ? OSQP_RHO_MIN : (prm->refine_rho > OSQP_RHO_MAX ? OSQP_RHO_MAX : prm->refine_rho);
         const int every = prm->refine_every > 0 ? prm->refine_every : 10;
         int nfac = 0, it2 = 0, frozen = 0, stop = 0;
+        const int cap_it = round + 1 < rounds ? (prm->refine_max_iter / 4 > every ? prm->refine_max_iter / 4 : every) : prm->refine_max_iter;
         double *snap = (double *)malloc(sizeof(double) * (size_t)(n + 2 * m)); /* the solved point: kept if the phase does not end at least as well */
         const double pri0 = pri_res, dua0 = dua_res;
         memcpy(snap, x, sizeof(double) * (size_t)n);
@@ -1192,7 +1200,7 @@ int po_oracle_qp_solve_ext(int n, int m, const int *Pp0, const int *Pi0, const d
                 ++nfac;
             }
             stop = 0;
-            for (int k = 0; k < every && it2 < prm->refine_max_iter; ++k) {
+            for (int k = 0; k < every && it2 < cap_it; ++k) {
                 ++it2;
                 memcpy(x_prev, x, sizeof(double) * (size_t)n);
                 memcpy(z_prev, z, sizeof(double) * (size_t)m);
@@ -1223,10 +1231,12 @@ int po_oracle_qp_solve_ext(int n, int m, const int *Pp0, const int *Pi0, const d
                 dn = dn > nPx ? dn : nPx;
                 stop = pri_res < prm->refine_eps + prm->refine_eps * (nz > nAx ? nz : nAx) && dua_res < prm->refine_eps + prm->refine_eps * cinv * dn;
             }
-            if (stop || it2 >= prm->refine_max_iter) break;
+            if (stop || it2 >= cap_it) break;
         }
-        info->iters += it2;
-        info->n_refactor += nfac;
+        refine_its += it2;
+        refine_fac += nfac;
+        info->iters = iter + refine_its;
+        info->n_refactor = n_refactor + refine_fac;
         if (stop || (pri_res <= pri0 && dua_res <= dua0)) {
             info->r_prim = pri_res;
             info->r_dual = dua_res;
@@ -1238,6 +1248,19 @@ int po_oracle_qp_solve_ext(int n, int m, const int *Pp0, const int *Pi0, const d
             dua_res = dua0;
         }
         free(snap);
+        if (!stop && round + 1 < rounds) { /* not certified at refine_eps: back to the type-based iteration (its own rho) at a 10 x tighter eps, then again */
+            ++round;
+            eps_mul *= 0.1;
+            for (int i = 0; i < m; ++i) {
+                rho_vec[i] = ctype[i] == -1 ? OSQP_RHO_MIN : (ctype[i] == 1 ? OSQP_RHO_EQ_OVER_INEQ * rho : rho);
+                rho_inv[i] = 1.0 / rho_vec[i];
+                K.Kx[K.rho_pos[i]] = -rho_inv[i];
+            }
+            if (ldl_numeric(&F, K.Kp, K.Ki, K.Kx)) { rc = PO_ERR_INVALID; goto done; }
+            ++n_refactor;
+            info->status = PO_STATUS_UNSOLVED;
+            goto resume_main;
+        }
     }
     /* ---- polish (OSQP polish.c, on the scaled problem like OSQP): reduced KKT system on the active set with the regularisation
      * +-delta, polish_refine_iter steps of iterative refinement, normal-cone projection, OSQP's acceptance rule.  polish_passes > 1

@@ -115,7 +115,7 @@ void po_default_params(po_params *p) {
     p->enable_dynamic_segmentation = 1;
     p->enable_raw_output = 1; p->output_spacing = 0.3; /* planning_flags.cpp:127-129 */
     p->polish = 0; p->polish_delta = 1e-6; p->polish_refine_iter = 3; p->polish_passes = 1;  /* OSQP defaults (polish off) */
-    p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-6;
+    p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-6; p->refine_rounds = 1;
 }
 
 int po_problem_dims(int form, int N, int keep, int *n, int *m, int *C) {
@@ -213,7 +213,7 @@ static int make_dev_params(const po_handle_s *h, int form, int keep, po::DevPara
     D->polish = p.polish; D->pol_delta = p.polish_delta > 0 ? p.polish_delta : 1e-6; D->pol_refine = p.polish_refine_iter < 0 ? 0 : p.polish_refine_iter;
     D->pol_passes = p.polish_passes;
     D->refine = p.refine; D->ref_every = p.refine_every > 0 ? p.refine_every : 10; D->ref_max_iter = p.refine_max_iter; D->ref_max_refactor = p.refine_max_refactor;
-    D->ref_rho = p.refine_rho; D->ref_eps = p.refine_eps;
+    D->ref_rho = p.refine_rho; D->ref_eps = p.refine_eps; D->ref_rounds = p.refine_rounds;
     return PO_OK;
 }
 
@@ -245,6 +245,7 @@ static void fill_dev_batch(po::DevBatch *D, const po_batch_in *in, const po_batc
     D->scale = nullptr;
     D->pol_state = nullptr; D->pol_stride = 0;
     D->use_split = 0;
+    D->round = 0;
     D->n = n; D->m = m;
 }
 
@@ -293,8 +294,8 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
         long long c4[16];
         HIP_TRY(hipStreamSynchronize(h->stream));
         HIP_TRY(hipMemcpy(c4, D.dbg_cycles, sizeof(c4), hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "[po] path0 cycles: rhs %lld solve %lld update %lld over %lld iterations | solve phases F1 %lld F2 %lld F3B1 %lld B2 %lld B3 %lld | uniform row classes %lld\n",
-                     c4[0], c4[1], c4[2], c4[3], c4[4], c4[5], c4[6], c4[7], c4[8], c4[10]);
+        std::fprintf(stderr, "[po] path0 cycles: rhs %lld solve %lld update %lld over %lld iterations | solve phases F1 %lld F2 %lld F3B1 %lld B2 %lld B3 %lld | first factorisation: blocks %lld chain %lld | uniform row classes %lld\n",
+                     c4[0], c4[1], c4[2], c4[3], c4[4], c4[5], c4[6], c4[7], c4[8], c4[10], c4[11], c4[12]);
     }
     return PO_OK;
 }

@@ -34,7 +34,7 @@ struct DevParams {
     int max_iter, check_every, adapt_every, end_heading;
     double pol_delta;           // OSQP delta
     int polish, pol_refine, pol_passes;
-    int refine, ref_every, ref_max_iter, ref_max_refactor;  // po_params.refine*
+    int refine, ref_every, ref_max_iter, ref_max_refactor, ref_rounds;  // po_params.refine*
     double ref_rho, ref_eps;
 };
 
@@ -52,6 +52,7 @@ struct DevBatch {
     int perm_bits;          // block -> path permutation: ceil(log2 B) bits of mixing (0 = blockIdx order), see solve_kernel_fast
     int only_deferred;      // set by the launcher for the second (general) launch of the two-level mapping: solve only the paths the first one deferred
     int n, m;
+    int round;              // po_params.refine_rounds: which round this launch is (0: all paths; r > 0: the paths round r - 1 handed back)
     int use_split;          // launcher hint: take the stage-split two-wave mapping where it exists (keep 4, one-wave shapes; not with polish)
     double *pol_state;      // polish only: [B][pol_stride] per-lane ADMM state left by the solve kernels for polish_kernel (or nullptr)
     int pol_stride;

@@ -57,6 +57,7 @@ PO_DECL(po_launch_solve_kp); PO_DECL(po_launch_solve_kp_uni);
 PO_DECL(po_launch_solve_kpc); PO_DECL(po_launch_solve_kpc_uni);
 PO_DECL(po_launch_solve_k); PO_DECL(po_launch_solve_k_uni);
 PO_DECL(po_launch_solve_kp_uni_ref); PO_DECL(po_launch_solve_kpc_uni_ref); PO_DECL(po_launch_solve_k_uni_ref);
+PO_DECL(po_launch_solve_kp_ref); PO_DECL(po_launch_solve_kpc_ref); PO_DECL(po_launch_solve_k_ref);
 #undef PO_DECL
 
 // Two launches on the same stream for the two-level mapping: the uniform-row-class variant first (solves what it can, defers the rest),
@@ -64,11 +65,25 @@ PO_DECL(po_launch_solve_kp_uni_ref); PO_DECL(po_launch_solve_kpc_uni_ref); PO_DE
 extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out) {
     using namespace po;
     hipError_t e;
-    const bool ref = P->refine != 0;  // the uniform variant that carries the refinement phase (the general variant always does)
-    if (form == F_KP) { e = ref ? po_launch_solve_kp_uni_ref(in, P, st, lds_out) : po_launch_solve_kp_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kp(in, P, st, lds_out); }
-    if (form == F_KPC) { e = ref ? po_launch_solve_kpc_uni_ref(in, P, st, lds_out) : po_launch_solve_kpc_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kpc(in, P, st, lds_out); }
-    e = ref ? po_launch_solve_k_uni_ref(in, P, st, lds_out) : po_launch_solve_k_uni(in, P, st, lds_out);
-    return e != hipSuccess ? e : po_launch_solve_k(in, P, st, lds_out);
+    const bool ref = P->refine != 0 && in->pol_state != nullptr;  // the kernels that carry the refinement phase (two-level shapes; they need the state block)
+    if (!ref) {
+        if (form == F_KP) { e = po_launch_solve_kp_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kp(in, P, st, lds_out); }
+        if (form == F_KPC) { e = po_launch_solve_kpc_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kpc(in, P, st, lds_out); }
+        e = po_launch_solve_k_uni(in, P, st, lds_out);
+        return e != hipSuccess ? e : po_launch_solve_k(in, P, st, lds_out);
+    }
+    // po_params.refine_rounds: one pair of launches per round; a later round finds only the paths the round before handed back (the others leave after one
+    // 4-byte read)
+    const int rounds = P->ref_rounds > 1 ? P->ref_rounds : 1;
+    DevBatch rb = *in;
+    for (int r = 0; r < rounds; ++r) {
+        rb.round = r;
+        if (form == F_KP) { e = po_launch_solve_kp_uni_ref(&rb, P, st, lds_out); if (e == hipSuccess) e = po_launch_solve_kp_ref(&rb, P, st, lds_out); }
+        else if (form == F_KPC) { e = po_launch_solve_kpc_uni_ref(&rb, P, st, lds_out); if (e == hipSuccess) e = po_launch_solve_kpc_ref(&rb, P, st, lds_out); }
+        else { e = po_launch_solve_k_uni_ref(&rb, P, st, lds_out); if (e == hipSuccess) e = po_launch_solve_k_ref(&rb, P, st, lds_out); }
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 #define PO_DECLP(name) extern "C" hipError_t name(const po::DevBatch *in, const po::DevParams *P, hipStream_t st)

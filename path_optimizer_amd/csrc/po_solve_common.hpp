@@ -131,8 +131,8 @@ inline bool resolve_shape(int form, int N, int C, int keep, Shape *s) {
 }
 // UNI = true: the uniform-row-class variant of the two-level kernels (no-op for shapes that use the single-level mapping and for K on multi-wave blocks); UNI = false: the general variant.  po_launch_solve issues them in this order on one stream.
 template <int F> inline bool has_uni_variant(const Shape &s) { return s.two && (F != F_K || s.nt == 64); }  // K: one-wave blocks only (Fast::classify)
-// REF: kernels that carry the refinement phase (po_params.refine) after the loop — the uniform variant exists with and without (the phase costs the hot loop
-// ~4 % even when it is not taken), the general variant only with.
+// REF: kernels that carry the refinement phase (po_params.refine) around the loop — every variant exists with and without (the phase costs the hot loop
+// a few % even when it is not taken); those with are launched only when po_params.refine is set.
 template <int F, bool UNI, bool REF> hipError_t launch_form(const DevBatch *in_, const DevParams *P, hipStream_t st, size_t *lds_out) {
     Shape s;
     if (!resolve_shape(F, in_->N, in_->C, in_->keep, &s)) return hipErrorInvalidValue;

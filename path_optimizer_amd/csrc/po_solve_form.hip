@@ -17,19 +17,21 @@
 #ifndef PO_REF
 #define PO_REF 0
 #endif
-#if PO_UNI && PO_REF  // the uniform variant with the refinement phase (po_params.refine): its own object
+#if PO_UNI && PO_REF  // the variants with the refinement phase (po_params.refine): their own objects
 #define PO_ENTRY PO_CAT(PO_ENTRY_BASE, _uni_ref)
 #elif PO_UNI
 #define PO_ENTRY PO_CAT(PO_ENTRY_BASE, _uni)
+#elif PO_REF
+#define PO_ENTRY PO_CAT(PO_ENTRY_BASE, _ref)
 #else
 #define PO_ENTRY PO_ENTRY_BASE
 #endif
 
 extern "C" hipError_t PO_ENTRY(const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out) {
-    return po::launch_form<PO_FORM, PO_UNI != 0, (PO_REF != 0) || (PO_UNI == 0)>(in, P, st, lds_out);
+    return po::launch_form<PO_FORM, PO_UNI != 0, PO_REF != 0>(in, P, st, lds_out);
 }
 
-#if !PO_UNI  // the polish kernels of this formulation build with the general-variant object
+#if !PO_UNI && !PO_REF  // the polish kernels of this formulation build with the general-variant object
 #if PO_FORM == 0
 #define PO_POLISH_ENTRY po_launch_polish_kp
 #define PO_POLISH_SIZE po_polish_state_doubles_kp

@@ -21,7 +21,7 @@ def _rms(xs, gold, N):
 
 def test_oracle_refine_defaults_and_off_is_identity(oracle):
     p = oracle.default_params()
-    assert (p.refine, p.refine_every, p.refine_max_iter, p.refine_max_refactor, p.refine_rho, p.refine_eps) == (0, 10, 400, 40, 10.0, 1e-6)
+    assert (p.refine, p.refine_every, p.refine_max_iter, p.refine_max_refactor, p.refine_rho, p.refine_eps, p.refine_rounds) == (0, 10, 400, 40, 10.0, 1e-6, 1)
     b = synth.make_batch(3, B=4)
     _, i0, x0 = oracle.solve_batch(b, oracle.device_equivalent_params())
     q = oracle.device_equivalent_params()
@@ -68,6 +68,52 @@ def test_oracle_refine_from_a_looser_solve(oracle):
     assert (_rms(x1, gold, b.N) <= 1e-4).mean() >= 0.95 and i1["iters"].mean() < i0["iters"].mean() and i1["iters"].max() < i0["iters"].max()
 
 
+def test_oracle_refine_rounds(oracle):
+    """refine_rounds = 3: solve to 100 x eps, refine; what is not certified goes back to the type-based iteration at 10 x eps, is refined again, then at eps.
+    Every path ends certified at refine_eps or solved at eps; the mean iteration count halves."""
+    b = synth.make_batch(3, B=96)
+    gold = np.load(GOLD)["e_y"]
+    _, i0, _ = oracle.solve_batch(b, oracle.device_equivalent_params())
+    p = oracle.device_equivalent_params()
+    p.refine, p.refine_rounds = 1, 3
+    _, i1, x1 = oracle.solve_batch(b, p)
+    assert (i1["status"] == 1).all()
+    assert (_rms(x1, gold, b.N) <= 1e-4).mean() >= 0.985
+    assert i1["iters"].mean() < 0.6 * i0["iters"].mean() and i1["iters"].max() < i0["iters"].max()
+    # the criteria a returned path satisfies are never looser than eps_abs / eps_rel
+    assert (i1["r_prim"] < 1e-3).all() and (i1["r_dual"] < 1e-3).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form,cfg,B,rounds", [(0, 3, 96, 3), (0, 3, 48, 2), (1, 5, 8, 3), (2, 3, 16, 3)])
+def test_device_refine_rounds_match_oracle(oracle, form, cfg, B, rounds):
+    """One pair of launches per round on the device (paths handed back through out_info / the HBM state block), a resume in the oracle: same counts, same points."""
+    from path_optimizer_amd import binding
+
+    b = synth.make_batch(cfg, B=B, formulation=form)
+    p = binding.default_params()
+    p.refine, p.refine_rounds = 1, rounds
+    st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
+    ost, oinfo, oxs = oracle.solve_batch(b, oracle.device_equivalent_params(p))
+    assert np.array_equal(info["status"], oinfo["status"]) and (info["status_polish"] == 0).all()
+    same = info["iters"] == oinfo["iters"]
+    assert same.mean() >= 0.7, (info["iters"], oinfo["iters"])
+    dn = np.abs(info["n_refactor"].astype(int) - oinfo["n_refactor"].astype(int))[same]
+    assert (dn == 0).mean() >= 0.9 and dn.max() <= 2  # (an activity test decided by the last bits can cost / save one refactorisation without changing the count)
+    ident = same & (info["n_refactor"] == oinfo["n_refactor"])
+    dx = np.abs(xs - oxs).max(axis=1)
+    # (1e-5, not 1e-6: with inactive rows at RHO_MIN the iteration is nearly unconstrained along the flat directions, which amplifies last-bit differences of
+    # the two linear solves on a path that is still far from converged when a round's budget ends; measured 1.3e-6 on one path of 96, median 1e-11)
+    assert dx[ident].max() < 1e-5 and np.median(dx[ident]) < 1e-8 and np.abs(st[ident] - ost[ident]).max() < 1e-5
+    assert dx[same].max() < 1e-4
+    conv = (info["r_prim"] < 2e-6) & (info["r_dual"] < 2e-6) & (oinfo["r_prim"] < 2e-6) & (oinfo["r_dual"] < 2e-6)
+    assert conv.mean() >= 0.8 and np.abs(st[conv] - ost[conv])[..., :3].max() < 2e-4
+    assert abs(info["iters"].mean() - oinfo["iters"].mean()) < 0.1 * oinfo["iters"].mean()
+    if form == 0:
+        gold = np.load(GOLD)["e_y"]
+        assert (_rms(xs, gold, b.N) <= 1e-4).mean() >= 0.98
+
+
 @pytest.mark.gpu
 def test_device_refine_matches_oracle_and_optimum(oracle):
     from path_optimizer_amd import binding
@@ -75,7 +121,7 @@ def test_device_refine_matches_oracle_and_optimum(oracle):
     b = synth.make_batch(3, B=128)
     gold = np.load(GOLD)["e_y"]
     p = binding.default_params()
-    assert (p.refine, p.refine_every, p.refine_max_iter, p.refine_max_refactor, p.refine_rho, p.refine_eps) == (0, 10, 400, 40, 10.0, 1e-6)
+    assert (p.refine, p.refine_every, p.refine_max_iter, p.refine_max_refactor, p.refine_rho, p.refine_eps, p.refine_rounds) == (0, 10, 400, 40, 10.0, 1e-6, 1)
     st0, i0, x0 = binding.Engine(0, p).solve_batch(b, want_x=True)
     p.refine = 1
     st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
