@@ -154,8 +154,11 @@ template <int F, bool UNI, bool REF> hipError_t launch_form(const DevBatch *in_,
             if (lds2 <= 160 * 1024) return launch1(&solve_kernel_split<F>, in, P, 128, lds2, st);
         }
     }
-#ifdef PO_DEV_HEADLINE  // dev builds: only the BASELINE config-3 variant (seconds to compile)
-    if (s.two && s.spl == 4 && s.nt == 64) PO_L(4, 64, true);
+#ifdef PO_DEV_HEADLINE  // dev builds: only the BASELINE config-3 variant (seconds to compile); -DPO_DEV_SPL=k: the one-wave variant of keep k instead
+#ifndef PO_DEV_SPL
+#define PO_DEV_SPL 4
+#endif
+    if (s.two && s.spl == PO_DEV_SPL && s.nt == 64) PO_L(PO_DEV_SPL, 64, true);
     return hipErrorInvalidValue;
 #else
     if (s.two) {
