@@ -97,6 +97,27 @@ def config_legs(torch, binding, synth, dev, stream, steps=3):
                      "ms": med, "paths_per_s": b.B / (med * 1e-3), "path_iters_per_s": float(info["iters"].sum()) / (med * 1e-3),
                      "iters_mean": float(info["iters"].mean()), "iters_max": int(info["iters"].max()), "unsolved": int((info["status"] != 1).sum())}
         eng.close()
+        # the same leg with the opt-in refinement (po_params.refine: same QP, OSQP's termination test at eps or tighter), from an eps 3e-4 solve and
+        # in three rounds (hand-over at 100 x eps): where the plain solve's time is its longest path (one planning instance; K's 3 550-iteration path) this is the latency lever
+        ref = {}
+        for tag, mut in (("eps3e-4_refine", dict(refine=1, eps_abs=3e-4, eps_rel=3e-4)), ("refine_rounds3", dict(refine=1, refine_rounds=3))):
+            p = binding.default_params()
+            if not hasattr(p, "refine_rounds"):
+                break
+            for k_, v_ in mut.items():
+                setattr(p, k_, v_)
+            eng = binding.Engine(torch.cuda.current_device(), p)
+            eng.set_stream(stream.cuda_stream)
+            eng.solve_batch_device(db)
+            torch.cuda.synchronize()
+            _, ms = time_serial(torch, eng, stream, db, steps, torch.cuda.synchronize)
+            info = db.info_numpy()
+            med = float(np.median(ms))
+            ref[tag] = {"ms": med, "paths_per_s": b.B / (med * 1e-3), "iters_mean": float(info["iters"].mean()), "iters_max": int(info["iters"].max()),
+                        "unsolved": int((info["status"] != 1).sum()), "r_prim_max": float(info["r_prim"].max()), "r_dual_max": float(info["r_dual"].max())}
+            eng.close()
+        if ref:
+            out[name]["with_refinement"] = ref
     # BASELINE config 1 as the reference itself runs it: its REAL benchmark scene (src/test/path_optimizer_benchmark.cpp; map / way points / reference outputs
     # in tests/golden/benchmark_scene.npz).  Single planning instance: a latency figure, B = 1 fills one CU of 256.
     gpath = os.path.join(ROOT, "tests", "golden", "benchmark_scene.npz")
