@@ -373,6 +373,203 @@ template <int KIND> __device__ __forceinline__ void band_solve_lanes(Prob<KIND> 
     }
 }
 
+
+// L D L' x = wk, in place, PARTITIONED over the lanes of the wave (narrow bands, W <= 4): lane t owns the c consecutive rows [t c, (t + 1) c), c a multiple of W.
+// A banded substitution is a linear recurrence of order W: with the W values before the chunk as incoming state s_in, the chunk's last W values are
+// s_out = p + Phi s_in, where p comes from the chunk's own right-hand side with s_in = 0 and column k of Phi from a unit incoming state and a zero
+// right-hand side.  So: (1) every lane runs the 1 + W recurrences over its own rows with rolling windows (no per-row storage), (2) the affine maps
+// (Phi_t, p_t) are composed by a Kogge-Stone scan over the lanes, which hands every lane its true incoming state, (3) every lane runs the recurrence once
+// more from that state and stores its rows.  The backward sweep (L' x = z) is the same recurrence from the far end (incoming state from the next
+// lane).  2 x (W + 2) passes over c rows per lane instead of 2 x n dependent columns on one lane: the substitution was 2/3 of a TENSION2 solve.
+// The factor is SPD-banded (P + sigma I + A' rho A): its homogeneous solutions decay, the products of the Phi_t stay bounded.
+template <int W> struct AffW { double M[W][W], p[W]; };
+template <int W> __device__ __forceinline__ AffW<W> aff_compose(const AffW<W> &first, const AffW<W> &second) {  // second o first
+    AffW<W> o;
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        double acc = second.p[i];
+#pragma unroll
+        for (int k = 0; k < W; ++k) acc += second.M[i][k] * first.p[k];
+        o.p[i] = acc;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            double a2 = 0;
+#pragma unroll
+            for (int k = 0; k < W; ++k) a2 += second.M[i][k] * first.M[k][j];
+            o.M[i][j] = a2;
+        }
+    }
+    return o;
+}
+template <int W, bool UP> __device__ __forceinline__ AffW<W> aff_shift(const AffW<W> &e, int d) {
+    AffW<W> o;
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        o.p[i] = UP ? __shfl_up(e.p[i], d) : __shfl_down(e.p[i], d);
+#pragma unroll
+        for (int j = 0; j < W; ++j) o.M[i][j] = UP ? __shfl_up(e.M[i][j], d) : __shfl_down(e.M[i][j], d);
+    }
+    return o;
+}
+template <int KIND> __device__ __forceinline__ void band_solve_scan(Prob<KIND> &pb, int lane, int c) {
+    using T = ST<KIND>;
+    constexpr int W = T::W, LS = Prob<KIND>::LS;
+    static_assert(W <= 4, "wide bands keep band_solve_lanes");
+    const double *__restrict__ Lb = pb.Lb;
+    double *__restrict__ wk = pb.wk;
+    const int nl = (pb.n + c - 1) / c;  // lanes that own rows (the last one may own padding rows: zero factor columns, zero right-hand side)
+    const int j0 = lane * c;
+    const bool own = lane < nl;
+    // ================= forward: L y = b, stored as z = D^-1 y =================
+    // row form: y_j = b_j - sum_{d = 1..W} L[j][j - d] y_{j - d},  L[j][j - d] = Lb[(j - d) LS + d]
+    auto lrow = [&](int j, int d) -> double { const int cidx = j - d; return cidx >= 0 ? Lb[cidx * LS + d] : 0.0; };
+    AffW<W> el;
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        el.p[i] = 0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) el.M[i][k] = i == k ? 1.0 : 0.0;
+    }
+    if (own) {
+        // windows: slot (j mod W) holds the value of row j once it is produced; before that, of row j - W.  Incoming state k = row j0 - W + k.
+        double wp[W], wh[W][W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            wp[k] = 0;
+#pragma unroll
+            for (int i = 0; i < W; ++i) wh[i][k] = i == k ? 1.0 : 0.0;  // wh[slot][k]: homogeneous solution k
+        }
+        for (int jb = 0; jb < c; jb += W) {
+#pragma unroll
+            for (int uu = 0; uu < W; ++uu) {  // j0 is a multiple of W: row j0 + jb + uu lives in slot uu
+                const int j = j0 + jb + uu;
+                double lr[W];
+#pragma unroll
+                for (int d = 1; d <= W; ++d) lr[d - 1] = lrow(j, d);
+                double accp = wk[j];
+#pragma unroll
+                for (int d = 1; d <= W; ++d) accp -= lr[d - 1] * wp[(uu - d + 4 * W) % W];
+                double acch[W];
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    double a2 = 0;
+#pragma unroll
+                    for (int d = 1; d <= W; ++d) a2 -= lr[d - 1] * wh[(uu - d + 4 * W) % W][k];
+                    acch[k] = a2;
+                }
+                wp[uu] = accp;
+#pragma unroll
+                for (int k = 0; k < W; ++k) wh[uu][k] = acch[k];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            el.p[i] = wp[i];
+#pragma unroll
+            for (int k = 0; k < W; ++k) el.M[i][k] = wh[i][k];
+        }
+    }
+    // inclusive scan over the lanes: el_t <- el_t o el_{t-1} o ... o el_0
+    for (int d = 1; d < nl; d <<= 1) {
+        const AffW<W> prev = aff_shift<W, true>(el, d);
+        if (lane >= d) el = aff_compose<W>(prev, el);
+    }
+    {
+        // incoming state of lane t = outgoing state of lane t - 1 applied to the zero state = p of the inclusive prefix
+        double sin_[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) { const double v = __shfl_up(el.p[i], 1); sin_[i] = lane > 0 ? v : 0.0; }
+        if (own) {
+            double wp[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) wp[i] = sin_[i];
+            for (int jb = 0; jb < c; jb += W) {
+#pragma unroll
+                for (int uu = 0; uu < W; ++uu) {
+                    const int j = j0 + jb + uu;
+                    double acc = wk[j];
+#pragma unroll
+                    for (int d = 1; d <= W; ++d) acc -= lrow(j, d) * wp[(uu - d + 4 * W) % W];
+                    wp[uu] = acc;
+                    wk[j] = acc * Lb[j * LS];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ================= backward: L' x = z,  x_j = z_j - sum_{d = 1..W} Lb[j LS + d] x_{j + d} =================
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        el.p[i] = 0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) el.M[i][k] = i == k ? 1.0 : 0.0;
+    }
+    if (own) {
+        // incoming state k = row j0 + c + k (slot k: rows are taken in descending order, row j lives in slot (j - j0) mod W)
+        double wp[W], wh[W][W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            wp[k] = 0;
+#pragma unroll
+            for (int i = 0; i < W; ++i) wh[i][k] = i == k ? 1.0 : 0.0;
+        }
+        for (int jb = c - W; jb >= 0; jb -= W) {
+#pragma unroll
+            for (int uu = W - 1; uu >= 0; --uu) {
+                const int j = j0 + jb + uu;
+                double lc[W];
+#pragma unroll
+                for (int d = 1; d <= W; ++d) lc[d - 1] = Lb[j * LS + d];
+                double accp = wk[j];
+#pragma unroll
+                for (int d = 1; d <= W; ++d) accp -= lc[d - 1] * wp[(uu + d) % W];
+                double acch[W];
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    double a2 = 0;
+#pragma unroll
+                    for (int d = 1; d <= W; ++d) a2 -= lc[d - 1] * wh[(uu + d) % W][k];
+                    acch[k] = a2;
+                }
+                wp[uu] = accp;
+#pragma unroll
+                for (int k = 0; k < W; ++k) wh[uu][k] = acch[k];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            el.p[i] = wp[i];
+#pragma unroll
+            for (int k = 0; k < W; ++k) el.M[i][k] = wh[i][k];
+        }
+    }
+    for (int d = 1; d < nl; d <<= 1) {  // el_t <- el_t o el_{t+1} o ... o el_{nl-1}
+        const AffW<W> nxt = aff_shift<W, false>(el, d);
+        if (lane + d < nl) el = aff_compose<W>(nxt, el);
+    }
+    {
+        double sin_[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) { const double v = __shfl_down(el.p[i], 1); sin_[i] = lane + 1 < nl ? v : 0.0; }
+        if (own) {
+            double wp[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) wp[i] = sin_[i];
+            for (int jb = c - W; jb >= 0; jb -= W) {
+#pragma unroll
+                for (int uu = W - 1; uu >= 0; --uu) {
+                    const int j = j0 + jb + uu;
+                    double acc = wk[j];
+#pragma unroll
+                    for (int d = 1; d <= W; ++d) acc -= Lb[j * LS + d] * wp[(uu + d) % W];
+                    wp[uu] = acc;
+                    wk[j] = acc;
+                }
+            }
+        }
+    }
+}
+
 #define PO_TICK(slot)                                                   \
     do {                                                                \
         if (a.dbg_cycles) { const long long t_ = clock64(); acc_[slot] += t_ - tprev_; tprev_ = t_; } \
@@ -576,7 +773,13 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
         // wide bands (TENSION, W = 9): one pending row per lane, one FMA per lane and column (35 instead of 40 ms per 4096 QPs); narrow bands (W = 3, 4): the
         // single-lane window is as fast or faster (measured: TENSION2 14.6 vs 17.2 ms) — the column-to-column latency, not the FMA count, bounds both
         if constexpr (ST<KIND>::W >= 8) band_solve_lanes<KIND>(pb, lane);
-        else { if (lane == 0) band_solve<KIND>(pb); }
+        else {
+            // narrow bands (W = 3, 4): the substitution partitioned over the lanes (chunks of c rows, c a multiple of W, every row's read-ahead inside the
+            // zero padding); QPs too small to give every chunk W rows keep the single-lane window
+            const int c = ((n + 63) / 64 + ST<KIND>::W - 1) / ST<KIND>::W * ST<KIND>::W;
+            if (!a.seq_band && c * ((n + c - 1) / c) <= np) band_solve_scan<KIND>(pb, lane, c);
+            else if (lane == 0) band_solve<KIND>(pb);
+        }
         __syncthreads();
         PO_TICK(3);
         for (int r = lane; r < m; r += 64) {  // ztilde = A xtilde ; v += alpha (ztilde - z)

@@ -22,5 +22,6 @@ struct DevSmooth {
     DevMap map;             // TENSION only
     int perm_bits;          // block -> instance mixing (po_device.hpp perm_index), 0 = blockIdx order
     long long *dbg_cycles;  // optional [B][8] per-phase shader-clock totals (dev tool: PO_SMOOTH_DEBUG=1), or nullptr
+    int seq_band;           // dev (PO_SMOOTH_SEQ=1): narrow-band substitutions on one lane (the round-1 path) instead of partitioned over the wave
 };
 }  // namespace po

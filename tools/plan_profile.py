@@ -11,7 +11,11 @@ from path_optimizer_amd.abi import INFO_DTYPE  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 scn = synth.make_planning_scenes(2, 64)
-eng = binding.Engine(0)
+par = binding.default_params()
+for kv in sys.argv[3:]:  # e.g. refine=1 eps_abs=3e-4 eps_rel=3e-4
+    k_, v_ = kv.split("=")
+    setattr(par, k_, type(getattr(par, k_))(float(v_)))
+eng = binding.Engine(0, par)
 eng.set_map(*scn["map"])
 rs = -(-B // 64)
 perm = np.random.default_rng(5).permutation(64 * rs)[:B] % 64  # shuffled replication; "periodic" as 2nd argument: scene b % 64 (worst case for a round-robin XCD dispatch)
