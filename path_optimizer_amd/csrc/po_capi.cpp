@@ -265,6 +265,7 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     if (dbg) {
         if ((rc = h->dbg_buf.ensure(sizeof(long long) * 16 * (size_t)in->B))) return rc;
         D.dbg_cycles = static_cast<long long *>(h->dbg_buf.p);
+        HIP_TRY(hipMemsetAsync(D.dbg_cycles, 0, sizeof(long long) * 16 * (size_t)in->B, h->stream));
     }
     if ((rc = h->scale_buf.ensure(sizeof(double) * 64 * (size_t)in->B))) return rc;
     D.scale = static_cast<double *>(h->scale_buf.p);
@@ -294,8 +295,8 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
         long long c4[16];
         HIP_TRY(hipStreamSynchronize(h->stream));
         HIP_TRY(hipMemcpy(c4, D.dbg_cycles, sizeof(c4), hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "[po] path0 cycles: rhs %lld solve %lld update %lld over %lld iterations | solve phases F1 %lld F2 %lld F3B1 %lld B2 %lld B3 %lld | first factorisation: blocks %lld chain %lld | uniform row classes %lld\n",
-                     c4[0], c4[1], c4[2], c4[3], c4[4], c4[5], c4[6], c4[7], c4[8], c4[10], c4[11], c4[12]);
+        std::fprintf(stderr, "[po] path0 cycles: rhs %lld solve %lld update %lld over %lld iterations | solve phases F1 %lld F2 %lld F3B1 %lld B2 %lld B3 %lld | first factorisation: blocks %lld chain %lld | uniform row classes %lld | scan factorisations %lld, fell back to the sequential chain %lld\n",
+                     c4[0], c4[1], c4[2], c4[3], c4[4], c4[5], c4[6], c4[7], c4[8], c4[10], c4[11], c4[12], c4[13], c4[14]);
     }
     return PO_OK;
 }
