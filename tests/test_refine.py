@@ -237,3 +237,41 @@ def test_device_refine_every_keep_value_matches_oracle(oracle, keep, N, ds):
         assert np.array_equal(info["status"], oinfo["status"])
         assert np.array_equal(info["iters"], oinfo["iters"]), (keep, N, pin, info["iters"], oinfo["iters"])
         assert np.abs(xs - oxs).max() < 1e-7, (keep, N, pin, np.abs(xs - oxs).max())
+
+
+def _tight(oracle, b):
+    p = oracle.device_equivalent_params()
+    p.eps_abs = p.eps_rel = 1e-8
+    p.max_iter = 200000
+    p.polish, p.polish_passes = 1, 6
+    st, info, _ = oracle.solve_batch(b, p)
+    assert (info["status"] == 1).all()
+    return st
+
+
+@pytest.mark.parametrize("form,cfg,B", [(2, 3, 6), (1, 5, 2)])
+def test_oracle_refine_other_formulations_reach_the_tight_optimum(oracle, form, cfg, B):
+    """K and KPC: position RMS against an eps 1e-8 + polish solve — 1e-4 .. 1e-3 m after the plain eps 1e-4 solve, < 1e-5 m after the refinement."""
+    b = synth.make_batch(cfg, B=B, formulation=form)
+    ref = _tight(oracle, b)
+    rms = lambda st: np.sqrt(np.mean(np.sum((st[:, :, :2] - ref[:, :, :2]) ** 2, axis=2), axis=1))
+    st0, i0, _ = oracle.solve_batch(b, oracle.device_equivalent_params())
+    p = oracle.device_equivalent_params()
+    p.refine = 1
+    st1, i1, _ = oracle.solve_batch(b, p)
+    assert rms(st1).max() < 1e-5 and rms(st1).max() < 0.05 * rms(st0).max()
+    assert ((i1["iters"] - i0["iters"]) <= 60).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form,cfg,B", [(2, 3, 6), (1, 5, 2)])
+def test_device_refine_other_formulations_reach_the_tight_optimum(oracle, form, cfg, B):
+    from path_optimizer_amd import binding
+
+    b = synth.make_batch(cfg, B=B, formulation=form)
+    ref = _tight(oracle, b)
+    p = binding.default_params()
+    p.refine = 1
+    st, info, _ = binding.Engine(0, p).solve_batch(b)
+    assert (info["status"] == 1).all()
+    assert np.sqrt(np.mean(np.sum((st[:, :, :2] - ref[:, :, :2]) ** 2, axis=2), axis=1)).max() < 1e-5

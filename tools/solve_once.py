@@ -4,7 +4,8 @@ import numpy as np
 sys.path.insert(0, os.getcwd())
 from path_optimizer_amd import binding, synth
 import torch
-full = synth.make_batch(3)
+cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+full = synth.make_batch(cfg)
 kw = json.loads(sys.argv[1])
 p = binding.default_params()
 for k, v in kw.items(): setattr(p, k, v)
