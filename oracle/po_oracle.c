@@ -1190,7 +1190,13 @@ resume_main:
                     double r;
                     if (ctype[i] == -1) r = OSQP_RHO_MIN;
                     else if (ctype[i] == 1) r = OSQP_RHO_EQ_OVER_INEQ * rb;
-                    else r = (frozen || (z[i] <= l[i] && y[i] < 0) || (z[i] >= u[i] && y[i] > 0) || (2 * nfac >= prm->refine_max_refactor && rho_vec[i] == rb)) ? rb : OSQP_RHO_MIN;
+                    else {
+                        /* active: z at a bound with a multiplier of the matching sign, tested on v = z + y / rho like the engine does (a multiplier so small
+                         * that it moves v off the bound by less than 1e-9 (1 + |bound|) counts as zero: its sign is rounding noise) */
+                        const double v = z[i] + rho_inv[i] * y[i];
+                        const double tl_ = 1e-9 * (1.0 + fabs(l[i])), tu_ = 1e-9 * (1.0 + fabs(u[i])); /* a numerically zero multiplier is no multiplier */
+                        r = (frozen || v < l[i] - tl_ || v > u[i] + tu_ || (2 * nfac >= prm->refine_max_refactor && rho_vec[i] == rb)) ? rb : OSQP_RHO_MIN;
+                    }
                     if (r != rho_vec[i]) { rho_vec[i] = r; changed = 1; }
                 }
             }

