@@ -132,8 +132,8 @@ typedef struct po_params {
 
 typedef struct po_info {
     int    status;      /* PO_STATUS_*                                  */
-    int    iters;       /* ADMM iterations run                          */
-    int    n_refactor;  /* numeric refactorisations after the first     */
+    int    iters;       /* ADMM iterations run (with po_params.refine: the solve's and the refinement's together) */
+    int    n_refactor;  /* numeric refactorisations after the first (the refinement's included) */
     int    status_polish; /* OSQP info.status_polish: 0 not attempted, 1 polished solution adopted, -1 polish unsuccessful (ADMM solution kept) */
     double r_prim;      /* ||Ax - z||_inf   at exit (unscaled)          */
     double r_dual;      /* ||Px + q + A'y||_inf at exit                 */

@@ -7,7 +7,7 @@ scipy's sparse LU (an algorithm independent of both ADMM implementations); accep
 the point satisfies the KKT conditions exactly (checked again by the oracle's solver-independent po_oracle_kkt_check: stationarity,
 primal violation, complementarity / dual sign <= 1e-8).  Paths the refinement does not settle fall back to ADMM at eps 1e-10.
 
-    python tests/golden/make_tight_c3.py [n_paths=256]
+    python tests/golden/make_tight_c3.py [n_paths=256] [config=3]      (config 2: tests/golden/tight_c2.npz, N = 120)
 """
 import os
 import sys
@@ -58,7 +58,8 @@ def active_set_refine(Pf, A, l, u, x, y, z, passes=12):
 
 def main():
     nb = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    batch = synth.make_batch(3, B=nb)
+    cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    batch = synth.make_batch(cfg, B=nb)
     p = O.device_equivalent_params()
 
     def par(eps, mi):
@@ -89,8 +90,8 @@ def main():
         ey[b] = xs[0:3 * N:3]
         print(b, method[b], cert[b], flush=True)
     assert cert.max() < 1e-7, cert.max()
-    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tight_c3.npz"), e_y=ey, kkt=cert, method=method,
-                        note="exact optima of synth.make_batch(3, B=%d): e_y[b, j] = x[3 j]; kkt = (stationarity, primal violation, complementarity)" % nb)
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tight_c%d.npz" % cfg), e_y=ey, kkt=cert, method=method,
+                        note="exact optima of synth.make_batch(%d, B=%d): e_y[b, j] = x[3 j]; kkt = (stationarity, primal violation, complementarity)" % (cfg, nb))
     print("methods", np.bincount(method), "max kkt", cert.max(axis=0))
 
 

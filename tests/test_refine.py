@@ -275,3 +275,34 @@ def test_device_refine_other_formulations_reach_the_tight_optimum(oracle, form, 
     st, info, _ = binding.Engine(0, p).solve_batch(b)
     assert (info["status"] == 1).all()
     assert np.sqrt(np.mean(np.sum((st[:, :, :2] - ref[:, :, :2]) ** 2, axis=2), axis=1)).max() < 1e-5
+
+
+GOLD2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tight_c2.npz")  # exact optima of BASELINE config 2 (N = 120), 128 paths
+
+
+def test_oracle_refine_config2_against_exact_optima(oracle):
+    gold = np.load(GOLD2)["e_y"]
+    b = synth.make_batch(2, B=len(gold))
+    res = {}
+    for tag, kw in (("plain", {}), ("refine", dict(refine=1)), ("loose+refine", dict(refine=1, eps_abs=3e-4, eps_rel=3e-4)), ("rounds", dict(refine=1, refine_rounds=3))):
+        p = oracle.device_equivalent_params()
+        for k, v in kw.items():
+            setattr(p, k, v)
+        _, info, xs = oracle.solve_batch(b, p)
+        res[tag] = ((_rms(xs, gold, b.N) <= 1e-4).mean(), info["iters"].mean())
+    assert res["plain"][0] < 0.6 and res["refine"][0] >= 0.97 and res["loose+refine"][0] >= 0.97 and res["rounds"][0] >= 0.97
+    assert res["loose+refine"][1] < res["plain"][1] and res["rounds"][1] < 0.5 * res["plain"][1]
+
+
+@pytest.mark.gpu
+def test_device_refine_config2_against_exact_optima():
+    from path_optimizer_amd import binding
+
+    gold = np.load(GOLD2)["e_y"]
+    b = synth.make_batch(2, B=len(gold))
+    for kw, bar in ((dict(refine=1), 0.97), (dict(refine=1, eps_abs=3e-4, eps_rel=3e-4), 0.97), (dict(refine=1, refine_rounds=3), 0.97)):
+        p = binding.default_params()
+        for k, v in kw.items():
+            setattr(p, k, v)
+        st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
+        assert (info["status"] == 1).all() and (_rms(xs, gold, b.N) <= 1e-4).mean() >= bar, kw
