@@ -207,6 +207,7 @@ def accuracy_legs(torch, binding, synth, batch, dev, stream, cpu_sample):
         res["settings"].append(run("eps 2e-4 + refine", lambda p: ref(p, 2e-4, 0))[0])
         res["settings"].append(run("eps 3e-4 + refine", lambda p: ref(p, 3e-4, 0))[0])
         res["settings"].append(run("eps 3e-4 + refine + polish (<= 6 passes)", lambda p: ref(p, 3e-4, 6))[0])
+        res["settings"].append(run("eps 1e-3 (OSQP's default) + refine", lambda p: ref(p, 1e-3, 0))[0])
     for eps in (1e-5, 1e-6, 1e-7):
         def tight(p, eps=eps):
             p.eps_abs = p.eps_rel = eps
