@@ -298,13 +298,16 @@ __global__ void limits_kernel(int B, int N, const int *n_points, const double *v
 // One block (one wave) per path, lane = lateral sample.  Layers are visited in order (each needs the costs of the previous one); inside a
 // layer every lane scans the <= 64 nodes of the previous layer from LDS.  Parent indices of all layers stay in LDS for the walk back.
 constexpr int kDpMaxLayers = 512, kDpMaxLat = 64;
-__global__ __launch_bounds__(64) void dp_search_kernel(DevMap m, DevSpline in, DevSearch q) {
+// NW waves per instance: every wave carries all lateral samples (lane = node of the current layer) and evaluates the edges from every NW-th node of the
+// previous layer; the partial minima meet in LDS (cost first, then the smaller previous index: the reference's first-minimum order).  NW = 8 for small
+// batches (B <= 512): a single planning instance otherwise spends 47 layers x 34 x 34 edges, each with an atan2, on one wave — 2.35 ms against 0.92 ms.
+template <int NW> __global__ __launch_bounds__(64 * NW) void dp_search_kernel(DevMap m, DevSpline in, DevSearch q) {
     extern __shared__ double lds[];
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t o = (size_t)b * q.L;
     if (in.n_knots && (in.n_knots[b] < 3 || in.n_knots[b] > in.K)) {  // no spline (an earlier stage of a pipeline failed): nothing to search
-        for (int i = lane; i < q.L; i += 64) { q.layer_s[o + i] = 0; q.lb[o + i] = 0; q.ub[o + i] = 0; }
-        if (lane == 0) { q.n_layers[b] = -1; q.l0[b] = 0; }
+        for (int i = threadIdx.x; i < q.L; i += 64 * NW) { q.layer_s[o + i] = 0; q.lb[o + i] = 0; q.ub[o + i] = 0; }
+        if (threadIdx.x == 0) { q.n_layers[b] = -1; q.l0[b] = 0; }
         return;
     }
     const Spl2 S = stage_spline(in, b, lds);
@@ -315,6 +318,7 @@ __global__ __launch_bounds__(64) void dp_search_kernel(DevMap m, DevSpline in, D
     unsigned long long *fmask = reinterpret_cast<unsigned long long *>(lat + kDpMaxLat);  // [LM] feasibility bits
     unsigned char *parent = reinterpret_cast<unsigned char *>(fmask + LM);             // [LM][64]
     unsigned char *chosen = parent + LM * kDpMaxLat;                                    // [LM]
+    double *red = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(chosen + LM) + 15) & ~(uintptr_t)15);  // NW > 1: [NW][3][64] partial (cost, direction, index)
     __shared__ int s_L, s_rc;
     const double length = in.length[b], sx = q.start[3 * b], sy = q.start[3 * b + 1], sz = q.start[3 * b + 2];
     const double search_threshold = 1.45;
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(64) void dp_search_kernel(DevMap m, DevSpline in, D
         tmp_s0 = cur_s < length ? cur_s : length;
     }
     // ---- layers (running sum, like the reference) ----
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         const double search_ds = length > 6 ? q.long_spacing : 0.5;
         const int cap = LM;
         double t = tmp_s0;
@@ -370,8 +374,8 @@ __global__ __launch_bounds__(64) void dp_search_kernel(DevMap m, DevSpline in, D
         start_idx = (int)((q.range + vl) / q.lat_spacing);
     }
     if (rc) {
-        for (int i = lane; i < q.L; i += 64) { q.layer_s[o + i] = 0; q.lb[o + i] = 0; q.ub[o + i] = 0; }
-        if (lane == 0) { q.n_layers[b] = rc; q.l0[b] = vl; }
+        for (int i = threadIdx.x; i < q.L; i += 64 * NW) { q.layer_s[o + i] = 0; q.lb[o + i] = 0; q.ub[o + i] = 0; }
+        if (threadIdx.x == 0) { q.n_layers[b] = rc; q.l0[b] = vl; }
         return;
     }
     // lateral offsets by the reference's running sum; every lane keeps its own
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(64) void dp_search_kernel(DevMap m, DevSpline in, D
             const unsigned long long pm = fmask[i - 1];
             const double ps = ls[i - 1];
             double min_cost = 1.7976931348623157e308;
-            for (int k = 0; k < nlat; ++k) {
+            for (int k = wv; k < nlat; k += NW) {
                 if (!((pm >> k) & 1ull)) continue;
                 if (fabs(lat[k] - my_l) > (cur_s - ps)) continue;
                 const double direction = po_patan2(y - prv[kDpMaxLat + k], x - prv[k]);
@@ -411,6 +415,19 @@ __global__ __launch_bounds__(64) void dp_search_kernel(DevMap m, DevSpline in, D
                 if (total < min_cost) { min_cost = total; par = k; dir = direction; }
             }
             if (par != 255) cost = min_cost;
+        }
+        if constexpr (NW > 1) {  // the waves' partial minima -> the minimum over all previous nodes, first index on ties (what the sequential scan finds)
+            red[(wv * 3 + 0) * 64 + lane] = cost; red[(wv * 3 + 1) * 64 + lane] = dir; red[(wv * 3 + 2) * 64 + lane] = (double)par;
+            __syncthreads();
+            if (i > 0) {
+                cost = 1.7976931348623157e308; par = 255; dir = 0;
+#pragma unroll
+                for (int w2 = 0; w2 < NW; ++w2) {
+                    const double c2 = red[(w2 * 3 + 0) * 64 + lane];
+                    const int p2 = (int)red[(w2 * 3 + 2) * 64 + lane];
+                    if (p2 != 255 && (c2 < cost || (c2 == cost && p2 < par))) { cost = c2; par = p2; dir = red[(w2 * 3 + 1) * 64 + lane]; }
+                }
+            }
         }
         const bool any = __any(par != 255);
         if (i != 0 && !any) break;
@@ -429,14 +446,14 @@ __global__ __launch_bounds__(64) void dp_search_kernel(DevMap m, DevSpline in, D
     }
     int count = 0;
     if (bj != 0x7fffffff) {
-        if (lane == 0) {
+        if (threadIdx.x == 0) {
             int j = bj;
             for (int i = max_layer; i >= 0; --i) { chosen[i] = (unsigned char)j; j = parent[i * kDpMaxLat + j]; }
         }
         count = max_layer + 1;
     }
     __syncthreads();
-    for (int i = lane; i < q.L; i += 64) {
+    for (int i = threadIdx.x; i < q.L; i += 64 * NW) {
         double lo = 0, hi = 0, sv = 0;
         if (i < count) {
             sv = ls[i];
@@ -466,7 +483,7 @@ __global__ __launch_bounds__(64) void dp_search_kernel(DevMap m, DevSpline in, D
         }
         q.layer_s[o + i] = sv; q.lb[o + i] = lo; q.ub[o + i] = hi;
     }
-    if (lane == 0) { q.n_layers[b] = count; q.l0[b] = vl; }
+    if (threadIdx.x == 0) { q.n_layers[b] = count; q.l0[b] = vl; }
 }
 
 
@@ -820,9 +837,9 @@ extern "C" hipError_t po_launch_bounds(const po::DevMap *m, const po::DevBounds 
 }
 
 extern "C" size_t po_spline_lds_bytes(int K) { return sizeof(double) * 15 * (size_t)K; }
-extern "C" size_t po_dp_lds_bytes(int K, int L) {
+extern "C" size_t po_dp_lds_bytes(int K, int L) {  // (with the 8-wave variant's reduction scratch: the upper bound the capacity check uses)
     const size_t LM = (size_t)(L < po::kDpMaxLayers ? L : po::kDpMaxLayers);
-    return sizeof(double) * (15 * (size_t)K + LM + 2 * 4 * po::kDpMaxLat + po::kDpMaxLat) + 8 * LM + LM * po::kDpMaxLat + LM + 16;
+    return sizeof(double) * (15 * (size_t)K + LM + 2 * 4 * po::kDpMaxLat + po::kDpMaxLat) + 8 * LM + LM * po::kDpMaxLat + LM + 32 + sizeof(double) * 8 * 3 * 64;
 }
 extern "C" hipError_t po_launch_resample(const po::DevSpline *in, const po::DevResample *r, hipStream_t st) {
     hipLaunchKernelGGL(po::resample_kernel, dim3(in->B), dim3(64), po_spline_lds_bytes(in->K), st, *in, *r);
@@ -835,10 +852,17 @@ extern "C" hipError_t po_launch_limits(int B, int N, const int *n_points, const 
     return hipGetLastError();
 }
 extern "C" hipError_t po_launch_dp_search(const po::DevMap *m, const po::DevSpline *in, const po::DevSearch *q, hipStream_t st) {
-    const size_t lds = po_dp_lds_bytes(in->K, q->L);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&po::dp_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds4 = po_dp_lds_bytes(in->K, q->L), lds1 = lds4 - sizeof(double) * 8 * 3 * 64;
+    // few instances (a planner's own call: B = 1): eight waves per instance share the edge evaluations of a layer; a full batch keeps one wave per instance
+    if (in->B <= 512 && !std::getenv("PO_DP_ONE_WAVE")) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&po::dp_search_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(po::dp_search_kernel<8>, dim3(in->B), dim3(512), lds4, st, *m, *in, *q);
+        return hipGetLastError();
+    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&po::dp_search_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(po::dp_search_kernel, dim3(in->B), dim3(64), lds, st, *m, *in, *q);
+    hipLaunchKernelGGL(po::dp_search_kernel<1>, dim3(in->B), dim3(64), lds1, st, *m, *in, *q);
     return hipGetLastError();
 }
 
