@@ -206,18 +206,46 @@ __device__ __forceinline__ double spline_deriv(int K, const double *x, const dou
     return order == 1 ? (3.0 * a[idx] * h + 2.0 * b[idx]) * h + c[idx] : 6.0 * a[idx] * h + 2.0 * b[idx];
 }
 // the pair x(s), y(s) of one path, staged in LDS: s, x, y knots and a, b, c of both splines = 9 arrays of K doubles
+// the interval search of spline_eval / spline_deriv done once per argument (seven dependent LDS reads for K ~ 70): same arithmetic afterwards
+struct SplAt { int idx, side; double h; };  // side: -1 left of the first knot, +1 right of the last, 0 inside
+__device__ __forceinline__ SplAt spline_at(int K, const double *x, double at) {
+    int lo = 0, hi = K;  // std::lower_bound
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (x[mid] < at) lo = mid + 1; else hi = mid; }
+    SplAt p;
+    p.idx = lo - 1 > 0 ? lo - 1 : 0;
+    p.h = at - x[p.idx];
+    p.side = at < x[0] ? -1 : (at > x[K - 1] ? 1 : 0);
+    return p;
+}
+__device__ __forceinline__ double spline_eval_at(int K, const double *y, const double *a, const double *b, const double *c, const SplAt &p) {
+    if (p.side < 0) return (b[0] * p.h + c[0]) * p.h + y[0];
+    if (p.side > 0) return (b[K - 1] * p.h + c[K - 1]) * p.h + y[K - 1];
+    return ((a[p.idx] * p.h + b[p.idx]) * p.h + c[p.idx]) * p.h + y[p.idx];
+}
+__device__ __forceinline__ double spline_deriv_at(int K, const double *a, const double *b, const double *c, int order, const SplAt &p) {
+    if (p.side < 0) return order == 1 ? 2.0 * b[0] * p.h + c[0] : 2.0 * b[0] * p.h;
+    if (p.side > 0) return order == 1 ? 2.0 * b[K - 1] * p.h + c[K - 1] : 2.0 * b[K - 1];
+    return order == 1 ? (3.0 * a[p.idx] * p.h + 2.0 * b[p.idx]) * p.h + c[p.idx] : 6.0 * a[p.idx] * p.h + 2.0 * b[p.idx];
+}
 struct Spl2 {
     int K;
     const double *s, *vx, *vy, *ax, *bx, *cx, *ay, *by, *cy;
-    __device__ __forceinline__ double x(double at) const { return spline_eval(K, s, vx, ax, bx, cx, at); }
-    __device__ __forceinline__ double y(double at) const { return spline_eval(K, s, vy, ay, by, cy, at); }
-    __device__ __forceinline__ double dx(int o, double at) const { return spline_deriv(K, s, ax, bx, cx, o, at); }
-    __device__ __forceinline__ double dy(int o, double at) const { return spline_deriv(K, s, ay, by, cy, o, at); }
-    __device__ __forceinline__ double heading(double at) const { return po_patan2(dy(1, at), dx(1, at)); }  // getHeading, tools.cpp:34-38
-    __device__ __forceinline__ double curvature(double at) const {                                     // getCurvature, tools.cpp:40-46
-        const double x1 = dx(1, at), y1 = dy(1, at), x2 = dx(2, at), y2 = dy(2, at);
+    __device__ __forceinline__ SplAt at(double t) const { return spline_at(K, s, t); }
+    __device__ __forceinline__ double x(const SplAt &p) const { return spline_eval_at(K, vx, ax, bx, cx, p); }
+    __device__ __forceinline__ double y(const SplAt &p) const { return spline_eval_at(K, vy, ay, by, cy, p); }
+    __device__ __forceinline__ double dx(int o, const SplAt &p) const { return spline_deriv_at(K, ax, bx, cx, o, p); }
+    __device__ __forceinline__ double dy(int o, const SplAt &p) const { return spline_deriv_at(K, ay, by, cy, o, p); }
+    __device__ __forceinline__ double heading(const SplAt &p) const { return po_patan2(dy(1, p), dx(1, p)); }
+    __device__ __forceinline__ double curvature(const SplAt &p) const {
+        const double x1 = dx(1, p), y1 = dy(1, p), x2 = dx(2, p), y2 = dy(2, p);
         return (x1 * y2 - y1 * x2) / po_ppow15(x1 * x1 + y1 * y1);
     }
+    __device__ __forceinline__ double x(double t) const { return x(at(t)); }
+    __device__ __forceinline__ double y(double t) const { return y(at(t)); }
+    __device__ __forceinline__ double dx(int o, double t) const { return dx(o, at(t)); }
+    __device__ __forceinline__ double dy(int o, double t) const { return dy(o, at(t)); }
+    __device__ __forceinline__ double heading(double t) const { return heading(at(t)); }      // getHeading, tools.cpp:34-38
+    __device__ __forceinline__ double curvature(double t) const { return curvature(at(t)); }  // getCurvature, tools.cpp:40-46
 };
 // Knots into LDS, then the two natural-spline fits (x(s) and y(s)) by lanes 0 and 1 right there: 15 K doubles of LDS
 // (s, x, y | a, b, c + 3 K scratch for each spline).  No separate fit kernel, no coefficient round trip through HBM.
@@ -276,8 +304,8 @@ __global__ __launch_bounds__(64) void resample_kernel(DevSpline in, DevResample 
     const int n = s_n < 0 ? 0 : s_n;
     for (int i = threadIdx.x; i < r.N; i += 64) {
         if (i < n) {
-            const double at = r.s[o + i];
-            r.x[o + i] = S.x(at); r.y[o + i] = S.y(at); r.z[o + i] = S.heading(at);
+            const SplAt pi_ = S.at(r.s[o + i]);
+            r.x[o + i] = S.x(pi_); r.y[o + i] = S.y(pi_); r.z[o + i] = S.heading(pi_);
         } else { r.x[o + i] = 0; r.y[o + i] = 0; r.z[o + i] = 0; r.k[o + i] = 0; r.s[o + i] = 0; }
     }
 }
@@ -328,7 +356,8 @@ template <int NW> __global__ __launch_bounds__(64 * NW) void dp_search_kernel(De
         double best = 1.7976931348623157e308;
         int bestk = 0x7fffffff;
         for (int k = lane; 0.5 * k <= length; k += 64) {  // tmp_s = 0.5 k exactly (the reference's running sum of 0.5 is exact)
-            const double at = 0.5 * k, ddx = S.x(at) - sx, ddy = S.y(at) - sy;
+            const SplAt pk = S.at(0.5 * k);
+            const double ddx = S.x(pk) - sx, ddy = S.y(pk) - sy;
             const double d = sqrt(ddx * ddx + ddy * ddy);
             if (d < best) { best = d; bestk = k; }
         }
@@ -339,7 +368,8 @@ template <int NW> __global__ __launch_bounds__(64 * NW) void dp_search_kernel(De
         }
         double cur_s = 0.5 * bestk, prev_s = cur_s;
         for (int i = 0; i < 20; ++i) {
-            const double px = S.x(cur_s), py = S.y(cur_s), dx = S.dx(1, cur_s), dy = S.dy(1, cur_s), ddx = S.dx(2, cur_s), ddy = S.dy(2, cur_s);
+            const SplAt pc = S.at(cur_s);
+            const double px = S.x(pc), py = S.y(pc), dx = S.dx(1, pc), dy = S.dy(1, pc), ddx = S.dx(2, pc), ddy = S.dy(2, pc);
             const double j = (px - sx) * dx + (py - sy) * dy;
             const double hh = dx * dx + (px - sx) * ddx + dy * dy + (py - sy) * ddy;
             cur_s -= j / hh;
@@ -367,7 +397,8 @@ template <int NW> __global__ __launch_bounds__(64 * NW) void dp_search_kernel(De
     double vl = 0;
     int start_idx = 0;
     if (!rc) {
-        const double vs = ls[0], pxr = S.x(vs), pyr = S.y(vs), pz = S.heading(vs);
+        const SplAt pv = S.at(ls[0]);
+        const double pxr = S.x(pv), pyr = S.y(pv), pz = S.heading(pv);
         const double dx = sx - pxr, dy = sy - pyr;
         vl = -dx * po_psin(pz) + dy * po_pcos(pz);  // global2Local(proj_point, start_state).y
         if (fabs(vl) > q.range) rc = -1;
@@ -389,7 +420,8 @@ template <int NW> __global__ __launch_bounds__(64 * NW) void dp_search_kernel(De
     double last_cost = 1.7976931348623157e308;  // this lane's cost in layer max_layer
     for (int i = 0; i < L; ++i) {
         const double cur_s = ls[i];
-        const double rx = S.x(cur_s), ry = S.y(cur_s), rh = S.heading(cur_s), rk = S.curvature(cur_s), rr = 1 / rk;
+        const SplAt pa = S.at(cur_s);
+        const double rx = S.x(pa), ry = S.y(pa), rh = S.heading(pa), rk = S.curvature(pa), rr = 1 / rk;
         double *cur = nx + (i & 1) * 4 * kDpMaxLat, *prv = nx + ((i & 1) ^ 1) * 4 * kDpMaxLat;
         const double x = rx + my_l * po_pcos(rh + M_PI_2), y = ry + my_l * po_psin(rh + M_PI_2);
         const double dis = map_inside(m, x, y) ? map_distance(m, x, y) : -1;
@@ -468,7 +500,8 @@ template <int NW> __global__ __launch_bounds__(64 * NW) void dp_search_kernel(De
                 }
                 const double check_s = 0.2, check_limit = 6.0;
                 hi = check_s + lat[jb]; lo = -check_s + lat[ja];
-                const double rx = S.x(sv), ry = S.y(sv), rh = S.heading(sv);
+                const SplAt ps = S.at(sv);
+                const double rx = S.x(ps), ry = S.y(ps), rh = S.heading(ps);
                 while (hi < check_limit) {
                     const double px2 = rx + hi * po_pcos(rh + M_PI_2), py2 = ry + hi * po_psin(rh + M_PI_2);
                     if (map_inside(m, px2, py2) && map_distance(m, px2, py2) > search_threshold) hi += check_s;
@@ -592,10 +625,12 @@ __global__ __launch_bounds__(64) void segment_raw_kernel(DevSpline in, int P, do
     const Spl2 S = stage_spline(in, b, lds);
     for (int i = lane; i < P; i += 64) {
         if (i < n) {
-            const double at = (double)i, dx = S.dx(1, at), dy = S.dy(1, at), ddx = S.dx(2, at), ddy = S.dy(2, at);
+            const double at = (double)i;
+            const SplAt pa = S.at(at);
+            const double dx = S.dx(1, pa), dy = S.dy(1, pa), ddx = S.dx(2, pa), ddy = S.dy(2, pa);
             angle[o + i] = po_patan2(dy, dx);
             k[o + i] = (dx * ddy - dy * ddx) / po_ppow15(dx * dx + dy * dy);
-            x[o + i] = S.x(at); y[o + i] = S.y(at); s[o + i] = at;
+            x[o + i] = S.x(pa); y[o + i] = S.y(pa); s[o + i] = at;
         } else { x[o + i] = 0; y[o + i] = 0; s[o + i] = 0; angle[o + i] = 0; k[o + i] = 0; }
     }
     if (lane == 0) n_points[b] = n;
@@ -619,9 +654,11 @@ __global__ __launch_bounds__(64) void post_project_kernel(DevSpline in, int L, c
     for (int i = lane; i < L; i += 64) {
         double ox = 0, oy = 0;
         if (i < n) {
-            const double ref_s = layer_s[o + i], ref_dir = S.heading(ref_s);
-            ox = S.x(ref_s) + off[o + i] * po_pcos(ref_dir + M_PI_2);
-            oy = S.y(ref_s) + off[o + i] * po_psin(ref_dir + M_PI_2);
+            const double ref_s = layer_s[o + i];
+            const SplAt pr = S.at(ref_s);
+            const double ref_dir = S.heading(pr);
+            ox = S.x(pr) + off[o + i] * po_pcos(ref_dir + M_PI_2);
+            oy = S.y(pr) + off[o + i] * po_psin(ref_dir + M_PI_2);
         }
         x[o + i] = ox; y[o + i] = oy;
     }
@@ -711,7 +748,8 @@ __global__ __launch_bounds__(128) void densify_kernel(DevMap m, DevCar c, int B,
         double v[5] = {0, 0, 0, 0, 0};
         if (i < lim) {
             const double at = (double)i * spacing;
-            v[0] = S.x(at); v[1] = S.y(at); v[2] = S.heading(at); v[3] = S.curvature(at); v[4] = at;
+            const SplAt pa = S.at(at);
+            v[0] = S.x(pa); v[1] = S.y(pa); v[2] = S.heading(pa); v[3] = S.curvature(pa); v[4] = at;
             if (c.enable && !collision_free(m, c, v[0], v[1], v[2])) atomicMin(&first, i);
         }
         for (int j = 0; j < 5; ++j) o[5 * i + j] = v[j];
