@@ -660,6 +660,8 @@ int po_smooth_batch_device(po_handle h, const po_smooth_in *in, const po_smooth_
     D.map = h->map;
     D.perm_bits = 0;
     { const char *e = std::getenv("PO_SMOOTH_SEQ"); D.seq_band = (e && e[0] == '1') ? 1 : 0; }
+    { const char *e = std::getenv("PO_SMOOTH_WAVES"); D.waves = e ? std::atoi(e) : 0; }
+    { const char *e = std::getenv("PO_SMOOTH_NOPAD"); D.nopad = (e && e[0] == '1') ? 1 : 0; }
     if (!std::getenv("PO_IDENTITY_ORDER") && in->B > 8)
         while ((1 << D.perm_bits) < in->B) ++D.perm_bits;
     const bool dbg = std::getenv("PO_SMOOTH_DEBUG") != nullptr;  // dev tool: per-phase cycle totals of instance 0..B-1 printed to stderr

@@ -48,6 +48,16 @@ constexpr int kKT = 4;  // a variable appears in at most 4 rows in all three QPs
 
 template <int W> __host__ __device__ constexpr int col_stride() { return (W + 2) & ~1; }  // dinv + W entries, padded to 16 bytes
 template <int W> __host__ __device__ constexpr int col_pad() { return 4 * W; }            // zero columns past n: the sweeps need no guards
+constexpr int kChunkPad = 72;  // doubles: one per chunk of the partitioned substitution (at most 64 chunks own rows, the zero padding columns reach a few further)
+// Rows per lane of the partitioned substitution (narrow bands, W <= 4): a multiple of W; 0 when the QP is too small to give every chunk W rows inside the
+// zero padding (the single-lane window then).  From 6 rows per lane on, the chunks are laid out bank-conflict-free (see Prob::cch); below that the natural
+// layout's conflicts are mild and the extra LDS would cost a resident QP per CU.
+template <int W> __host__ __device__ constexpr int scan_chunk(int n) {
+    const int c = ((n + 63) / 64 + W - 1) / W * W;
+    return c * ((n + c - 1) / c) <= n + col_pad<W>() ? c : 0;
+}
+__host__ __device__ constexpr bool scan_padded(int c) { return c >= 6; }
+
 
 // LDS carve-up (doubles first, then 16-bit and 8-bit tables)
 template <int KIND> struct Lds {
@@ -56,6 +66,9 @@ template <int KIND> struct Lds {
     static __host__ __device__ size_t bytes(int P) {
         const size_t n = (size_t)T::n(P), m = (size_t)T::m(P), np = n + col_pad<T::W>();
         size_t d = np * LS + (size_t)T::KA * m + n + np + 3 * m;  // Lb, Av, x, wk, v, l, u  (q and the dy / scaling scratch tm live in the HBM block)
+        if constexpr (T::W <= 4) {
+            if (scan_padded(scan_chunk<T::W>((int)n))) d += kChunkPad + np + kChunkPad;  // chunk-padded factor, wkp (the partitioned substitution's right-hand side)
+        }
         size_t b = d * 8 + ((size_t)T::KA * m + (size_t)kKT * n) * 2 + n * 4 + m + 8;
         return (b + 15) & ~(size_t)15;
     }
@@ -75,18 +88,31 @@ template <int KIND> struct Prob {  // views into LDS + scratch for one QP
     int *Tc;
     uint8_t *cls;
     double *Pb, *Dv, *Ev;  // HBM scratch: Pb[d*n + j] = P[j][j+d] (scaled), D[n], E[m], then q[n] and tm[m]
+    // Partitioned substitution (narrow bands): lane t owns the cch rows [t cch, (t + 1) cch).  In the natural layout the lanes of a wave would read the factor
+    // cch LS doubles apart and the right-hand side cch doubles apart — even strides, 16- to 64-way LDS bank conflicts (measured: 60 % of the LDS-active
+    // cycles).  So the factor carries one dead double per chunk (lane stride cch LS + 1: odd) and the substitution works on wkp, a copy of wk with one dead
+    // double per chunk when cch is even.  cch == 0: natural layout (single-lane substitution).
+    int cch, wpad;
+    float rcch;
+    double *wkp;
+    __device__ __forceinline__ int chunk_of(int j) const { return (int)(((float)j + 0.5f) * rcch); }  // j / cch, exact for j < 2^16
+    __device__ __forceinline__ int lcol(int j) const {  // offset of factor column j in Lb
+        if constexpr (W <= 4) return j * LS + (cch ? chunk_of(j) : 0);
+        else return j * LS;
+    }
+    __device__ __forceinline__ int pidx(int j) const { return j + chunk_of(j) * wpad; }  // offset of row j in wkp (cch != 0)
     __device__ __forceinline__ void setA(int r, int s, int col, double val) { Av[s * m + r] = val; Ac[s * m + r] = (uint16_t)col; }
     __device__ __forceinline__ void setRow(int r, double lo, double hi) { l[r] = lo; u[r] = hi; }
     __device__ __forceinline__ void setP(int j, int d, double val) { Lb[j * LS + d] = val; }  // P band parked in the factor storage during setup
 };
 
 // ---- assemblies: rows in point order; values follow the reference expressions term by term ----------------------------------
-template <int KIND> __device__ void assemble(const DevSmooth &a, Prob<KIND> &pb, int b, int P, int lane) {
+template <int KIND> __device__ void assemble(const DevSmooth &a, Prob<KIND> &pb, int b, int P, int lane, int nts = 64) {  // lane: thread index, nts: threads of the block
     const size_t o = (size_t)b * a.P;
     if constexpr (KIND == PO_SMOOTH_TENSION2) {
         // tension_smoother_2.cpp:220-241 (Hessian), :288-299 (gradient), :243-286 (constraints)
         const double wd = a.w[0], wc = a.w[1], wr = a.w[2];
-        for (int i = lane; i < P; i += 64) {
+        for (int i = lane; i < P; i += nts) {
             const double xi = a.x[o + i], yi = a.y[o + i];
             pb.setP(4 * i, 0, wd * 2); pb.setP(4 * i + 1, 0, wd * 2); pb.setP(4 * i + 2, 0, 0.0);
             pb.q[4 * i] = -2 * wd * xi; pb.q[4 * i + 1] = -2 * wd * yi; pb.q[4 * i + 2] = 0;
@@ -117,7 +143,7 @@ template <int KIND> __device__ void assemble(const DevSmooth &a, Prob<KIND> &pb,
         // tension_smoother.cpp:238-261 (Hessian: [1 -2 1] and [-1 3 -3 1] stencils on x and on y), :263-314 (constraints)
         const double wc = a.w[3], wcr = a.w[4], wdev = a.w[5];
         const double v3[3] = {1, -2, 1}, v4[4] = {-1, 3, -3, 1};
-        for (int i = lane; i < P; i += 64) {
+        for (int i = lane; i < P; i += nts) {
             for (int e = 0; e <= 3; ++e) {  // H[i][i+e], accumulated block by block like the reference's loop
                 double acc = 0;
                 if (i + e < P)
@@ -145,7 +171,7 @@ template <int KIND> __device__ void assemble(const DevSmooth &a, Prob<KIND> &pb,
         }
     } else {
         // reference_path_smoother.cpp:598-612 (Hessian), :614-650 (constraints)
-        for (int i = lane; i < P; i += 64) {
+        for (int i = lane; i < P; i += nts) {
             pb.setP(3 * i, 0, 1.0); pb.setP(3 * i + 1, 0, 100.0); pb.setP(3 * i + 2, 0, 1000.0);
             pb.q[3 * i] = 0; pb.q[3 * i + 1] = 0; pb.q[3 * i + 2] = 0;
             pb.setA(3 * i, 0, 3 * i, 1.0); pb.setA(3 * i, 1, 3 * i, 0.0); pb.setA(3 * i, 2, 3 * i, 0.0);
@@ -174,11 +200,19 @@ template <int KIND> __device__ __forceinline__ double rho_row(const Prob<KIND> &
 }
 
 // M = P + sigma I + A' diag(rho) A into the band storage, then right-looking banded LDL' (column j: dinv, L[j+1..j+W][j]).
-template <int KIND> __device__ void factorise(Prob<KIND> &pb, double rho, double sigma, int lane) {
+// Barrier of the threads that work on one band: the block when it is one wave, wave 0 alone when the block has more (the pivot loop and the partitioned
+// substitution run on wave 0 only; a wave's LDS operations complete in order, so draining its own counters is all the ordering they need).
+template <int NWV> __device__ __forceinline__ void band_sync() {
+    if constexpr (NWV == 1) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+}
+
+template <int KIND, int NWV = 1> __device__ void factorise(Prob<KIND> &pb, double rho, double sigma, int tid, int lane) {  // tid: thread of the block; lane: lane of the block's serial wave (outside 0 .. 63 on the others) — the pivot loop works on lanes 0 .. W (W + 1) / 2 - 1
     using T = ST<KIND>;
-    constexpr int W = T::W, LS = Prob<KIND>::LS, KA = T::KA, WP = T::WP;
+    constexpr int W = T::W, KA = T::KA, WP = T::WP;
+    constexpr int nts = 64 * NWV;
     const int n = pb.n, m = pb.m;
-    for (int j = lane; j < pb.np; j += 64) {
+    for (int j = tid; j < pb.np; j += nts) {
         double col[W + 1];
 #pragma unroll
         for (int d = 0; d <= W; ++d) col[d] = 0;
@@ -203,8 +237,9 @@ template <int KIND> __device__ void factorise(Prob<KIND> &pb, double rho, double
                 }
             }
         }
+        { const int bj = pb.lcol(j);
 #pragma unroll
-        for (int d = 0; d <= W; ++d) pb.Lb[j * LS + d] = col[d];
+        for (int d = 0; d <= W; ++d) pb.Lb[bj + d] = col[d]; }
     }
     __syncthreads();
     // lane -> (a, b), 1 <= a <= b <= W
@@ -218,23 +253,26 @@ template <int KIND> __device__ void factorise(Prob<KIND> &pb, double rho, double
             t -= len;
         }
     }
+    if (NWV == 1 || (unsigned)lane < 64u)
     for (int j = 0; j < n; ++j) {
-        const double d = pb.Lb[j * LS];
+        const int bj = pb.lcol(j);
+        const double d = pb.Lb[bj];
         const double dinv = 1.0 / d;
         double mine = 0;
-        if (lane >= 1 && lane <= W) mine = pb.Lb[j * LS + lane];
+        if (lane >= 1 && lane <= W) mine = pb.Lb[bj + lane];
         if (lane < NPAIR) {
-            const double ca = pb.Lb[j * LS + pa], cb = pb.Lb[j * LS + pbb];
-            pb.Lb[(j + pa) * LS + (pbb - pa)] -= ca * dinv * cb;
+            const double ca = pb.Lb[bj + pa], cb = pb.Lb[bj + pbb];
+            pb.Lb[pb.lcol(j + pa) + (pbb - pa)] -= ca * dinv * cb;
         }
-        __syncthreads();
-        if (lane == 0) pb.Lb[j * LS] = dinv;
-        else if (lane <= W) pb.Lb[j * LS + lane] = mine * dinv;
-        __syncthreads();
+        band_sync<NWV>();
+        if (lane == 0) pb.Lb[bj] = dinv;
+        else if (lane <= W) pb.Lb[bj + lane] = mine * dinv;
+        band_sync<NWV>();
     }
-    for (int j = n + lane; j < pb.np; j += 64) {  // padding columns: the trailing updates of the last columns spilled into them
+    if constexpr (NWV > 1) __syncthreads();  // the trailing updates of the last columns land in the padding columns cleared below
+    for (int j = n + tid; j < pb.np; j += nts) {  // padding columns: the trailing updates of the last columns spilled into them
 #pragma unroll
-        for (int d = 0; d <= W; ++d) pb.Lb[j * LS + d] = 0;
+        for (int d = 0; d <= W; ++d) pb.Lb[pb.lcol(j) + d] = 0;
     }
     __syncthreads();
 }
@@ -411,18 +449,24 @@ template <int W, bool UP> __device__ __forceinline__ AffW<W> aff_shift(const Aff
     }
     return o;
 }
-template <int KIND> __device__ __forceinline__ void band_solve_scan(Prob<KIND> &pb, int lane, int c) {
+template <int KIND, int NWV = 1> __device__ __forceinline__ void band_solve_scan(Prob<KIND> &pb, int lane, int c) {
     using T = ST<KIND>;
     constexpr int W = T::W, LS = Prob<KIND>::LS;
     static_assert(W <= 4, "wide bands keep band_solve_lanes");
     const double *__restrict__ Lb = pb.Lb;
-    double *__restrict__ wk = pb.wk;
+    const bool pad = pb.cch != 0;
+    double *wk = pad ? pb.wkp : pb.wk;  // chunk-padded copy: the caller's right-hand side is there; rows j0 .. j0 + c - 1 at wk + wb
+    double *wout = pb.wk;               // the solution goes to the natural layout (stores: off the latency path, their bank conflicts cost nothing)
     const int nl = (pb.n + c - 1) / c;  // lanes that own rows (the last one may own padding rows: zero factor columns, zero right-hand side)
     const int j0 = lane * c;
     const bool own = lane < nl;
+    const int lb = pad ? lane : 0, lbp = pad ? lane - 1 : 0, wb = pad ? lane * pb.wpad : 0;  // this lane's dead doubles before its chunk: factor column j at Lb[j LS + lb], row j at wk[j + wb]
     // ================= forward: L y = b, stored as z = D^-1 y =================
     // row form: y_j = b_j - sum_{d = 1..W} L[j][j - d] y_{j - d},  L[j][j - d] = Lb[(j - d) LS + d]
-    auto lrow = [&](int j, int d) -> double { const int cidx = j - d; return cidx >= 0 ? Lb[cidx * LS + d] : 0.0; };
+    auto lrow = [&](int j, int d) -> double {  // (the first W rows of a chunk reach into the previous lane's columns)
+        const int cidx = j - d;
+        return cidx >= 0 ? Lb[cidx * LS + d + (cidx >= j0 ? lb : lbp)] : 0.0;
+    };
     AffW<W> el;
 #pragma unroll
     for (int i = 0; i < W; ++i) {
@@ -446,7 +490,7 @@ template <int KIND> __device__ __forceinline__ void band_solve_scan(Prob<KIND> &
                 double lr[W];
 #pragma unroll
                 for (int d = 1; d <= W; ++d) lr[d - 1] = lrow(j, d);
-                double accp = wk[j];
+                double accp = wk[j + wb];
 #pragma unroll
                 for (int d = 1; d <= W; ++d) accp -= lr[d - 1] * wp[(uu - d + 4 * W) % W];
                 double acch[W];
@@ -487,16 +531,16 @@ template <int KIND> __device__ __forceinline__ void band_solve_scan(Prob<KIND> &
 #pragma unroll
                 for (int uu = 0; uu < W; ++uu) {
                     const int j = j0 + jb + uu;
-                    double acc = wk[j];
+                    double acc = wk[j + wb];
 #pragma unroll
                     for (int d = 1; d <= W; ++d) acc -= lrow(j, d) * wp[(uu - d + 4 * W) % W];
                     wp[uu] = acc;
-                    wk[j] = acc * Lb[j * LS];
+                    wk[j + wb] = acc * Lb[j * LS + lb];
                 }
             }
         }
     }
-    __syncthreads();
+    band_sync<NWV>();
     // ================= backward: L' x = z,  x_j = z_j - sum_{d = 1..W} Lb[j LS + d] x_{j + d} =================
 #pragma unroll
     for (int i = 0; i < W; ++i) {
@@ -519,8 +563,8 @@ template <int KIND> __device__ __forceinline__ void band_solve_scan(Prob<KIND> &
                 const int j = j0 + jb + uu;
                 double lc[W];
 #pragma unroll
-                for (int d = 1; d <= W; ++d) lc[d - 1] = Lb[j * LS + d];
-                double accp = wk[j];
+                for (int d = 1; d <= W; ++d) lc[d - 1] = Lb[j * LS + lb + d];
+                double accp = wk[j + wb];
 #pragma unroll
                 for (int d = 1; d <= W; ++d) accp -= lc[d - 1] * wp[(uu + d) % W];
                 double acch[W];
@@ -559,33 +603,67 @@ template <int KIND> __device__ __forceinline__ void band_solve_scan(Prob<KIND> &
 #pragma unroll
                 for (int uu = W - 1; uu >= 0; --uu) {
                     const int j = j0 + jb + uu;
-                    double acc = wk[j];
+                    double acc = wk[j + wb];
 #pragma unroll
-                    for (int d = 1; d <= W; ++d) acc -= Lb[j * LS + d] * wp[(uu + d) % W];
+                    for (int d = 1; d <= W; ++d) acc -= Lb[j * LS + lb + d] * wp[(uu + d) % W];
                     wp[uu] = acc;
-                    wk[j] = acc;
+                    wout[j] = acc;
                 }
             }
         }
     }
 }
 
+
+// reductions over the block: NWV waves (the smoothing kernels run one wave per QP in a full batch, four for small batches)
+template <int NWV> __device__ __forceinline__ double blk_max(double v, double *red) {
+    v = wave_max(v);
+    if constexpr (NWV > 1) {
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        v = red[0];
+#pragma unroll
+        for (int k = 1; k < NWV; ++k) v = fmax(v, red[k]);
+    }
+    return v;
+}
+template <int NWV> __device__ __forceinline__ double blk_sum(double v, double *red) {
+    v = wave_sum(v);
+    if constexpr (NWV > 1) {
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        v = red[0];
+#pragma unroll
+        for (int k = 1; k < NWV; ++k) v += red[k];
+    }
+    return v;
+}
+
 #define PO_TICK(slot)                                                   \
     do {                                                                \
         if (a.dbg_cycles) { const long long t_ = clock64(); acc_[slot] += t_ - tprev_; tprev_ = t_; } \
     } while (0)
-template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmooth a) {
+// NWV waves per QP, WPE resident waves per SIMD the registers are allocated for.
+//  <1, 1>: one wave per QP — many small QPs per CU (each SIMD holds several QPs' waves).
+//  <4, 3>, <4, 2>, <8, 2> (narrow bands only): every row / variable loop of an iteration (right-hand side, update, residuals, scaling, assembly) runs on the
+//  whole block; the substitution and the pivot loop stay on wave 0.  Taken whenever the LDS footprint leaves a CU with three QPs or fewer (one wave per QP
+//  would idle the other SIMDs) and for batches that fit the chip at once — a planner's own call is ONE QP.
+template <int KIND, int NWV, int WPE> __global__ __launch_bounds__(64 * NWV, WPE) void smooth_kernel(DevSmooth a) {
+    constexpr int NTS = 64 * NWV;
+    __shared__ double red_[8];
     long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = a.dbg_cycles ? clock64() : 0;
     using T = ST<KIND>;
     constexpr int W = T::W, LS = Prob<KIND>::LS, KA = T::KA, WP = T::WP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int b = perm_index(blockIdx.x, a.perm_bits, a.B), lane = threadIdx.x;  // iteration counts vary 10x between instances (post QP)
+    const int b = perm_index(blockIdx.x, a.perm_bits, a.B), lane = threadIdx.x;  // (lane = thread index of the block: 0 .. NTS - 1)  // iteration counts vary 10x between instances (post QP)
     const int P = a.n_points ? a.n_points[b] : a.P;
     const size_t o = (size_t)b * a.P;
     po_info info{};
     info.status = PO_STATUS_UNSOLVED;
     if (P < T::MINP || P > a.P) {  // misuse inside a device-pointer batch: no abort, flagged per instance
-        for (int i = lane; i < a.P; i += 64) {
+        for (int i = lane; i < a.P; i += NTS) {
             a.out_x[o + i] = 0;
             if (a.out_y) a.out_y[o + i] = 0;
             if (a.out_s) a.out_s[o + i] = 0;
@@ -595,12 +673,19 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
     }
     Prob<KIND> pb;
     const int n = pb.n = T::n(P), m = pb.m = T::m(P), np = pb.np = n + col_pad<W>();
+    int cfull = 0;  // the LDS block is sized for a.P points
+    if constexpr (W <= 4) cfull = scan_chunk<W>(T::n(a.P));
+    const bool lds_pad = scan_padded(cfull);
+    // the serial parts (pivot loop, substitution) run on wave 0 of the block (rotating the wave with the block index, to spread the QPs of a CU over the
+    // SIMDs by hand, measured 10 % slower: the dispatcher already does it)
     {
         double *dp = reinterpret_cast<double *>(smem_raw);
-        pb.Lb = dp; dp += (size_t)np * LS;
+        pb.Lb = dp; dp += (size_t)np * LS + (lds_pad ? kChunkPad : 0);
         pb.Av = dp; dp += KA * m;
         pb.x = dp; dp += n;
         pb.wk = dp; dp += np;
+        pb.wkp = nullptr;
+        if constexpr (W <= 4) { if (lds_pad) { pb.wkp = dp; dp += np + kChunkPad; } }
         pb.v = dp; dp += m;
         pb.l = dp; dp += m;
         pb.u = dp; dp += m;
@@ -613,16 +698,25 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
         pb.Pb = sc; pb.Dv = sc + (size_t)(WP + 1) * T::n(a.P); pb.Ev = pb.Dv + T::n(a.P);
         pb.q = pb.Ev + T::m(a.P); pb.tm = pb.q + T::n(a.P);  // q[j] is only ever touched by lane j % 64; tm crosses lanes behind __syncthreads
     }
-    for (int i = lane; i < np * LS; i += 64) pb.Lb[i] = 0;
-    for (int i = lane; i < np; i += 64) pb.wk[i] = 0;
-    for (int i = lane; i < n; i += 64) { pb.x[i] = 0; pb.Tc[i] = 0; }
-    for (int i = lane; i < m; i += 64) pb.v[i] = 0;
+    // narrow bands (W = 3, 4): the substitution is partitioned over the lanes of a wave (chunks of c rows, c a multiple of W, every row's read-ahead inside
+    // the zero padding); QPs too small to give every chunk W rows keep the single-lane window
+    int cscan = 0;
+    pb.cch = 0; pb.wpad = 0; pb.rcch = 0;
+    if constexpr (W <= 4) {
+        cscan = a.seq_band ? 0 : scan_chunk<W>(n);
+        if (lds_pad && scan_padded(cscan) && !a.nopad) { pb.cch = cscan; pb.wpad = (cscan & 1) ? 0 : 1; pb.rcch = 1.0f / (float)cscan; }
+    }
+    for (int i = lane; i < np * LS + (lds_pad ? kChunkPad : 0); i += NTS) pb.Lb[i] = 0;  // (the P band is parked here in the natural layout until the first factorisation)
+    for (int i = lane; i < np; i += NTS) pb.wk[i] = 0;
+    if (pb.wkp) for (int i = lane; i < np + kChunkPad; i += NTS) pb.wkp[i] = 0;
+    for (int i = lane; i < n; i += NTS) { pb.x[i] = 0; pb.Tc[i] = 0; }
+    for (int i = lane; i < m; i += NTS) pb.v[i] = 0;
     __syncthreads();
-    assemble<KIND>(a, pb, b, P, lane);
+    assemble<KIND>(a, pb, b, P, lane, NTS);
     __syncthreads();
 
     // ---- transposed index lists (variable -> rows), deterministic: count with LDS atomics, then sort each short list ----
-    for (int e = lane; e < KA * m; e += 64) {
+    for (int e = lane; e < KA * m; e += NTS) {
         const int s = e / m, r = e - s * m;
         if (pb.Av[e] != 0.0) {
             const int c = pb.Ac[e];
@@ -631,7 +725,7 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
         }
     }
     __syncthreads();
-    for (int j = lane; j < n; j += 64) {
+    for (int j = lane; j < n; j += NTS) {
         const int cnt = pb.Tc[j] < kKT ? pb.Tc[j] : kKT;
         pb.Tc[j] = cnt;
         for (int i = 1; i < cnt; ++i) {
@@ -646,15 +740,15 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
     // ---- data validation (OSQP validate_data: l <= u, else setup fails and the reference's initSolver() returns false) ----
     {
         double bad = 0;
-        for (int r = lane; r < m; r += 64) bad = fmax(bad, pb.l[r] > pb.u[r] ? 1.0 : 0.0);
-        bad = wave_max(bad);
+        for (int r = lane; r < m; r += NTS) bad = fmax(bad, pb.l[r] > pb.u[r] ? 1.0 : 0.0);
+        bad = blk_max<NWV>(bad, red_);
         if (bad > 0) {
-            for (int i = lane; i < a.P; i += 64) {
+            for (int i = lane; i < a.P; i += NTS) {
                 a.out_x[o + i] = 0;
                 if (a.out_y) a.out_y[o + i] = 0;
                 if (a.out_s) a.out_s[o + i] = 0;
             }
-            if (a.raw) for (int j = lane; j < a.raw_stride; j += 64) a.raw[(size_t)b * a.raw_stride + j] = 0;
+            if (a.raw) for (int j = lane; j < a.raw_stride; j += NTS) a.raw[(size_t)b * a.raw_stride + j] = 0;
             info.status = PO_STATUS_PRIMAL_INFEASIBLE;
             info.rho = a.rho0;
             if (lane == 0) a.info[b] = info;
@@ -664,10 +758,10 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
 
     // ---- Ruiz equilibration (OSQP scale_data), P band parked in Lb, D in wk-free storage: Dv/Ev in scratch ----
     double cscale = 1.0;
-    for (int j = lane; j < n; j += 64) pb.Dv[j] = 1.0;
-    for (int r = lane; r < m; r += 64) pb.Ev[r] = 1.0;
+    for (int j = lane; j < n; j += NTS) pb.Dv[j] = 1.0;
+    for (int r = lane; r < m; r += NTS) pb.Ev[r] = 1.0;
     for (int pass = 0; pass < a.scaling; ++pass) {
-        for (int j = lane; j < n; j += 64) {  // column inf-norm of [P; A]
+        for (int j = lane; j < n; j += NTS) {  // column inf-norm of [P; A]
             double cn = 0;
 #pragma unroll
             for (int d = 0; d <= WP; ++d) {
@@ -681,14 +775,14 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
             }
             pb.wk[j] = 1.0 / sqrt(lim_scaling(cn));
         }
-        for (int r = lane; r < m; r += 64) {
+        for (int r = lane; r < m; r += NTS) {
             double rn = 0;
 #pragma unroll
             for (int s = 0; s < KA; ++s) rn = fmax(rn, fabs(pb.Av[s * m + r]));
             pb.tm[r] = 1.0 / sqrt(lim_scaling(rn));
         }
         __syncthreads();
-        for (int j = lane; j < n; j += 64) {
+        for (int j = lane; j < n; j += NTS) {
             const double dj = pb.wk[j];
 #pragma unroll
             for (int d = 0; d <= WP; ++d)
@@ -696,7 +790,7 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
             pb.q[j] *= dj;
             pb.Dv[j] *= dj;
         }
-        for (int r = lane; r < m; r += 64) {
+        for (int r = lane; r < m; r += NTS) {
             const double er = pb.tm[r];
 #pragma unroll
             for (int s = 0; s < KA; ++s) pb.Av[s * m + r] *= pb.wk[pb.Ac[s * m + r]] * er;
@@ -704,7 +798,7 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
         }
         __syncthreads();
         double csum = 0, qn = 0;  // cost scaling: mean column norm of P vs ||q||_inf
-        for (int j = lane; j < n; j += 64) {
+        for (int j = lane; j < n; j += NTS) {
             double cn = 0;
 #pragma unroll
             for (int d = 0; d <= WP; ++d) {
@@ -714,12 +808,12 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
             csum += cn;
             qn = fmax(qn, fabs(pb.q[j]));
         }
-        csum = wave_sum(csum) / n;
-        qn = lim_scaling(wave_max(qn));
+        csum = blk_sum<NWV>(csum, red_) / n;
+        qn = lim_scaling(blk_max<NWV>(qn, red_));
         double ct = csum > qn ? csum : qn;
         ct = 1.0 / lim_scaling(ct);
         __syncthreads();
-        for (int j = lane; j < n; j += 64) {
+        for (int j = lane; j < n; j += NTS) {
 #pragma unroll
             for (int d = 0; d <= WP; ++d) pb.Lb[j * LS + d] *= ct;
             pb.q[j] *= ct;
@@ -728,23 +822,23 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
         __syncthreads();
     }
     const double cinv = 1.0 / cscale;
-    for (int j = lane; j < n; j += 64) {  // park the scaled P band in HBM; the band storage becomes the factor
+    for (int j = lane; j < n; j += NTS) {  // park the scaled P band in HBM; the band storage becomes the factor
 #pragma unroll
         for (int d = 0; d <= WP; ++d) pb.Pb[(size_t)d * n + j] = pb.Lb[j * LS + d];
     }
-    for (int r = lane; r < m; r += 64) {
+    for (int r = lane; r < m; r += NTS) {
         const double e = pb.Ev[r];
         const double lo = pb.l[r] * e, hi = pb.u[r] * e;
         pb.l[r] = lo; pb.u[r] = hi;
         pb.cls[r] = (uint8_t)((lo < -kInfThresh && hi > kInfThresh) ? 2u : ((hi - lo < kRhoTol) ? 1u : 0u));  // set_rho_vec
     }
-    for (int i = lane; i < np; i += 64) pb.wk[i] = 0;
+    for (int i = lane; i < np; i += NTS) pb.wk[i] = 0;
     __threadfence_block();
     __syncthreads();
 
     PO_TICK(0);
     double rho = fmin(fmax(a.rho0, kRhoMin), kRhoMax);
-    factorise<KIND>(pb, rho, a.sigma, lane);
+    factorise<KIND, NWV>(pb, rho, a.sigma, lane, lane);
     PO_TICK(1);
 
     // ---- ADMM (OSQP osqp_solve, cold start) ----
@@ -757,7 +851,7 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
         const bool can_adapt = a.adapt_every > 0 && (iter % a.adapt_every == 0);
         const bool last = iter == a.max_iter;
         const bool term = can_check || last;
-        for (int j = lane; j < n; j += 64) {  // rhs = sigma x - q + A' rho (2 z - v)
+        for (int j = lane; j < n; j += NTS) {  // rhs = sigma x - q + A' rho (2 z - v)
             double acc = sigma * pb.x[j] - pb.q[j];
             const int cnt = pb.Tc[j];
             for (int t = 0; t < cnt; ++t) {
@@ -766,23 +860,21 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
                 const double z = first ? 0.0 : clipd(vv, pb.l[r], pb.u[r]);
                 acc += pb.Av[s * m + r] * (rho_row(pb, r, rho) * (2.0 * z - vv));
             }
-            pb.wk[j] = acc;
+            if (pb.cch) pb.wkp[pb.pidx(j)] = acc;
+            else pb.wk[j] = acc;
         }
         __syncthreads();
         PO_TICK(2);
         // wide bands (TENSION, W = 9): one pending row per lane, one FMA per lane and column (35 instead of 40 ms per 4096 QPs); narrow bands (W = 3, 4): the
         // single-lane window is as fast or faster (measured: TENSION2 14.6 vs 17.2 ms) — the column-to-column latency, not the FMA count, bounds both
-        if constexpr (ST<KIND>::W >= 8) band_solve_lanes<KIND>(pb, lane);
+        if constexpr (ST<KIND>::W >= 8) { if (lane < 64) band_solve_lanes<KIND>(pb, lane); }
         else {
-            // narrow bands (W = 3, 4): the substitution partitioned over the lanes (chunks of c rows, c a multiple of W, every row's read-ahead inside the
-            // zero padding); QPs too small to give every chunk W rows keep the single-lane window
-            const int c = ((n + 63) / 64 + ST<KIND>::W - 1) / ST<KIND>::W * ST<KIND>::W;
-            if (!a.seq_band && c * ((n + c - 1) / c) <= np) band_solve_scan<KIND>(pb, lane, c);
+            if (cscan) { if (NWV == 1 || lane < 64) band_solve_scan<KIND, NWV>(pb, lane, cscan); }
             else if (lane == 0) band_solve<KIND>(pb);
         }
         __syncthreads();
         PO_TICK(3);
-        for (int r = lane; r < m; r += 64) {  // ztilde = A xtilde ; v += alpha (ztilde - z)
+        for (int r = lane; r < m; r += NTS) {  // ztilde = A xtilde ; v += alpha (ztilde - z)
             double zt = 0;
 #pragma unroll
             for (int s = 0; s < KA; ++s) zt += pb.Av[s * m + r] * pb.wk[pb.Ac[s * m + r]];
@@ -793,7 +885,7 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
             if (term) pb.tm[r] = rho_row(pb, r, rho) * ((vn - clipd(vn, pb.l[r], pb.u[r])) - (vv - z));  // delta y of this iteration
         }
         __syncthreads();
-        for (int j = lane; j < n; j += 64) {
+        for (int j = lane; j < n; j += NTS) {
             const double xo = pb.x[j];
             const double xn = xo + alpha * (pb.wk[j] - xo);
             pb.x[j] = xn;
@@ -805,7 +897,7 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
 
         // ---- update_info: residuals, unscaled (termination) and scaled (rho estimate) ----
         double pr = 0, nz = 0, nAx = 0, prs = 0, nzs = 0, nAxs = 0;
-        for (int r = lane; r < m; r += 64) {
+        for (int r = lane; r < m; r += NTS) {
             double ax = 0;
 #pragma unroll
             for (int s = 0; s < KA; ++s) ax += pb.Av[s * m + r] * pb.x[pb.Ac[s * m + r]];
@@ -815,7 +907,7 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
             pr = fmax(pr, ei * fabs(ax - z)); nz = fmax(nz, ei * fabs(z)); nAx = fmax(nAx, ei * fabs(ax));
         }
         double du = 0, nq = 0, nAty = 0, nPx = 0, dus = 0, nqs = 0, nAtys = 0, nPxs = 0;
-        for (int j = lane; j < n; j += 64) {
+        for (int j = lane; j < n; j += NTS) {
             double px = 0;
 #pragma unroll
             for (int d = 0; d <= WP; ++d) {
@@ -834,9 +926,9 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
             dus = fmax(dus, fabs(dres)); nqs = fmax(nqs, fabs(qq)); nAtys = fmax(nAtys, fabs(aty)); nPxs = fmax(nPxs, fabs(px));
             du = fmax(du, di * fabs(dres)); nq = fmax(nq, di * fabs(qq)); nAty = fmax(nAty, di * fabs(aty)); nPx = fmax(nPx, di * fabs(px));
         }
-        pr = wave_max(pr); nz = wave_max(nz); nAx = wave_max(nAx); prs = wave_max(prs); nzs = wave_max(nzs); nAxs = wave_max(nAxs);
-        du = wave_max(du); nq = wave_max(nq); nAty = wave_max(nAty); nPx = wave_max(nPx);
-        dus = wave_max(dus); nqs = wave_max(nqs); nAtys = wave_max(nAtys); nPxs = wave_max(nPxs);
+        pr = blk_max<NWV>(pr, red_); nz = blk_max<NWV>(nz, red_); nAx = blk_max<NWV>(nAx, red_); prs = blk_max<NWV>(prs, red_); nzs = blk_max<NWV>(nzs, red_); nAxs = blk_max<NWV>(nAxs, red_);
+        du = blk_max<NWV>(du, red_); nq = blk_max<NWV>(nq, red_); nAty = blk_max<NWV>(nAty, red_); nPx = blk_max<NWV>(nPx, red_);
+        dus = blk_max<NWV>(dus, red_); nqs = blk_max<NWV>(nqs, red_); nAtys = blk_max<NWV>(nAtys, red_); nPxs = blk_max<NWV>(nPxs, red_);
         pri_res = pr;
         dua_res = cinv * du;
         if (term) {
@@ -846,7 +938,7 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
             bool prim_inf = false, dual_inf = false;
             if (!prim_ok) {  // is_primal_infeasible on delta y
                 double ndy = 0, lhs = 0;
-                for (int r = lane; r < m; r += 64) {
+                for (int r = lane; r < m; r += NTS) {
                     double d = pb.tm[r];
                     const bool uinf = pb.u[r] > kInfThresh, linf = pb.l[r] < -kInfThresh;
                     if (uinf) d = linf ? 0.0 : fmin(d, 0.0);
@@ -855,11 +947,11 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
                     ndy = fmax(ndy, pb.Ev[r] * fabs(d));
                     lhs += (uinf ? 0.0 : pb.u[r] * fmax(d, 0.0)) + (linf ? 0.0 : pb.l[r] * fmin(d, 0.0));
                 }
-                ndy = wave_max(ndy); lhs = wave_sum(lhs);
+                ndy = blk_max<NWV>(ndy, red_); lhs = blk_sum<NWV>(lhs, red_);
                 __syncthreads();
                 if (ndy > a.eps_pinf && lhs < -a.eps_pinf * ndy) {
                     double na = 0;
-                    for (int j = lane; j < n; j += 64) {
+                    for (int j = lane; j < n; j += NTS) {
                         double s2 = 0;
                         const int cnt = pb.Tc[j];
                         for (int t = 0; t < cnt; ++t) {
@@ -868,16 +960,16 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
                         }
                         na = fmax(na, fabs(s2) / pb.Dv[j]);
                     }
-                    prim_inf = wave_max(na) < a.eps_pinf * ndy;
+                    prim_inf = blk_max<NWV>(na, red_) < a.eps_pinf * ndy;
                 }
             }
             if (!dual_ok && !prim_inf) {  // is_dual_infeasible on delta x
                 double ndx = 0, qdx = 0;
-                for (int j = lane; j < n; j += 64) { ndx = fmax(ndx, pb.Dv[j] * fabs(pb.wk[j])); qdx += pb.q[j] * pb.wk[j]; }
-                ndx = wave_max(ndx); qdx = wave_sum(qdx);
+                for (int j = lane; j < n; j += NTS) { ndx = fmax(ndx, pb.Dv[j] * fabs(pb.wk[j])); qdx += pb.q[j] * pb.wk[j]; }
+                ndx = blk_max<NWV>(ndx, red_); qdx = blk_sum<NWV>(qdx, red_);
                 if (ndx > a.eps_dinf && qdx < -cscale * a.eps_dinf * ndx) {
                     double npdx = 0;
-                    for (int j = lane; j < n; j += 64) {
+                    for (int j = lane; j < n; j += NTS) {
                         double px = 0;
 #pragma unroll
                         for (int d = 0; d <= WP; ++d) {
@@ -886,16 +978,16 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
                         }
                         npdx = fmax(npdx, fabs(px) / pb.Dv[j]);
                     }
-                    if (wave_max(npdx) < cscale * a.eps_dinf * ndx) {
+                    if (blk_max<NWV>(npdx, red_) < cscale * a.eps_dinf * ndx) {
                         double viol = 0;
-                        for (int r = lane; r < m; r += 64) {
+                        for (int r = lane; r < m; r += NTS) {
                             double adx = 0;
 #pragma unroll
                             for (int s = 0; s < KA; ++s) adx += pb.Av[s * m + r] * pb.wk[pb.Ac[s * m + r]];
                             adx /= pb.Ev[r];
                             if ((pb.u[r] < kInfThresh && adx > a.eps_dinf * ndx) || (pb.l[r] > -kInfThresh && adx < -a.eps_dinf * ndx)) viol = 1.0;
                         }
-                        dual_inf = wave_max(viol) == 0.0;
+                        dual_inf = blk_max<NWV>(viol, red_) == 0.0;
                     }
                 }
             }
@@ -911,14 +1003,14 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
             rho_new = fmin(fmax(rho_new, kRhoMin), kRhoMax);
             if (rho_new > rho * a.adapt_tol || rho_new < rho / a.adapt_tol) {
                 const double ratio = rho / rho_new;
-                for (int r = lane; r < m; r += 64) {  // keep z and y: v = z + y / rho_new
+                for (int r = lane; r < m; r += NTS) {  // keep z and y: v = z + y / rho_new
                     if (pb.cls[r] == 2u) continue;
                     const double vv = pb.v[r], z = clipd(vv, pb.l[r], pb.u[r]);
                     pb.v[r] = z + ratio * (vv - z);
                 }
                 rho = rho_new;
                 __syncthreads();
-                factorise<KIND>(pb, rho, sigma, lane);
+                factorise<KIND, NWV>(pb, rho, sigma, lane, lane);
                 ++n_refactor;
             }
             PO_TICK(1);
@@ -932,7 +1024,7 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
 
     // ---- unscale, objective, outputs ----
     double obj = 0;
-    for (int j = lane; j < n; j += 64) {
+    for (int j = lane; j < n; j += NTS) {
         double px = 0;
 #pragma unroll
         for (int d = 0; d <= WP; ++d) {
@@ -941,17 +1033,17 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
         }
         obj += (0.5 * px + pb.q[j]) * pb.x[j];
     }
-    obj = wave_sum(obj) * cinv;
-    for (int j = lane; j < n; j += 64) pb.wk[j] = pb.x[j] * pb.Dv[j];
+    obj = blk_sum<NWV>(obj, red_) * cinv;
+    for (int j = lane; j < n; j += NTS) pb.wk[j] = pb.x[j] * pb.Dv[j];
     __syncthreads();
     if (a.raw) {
         double *rw = a.raw + (size_t)b * a.raw_stride;
-        for (int j = lane; j < a.raw_stride; j += 64) rw[j] = 0;
+        for (int j = lane; j < a.raw_stride; j += NTS) rw[j] = 0;
         __syncthreads();
-        for (int j = lane; j < n; j += 64) rw[ref_var<KIND>(j, P)] = pb.wk[j];
+        for (int j = lane; j < n; j += NTS) rw[ref_var<KIND>(j, P)] = pb.wk[j];
     }
     constexpr int NVV = KIND == PO_SMOOTH_TENSION2 ? 4 : 3;
-    for (int i = lane; i < a.P; i += 64) {
+    for (int i = lane; i < a.P; i += NTS) {
         a.out_x[o + i] = i < P ? pb.wk[NVV * i] : 0.0;
         if (a.out_y) a.out_y[o + i] = (KIND != PO_SMOOTH_POST && i < P) ? pb.wk[NVV * i + 1] : 0.0;
         if (KIND == PO_SMOOTH_POST && a.out_s) a.out_s[o + i] = 0.0;
@@ -976,11 +1068,32 @@ template <int KIND> __global__ __launch_bounds__(64) void smooth_kernel(DevSmoot
     }
 }
 
-template <int KIND> static hipError_t launch_kind(const DevSmooth &a, hipStream_t st, size_t lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&smooth_kernel<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+template <int KIND, int NWV, int WPE> static hipError_t launch_kind_w(const DevSmooth &a, hipStream_t st, size_t lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&smooth_kernel<KIND, NWV, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(smooth_kernel<KIND>, dim3(a.B), dim3(64), lds, st, a);
+    hipLaunchKernelGGL((smooth_kernel<KIND, NWV, WPE>), dim3(a.B), dim3(64 * NWV), lds, st, a);
     return hipGetLastError();
+}
+template <int KIND> static hipError_t launch_kind(const DevSmooth &a, hipStream_t st, size_t lds) {
+    if constexpr (ST<KIND>::W <= 4) {
+        constexpr int kCUs = 256, kLdsPerCU = 160 * 1024;
+        const int by_lds = (int)(kLdsPerCU / (lds ? lds : 1));  // QPs a CU holds
+        // measured (tools/smooth_small.py, ms per batch, one wave -> four waves): 4096 QPs of P = 100 (three per CU) 6.6 -> 4.9, of P = 250 (one per CU)
+        // 34 -> 20; a single QP 1.09 -> 0.74 (P = 100), 2.14 -> 1.25 (P = 250; eight waves: 1.17).  Seven small QPs per CU (post QP, P = 60): 5.6 -> 8.2,
+        // one wave per QP stays.
+        int waves = a.waves;
+        if (waves <= 0) {
+            const bool alone = by_lds == 1 || a.B <= kCUs;
+            waves = (alone && ST<KIND>::n(a.P) >= 768) ? 8 : ((by_lds <= 3 || a.B <= 3 * kCUs) ? 4 : 1);
+        }
+        if (waves == 8) return launch_kind_w<KIND, 8, 2>(a, st, lds);
+        if (waves == 4) {
+            // three QPs per CU need the 168-register allocation (a handful of spilled values); up to two per CU keep the full one
+            if (by_lds >= 3 && a.B > 2 * kCUs) return launch_kind_w<KIND, 4, 3>(a, st, lds);
+            return launch_kind_w<KIND, 4, 2>(a, st, lds);
+        }
+    }
+    return launch_kind_w<KIND, 1, 1>(a, st, lds);
 }
 
 }  // namespace po
