@@ -422,22 +422,37 @@ template <int KIND> __device__ __forceinline__ void band_solve_lanes(Prob<KIND> 
 // The factor is SPD-banded (P + sigma I + A' rho A): its homogeneous solutions decay, the products of the Phi_t stay bounded.
 template <int W> struct AffW { double M[W][W], p[W]; };
 template <int W> __device__ __forceinline__ AffW<W> aff_compose(const AffW<W> &first, const AffW<W> &second) {  // second o first
+    // k outermost: W (W + 1) independent accumulators take one term each per round.  A wave alone on its SIMD has only its own instruction stream to cover the
+    // latency of a dependent fp64 FMA (about four issue slots); summing each output's W terms back to back ran at a quarter of the issue rate.
     AffW<W> o;
 #pragma unroll
     for (int i = 0; i < W; ++i) {
-        double acc = second.p[i];
+        o.p[i] = second.p[i];
 #pragma unroll
-        for (int k = 0; k < W; ++k) acc += second.M[i][k] * first.p[k];
-        o.p[i] = acc;
+        for (int j = 0; j < W; ++j) o.M[i][j] = 0;
+    }
 #pragma unroll
-        for (int j = 0; j < W; ++j) {
-            double a2 = 0;
+    for (int k = 0; k < W; ++k) {
 #pragma unroll
-            for (int k = 0; k < W; ++k) a2 += second.M[i][k] * first.M[k][j];
-            o.M[i][j] = a2;
+        for (int i = 0; i < W; ++i) {
+            o.p[i] += second.M[i][k] * first.p[k];
+#pragma unroll
+            for (int j = 0; j < W; ++j) o.M[i][j] += second.M[i][k] * first.M[k][j];
         }
     }
     return o;
+}
+template <int W> __device__ __forceinline__ void aff_apply(AffW<W> &e, const double (&pin)[W]) {  // e.p <- e.p + e.M pin (the map applied to a state)
+    double acc[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) acc[i] = e.p[i];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+#pragma unroll
+        for (int i = 0; i < W; ++i) acc[i] += e.M[i][k] * pin[k];
+    }
+#pragma unroll
+    for (int i = 0; i < W; ++i) e.p[i] = acc[i];
 }
 template <int W, bool UP> __device__ __forceinline__ AffW<W> aff_shift(const AffW<W> &e, int d) {
     AffW<W> o;
@@ -453,161 +468,195 @@ template <int KIND, int NWV = 1> __device__ __forceinline__ void band_solve_scan
     using T = ST<KIND>;
     constexpr int W = T::W, LS = Prob<KIND>::LS;
     static_assert(W <= 4, "wide bands keep band_solve_lanes");
-    const double *__restrict__ Lb = pb.Lb;
     const bool pad = pb.cch != 0;
-    double *wk = pad ? pb.wkp : pb.wk;  // chunk-padded copy: the caller's right-hand side is there; rows j0 .. j0 + c - 1 at wk + wb
-    double *wout = pb.wk;               // the solution goes to the natural layout (stores: off the latency path, their bank conflicts cost nothing)
     const int nl = (pb.n + c - 1) / c;  // lanes that own rows (the last one may own padding rows: zero factor columns, zero right-hand side)
     const int j0 = lane * c;
     const bool own = lane < nl;
-    const int lb = pad ? lane : 0, lbp = pad ? lane - 1 : 0, wb = pad ? lane * pb.wpad : 0;  // this lane's dead doubles before its chunk: factor column j at Lb[j LS + lb], row j at wk[j + wb]
-    // ================= forward: L y = b, stored as z = D^-1 y =================
-    // row form: y_j = b_j - sum_{d = 1..W} L[j][j - d] y_{j - d},  L[j][j - d] = Lb[(j - d) LS + d]
-    auto lrow = [&](int j, int d) -> double {  // (the first W rows of a chunk reach into the previous lane's columns)
-        const int cidx = j - d;
-        return cidx >= 0 ? Lb[cidx * LS + d + (cidx >= j0 ? lb : lbp)] : 0.0;
-    };
+    // Both sweeps read the lane's OWN factor columns only (column j: 1/d_j, then L[j+1][j] .. L[j+W][j]): the forward sweep in column form (a column's value
+    // is final when the W pending sums ahead of it have taken the columns before), the backward sweep in row form on L'.  A block of W columns is loaded
+    // in one go, then its W steps run from registers: one LDS round trip per block, not per row (a wave alone on its SIMD has nothing else to hide it).
+    const double *__restrict__ Lc = pb.Lb + (size_t)j0 * LS + (pad ? lane : 0);                 // own columns (chunk-padded layout: see Prob::cch)
+    double *wc = (pad ? pb.wkp + lane * pb.wpad : pb.wk) + j0;                                 // own rows: right-hand side in, z = D^-1 y in between
+    double *wout = pb.wk + j0;                                                                 // the solution goes to the natural layout
     AffW<W> el;
+    auto identity = [&]() {
 #pragma unroll
-    for (int i = 0; i < W; ++i) {
-        el.p[i] = 0;
+        for (int i = 0; i < W; ++i) {
+            el.p[i] = 0;
 #pragma unroll
-        for (int k = 0; k < W; ++k) el.M[i][k] = i == k ? 1.0 : 0.0;
-    }
+            for (int k = 0; k < W; ++k) el.M[i][k] = i == k ? 1.0 : 0.0;
+        }
+    };
+    // ================= forward: L y = b, stored as z = D^-1 y =================
+    // State of a chunk: the W pending sums u_k = - sum over the columns before the chunk of L[j0 + k][.] y[.], k = 0 .. W - 1.  The window up[k] holds
+    // b + (pending sum) of row (current + k): row r's value is up[0] when its turn comes, and it waits for ONE FMA of row r - 1.
+    identity();
     if (own) {
-        // windows: slot (j mod W) holds the value of row j once it is produced; before that, of row j - W.  Incoming state k = row j0 - W + k.
-        double wp[W], wh[W][W];
+        double up[W], uh[W][W];
 #pragma unroll
         for (int k = 0; k < W; ++k) {
-            wp[k] = 0;
+            up[k] = wc[k];
 #pragma unroll
-            for (int i = 0; i < W; ++i) wh[i][k] = i == k ? 1.0 : 0.0;  // wh[slot][k]: homogeneous solution k
+            for (int i = 0; i < W; ++i) uh[k][i] = i == k ? 1.0 : 0.0;  // uh[k][i]: homogeneous solution for the unit incoming sum i
         }
         for (int jb = 0; jb < c; jb += W) {
+            double L[W][W], bn[W];
+            const bool more = jb + W < c;  // (the sums handed to the next chunk do not hold its right-hand side)
 #pragma unroll
-            for (int uu = 0; uu < W; ++uu) {  // j0 is a multiple of W: row j0 + jb + uu lives in slot uu
-                const int j = j0 + jb + uu;
-                double lr[W];
+            for (int uu = 0; uu < W; ++uu) {
 #pragma unroll
-                for (int d = 1; d <= W; ++d) lr[d - 1] = lrow(j, d);
-                double accp = wk[j + wb];
+                for (int d = 1; d <= W; ++d) L[uu][d - 1] = Lc[(jb + uu) * LS + d];
+                bn[uu] = more ? wc[jb + W + uu] : 0.0;
+            }
 #pragma unroll
-                for (int d = 1; d <= W; ++d) accp -= lr[d - 1] * wp[(uu - d + 4 * W) % W];
-                double acch[W];
+            for (int uu = 0; uu < W; ++uu) {
+                const double y = up[0];
+                double yh[W];
+#pragma unroll
+                for (int i = 0; i < W; ++i) yh[i] = uh[0][i];
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
-                    double a2 = 0;
+                    up[k] = (k + 1 < W ? up[k + 1 < W ? k + 1 : k] : bn[uu]) - L[uu][k] * y;
 #pragma unroll
-                    for (int d = 1; d <= W; ++d) a2 -= lr[d - 1] * wh[(uu - d + 4 * W) % W][k];
-                    acch[k] = a2;
+                    for (int i = 0; i < W; ++i) uh[k][i] = (k + 1 < W ? uh[k + 1 < W ? k + 1 : k][i] : 0.0) - L[uu][k] * yh[i];
                 }
-                wp[uu] = accp;
-#pragma unroll
-                for (int k = 0; k < W; ++k) wh[uu][k] = acch[k];
             }
         }
 #pragma unroll
-        for (int i = 0; i < W; ++i) {
-            el.p[i] = wp[i];
+        for (int k = 0; k < W; ++k) {
+            el.p[k] = up[k];
 #pragma unroll
-            for (int k = 0; k < W; ++k) el.M[i][k] = wh[i][k];
+            for (int i = 0; i < W; ++i) el.M[k][i] = uh[k][i];
         }
     }
     // inclusive scan over the lanes: el_t <- el_t o el_{t-1} o ... o el_0
     for (int d = 1; d < nl; d <<= 1) {
-        const AffW<W> prev = aff_shift<W, true>(el, d);
-        if (lane >= d) el = aff_compose<W>(prev, el);
+        if (2 * d < nl) {
+            const AffW<W> prev = aff_shift<W, true>(el, d);
+            if (lane >= d) el = aff_compose<W>(prev, el);
+        } else {  // last level: only the sums are read afterwards
+            double pp[W];
+#pragma unroll
+            for (int k = 0; k < W; ++k) pp[k] = __shfl_up(el.p[k], d);
+            if (lane >= d) aff_apply<W>(el, pp);
+        }
     }
     {
-        // incoming state of lane t = outgoing state of lane t - 1 applied to the zero state = p of the inclusive prefix
+        // incoming sums of lane t = outgoing sums of lane t - 1 from the zero state = p of its inclusive prefix
         double sin_[W];
 #pragma unroll
         for (int i = 0; i < W; ++i) { const double v = __shfl_up(el.p[i], 1); sin_[i] = lane > 0 ? v : 0.0; }
         if (own) {
-            double wp[W];
+            double up[W];
 #pragma unroll
-            for (int i = 0; i < W; ++i) wp[i] = sin_[i];
+            for (int k = 0; k < W; ++k) up[k] = sin_[k] + wc[k];
             for (int jb = 0; jb < c; jb += W) {
+                double L[W][W], dinv[W], bn[W], z[W];
+                const bool more = jb + W < c;
 #pragma unroll
                 for (int uu = 0; uu < W; ++uu) {
-                    const int j = j0 + jb + uu;
-                    double acc = wk[j + wb];
+                    dinv[uu] = Lc[(jb + uu) * LS];
 #pragma unroll
-                    for (int d = 1; d <= W; ++d) acc -= lrow(j, d) * wp[(uu - d + 4 * W) % W];
-                    wp[uu] = acc;
-                    wk[j + wb] = acc * Lb[j * LS + lb];
+                    for (int d = 1; d <= W; ++d) L[uu][d - 1] = Lc[(jb + uu) * LS + d];
+                    bn[uu] = more ? wc[jb + W + uu] : 0.0;
                 }
+#pragma unroll
+                for (int uu = 0; uu < W; ++uu) {
+                    const double y = up[0];
+                    z[uu] = y * dinv[uu];
+#pragma unroll
+                    for (int k = 0; k < W; ++k) up[k] = (k + 1 < W ? up[k + 1 < W ? k + 1 : k] : bn[uu]) - L[uu][k] * y;
+                }
+#pragma unroll
+                for (int uu = 0; uu < W; ++uu) wc[jb + uu] = z[uu];
             }
         }
     }
     band_sync<NWV>();
-    // ================= backward: L' x = z,  x_j = z_j - sum_{d = 1..W} Lb[j LS + d] x_{j + d} =================
-#pragma unroll
-    for (int i = 0; i < W; ++i) {
-        el.p[i] = 0;
-#pragma unroll
-        for (int k = 0; k < W; ++k) el.M[i][k] = i == k ? 1.0 : 0.0;
-    }
+    // ================= backward: L' x = z,  x_j = z_j - sum_{d = 1..W} L[j + d][j] x_{j + d} =================
+    // State of a chunk: the W values after it, x[j0 + c + k].  The window xw[k] holds x of row (current + 1 + k); the newest enters every sum last.
+    identity();
     if (own) {
-        // incoming state k = row j0 + c + k (slot k: rows are taken in descending order, row j lives in slot (j - j0) mod W)
-        double wp[W], wh[W][W];
+        double xw[W], xh[W][W];
 #pragma unroll
         for (int k = 0; k < W; ++k) {
-            wp[k] = 0;
+            xw[k] = 0;
 #pragma unroll
-            for (int i = 0; i < W; ++i) wh[i][k] = i == k ? 1.0 : 0.0;
+            for (int i = 0; i < W; ++i) xh[k][i] = i == k ? 1.0 : 0.0;
         }
         for (int jb = c - W; jb >= 0; jb -= W) {
+            double L[W][W], z[W];
+#pragma unroll
+            for (int uu = 0; uu < W; ++uu) {
+#pragma unroll
+                for (int d = 1; d <= W; ++d) L[uu][d - 1] = Lc[(jb + uu) * LS + d];
+                z[uu] = wc[jb + uu];
+            }
 #pragma unroll
             for (int uu = W - 1; uu >= 0; --uu) {
-                const int j = j0 + jb + uu;
-                double lc[W];
+                double x = z[uu], xn[W];
 #pragma unroll
-                for (int d = 1; d <= W; ++d) lc[d - 1] = Lb[j * LS + lb + d];
-                double accp = wk[j + wb];
+                for (int i = 0; i < W; ++i) xn[i] = 0;
 #pragma unroll
-                for (int d = 1; d <= W; ++d) accp -= lc[d - 1] * wp[(uu + d) % W];
-                double acch[W];
+                for (int d = W; d >= 1; --d) {
+                    x -= L[uu][d - 1] * xw[d - 1];
 #pragma unroll
-                for (int k = 0; k < W; ++k) {
-                    double a2 = 0;
-#pragma unroll
-                    for (int d = 1; d <= W; ++d) a2 -= lc[d - 1] * wh[(uu + d) % W][k];
-                    acch[k] = a2;
+                    for (int i = 0; i < W; ++i) xn[i] -= L[uu][d - 1] * xh[d - 1][i];
                 }
-                wp[uu] = accp;
 #pragma unroll
-                for (int k = 0; k < W; ++k) wh[uu][k] = acch[k];
+                for (int k = W - 1; k >= 1; --k) {
+                    xw[k] = xw[k - 1];
+#pragma unroll
+                    for (int i = 0; i < W; ++i) xh[k][i] = xh[k - 1][i];
+                }
+                xw[0] = x;
+#pragma unroll
+                for (int i = 0; i < W; ++i) xh[0][i] = xn[i];
             }
         }
 #pragma unroll
-        for (int i = 0; i < W; ++i) {
-            el.p[i] = wp[i];
+        for (int k = 0; k < W; ++k) {
+            el.p[k] = xw[k];
 #pragma unroll
-            for (int k = 0; k < W; ++k) el.M[i][k] = wh[i][k];
+            for (int i = 0; i < W; ++i) el.M[k][i] = xh[k][i];
         }
     }
     for (int d = 1; d < nl; d <<= 1) {  // el_t <- el_t o el_{t+1} o ... o el_{nl-1}
-        const AffW<W> nxt = aff_shift<W, false>(el, d);
-        if (lane + d < nl) el = aff_compose<W>(nxt, el);
+        if (2 * d < nl) {
+            const AffW<W> nxt = aff_shift<W, false>(el, d);
+            if (lane + d < nl) el = aff_compose<W>(nxt, el);
+        } else {
+            double pp[W];
+#pragma unroll
+            for (int k = 0; k < W; ++k) pp[k] = __shfl_down(el.p[k], d);
+            if (lane + d < nl) aff_apply<W>(el, pp);
+        }
     }
     {
         double sin_[W];
 #pragma unroll
         for (int i = 0; i < W; ++i) { const double v = __shfl_down(el.p[i], 1); sin_[i] = lane + 1 < nl ? v : 0.0; }
         if (own) {
-            double wp[W];
+            double xw[W];
 #pragma unroll
-            for (int i = 0; i < W; ++i) wp[i] = sin_[i];
+            for (int k = 0; k < W; ++k) xw[k] = sin_[k];
             for (int jb = c - W; jb >= 0; jb -= W) {
+                double L[W][W], z[W];
+#pragma unroll
+                for (int uu = 0; uu < W; ++uu) {
+#pragma unroll
+                    for (int d = 1; d <= W; ++d) L[uu][d - 1] = Lc[(jb + uu) * LS + d];
+                    z[uu] = wc[jb + uu];
+                }
 #pragma unroll
                 for (int uu = W - 1; uu >= 0; --uu) {
-                    const int j = j0 + jb + uu;
-                    double acc = wk[j + wb];
+                    double x = z[uu];
 #pragma unroll
-                    for (int d = 1; d <= W; ++d) acc -= Lb[j * LS + lb + d] * wp[(uu + d) % W];
-                    wp[uu] = acc;
-                    wout[j] = acc;
+                    for (int d = W; d >= 1; --d) x -= L[uu][d - 1] * xw[d - 1];
+#pragma unroll
+                    for (int k = W - 1; k >= 1; --k) xw[k] = xw[k - 1];
+                    xw[0] = x;
+                    wout[jb + uu] = x;
                 }
             }
         }
@@ -1078,13 +1127,13 @@ template <int KIND> static hipError_t launch_kind(const DevSmooth &a, hipStream_
     if constexpr (ST<KIND>::W <= 4) {
         constexpr int kCUs = 256, kLdsPerCU = 160 * 1024;
         const int by_lds = (int)(kLdsPerCU / (lds ? lds : 1));  // QPs a CU holds
-        // measured (tools/smooth_small.py, ms per batch, one wave -> four waves): 4096 QPs of P = 100 (three per CU) 6.6 -> 4.9, of P = 250 (one per CU)
-        // 34 -> 20; a single QP 1.09 -> 0.74 (P = 100), 2.14 -> 1.25 (P = 250; eight waves: 1.17).  Seven small QPs per CU (post QP, P = 60): 5.6 -> 8.2,
-        // one wave per QP stays.
+        // measured (tools/smooth_small.py, ms per batch, one wave -> four waves): 4096 QPs of P = 100 (three per CU) 6.3 -> 4.3, of P = 250 (one per CU)
+        // 32 -> 17 (eight waves: 15); a single QP 1.03 -> 0.65 (P = 100; eight waves 0.60), 2.0 -> 1.09 (P = 250; eight waves 0.94).  Seven small QPs per
+        // CU (post QP, P = 60): 5.5 -> 7.3, one wave per QP stays.
         int waves = a.waves;
         if (waves <= 0) {
             const bool alone = by_lds == 1 || a.B <= kCUs;
-            waves = (alone && ST<KIND>::n(a.P) >= 768) ? 8 : ((by_lds <= 3 || a.B <= 3 * kCUs) ? 4 : 1);
+            waves = (alone && ST<KIND>::n(a.P) >= 256) ? 8 : ((by_lds <= 4 || a.B <= 3 * kCUs) ? 4 : 1);
         }
         if (waves == 8) return launch_kind_w<KIND, 8, 2>(a, st, lds);
         if (waves == 4) {
