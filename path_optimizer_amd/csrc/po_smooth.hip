@@ -1124,7 +1124,7 @@ template <int KIND, int NWV, int WPE> static hipError_t launch_kind_w(const DevS
     return hipGetLastError();
 }
 template <int KIND> static hipError_t launch_kind(const DevSmooth &a, hipStream_t st, size_t lds) {
-    if constexpr (ST<KIND>::W <= 4) {
+    {
         constexpr int kCUs = 256, kLdsPerCU = 160 * 1024;
         const int by_lds = (int)(kLdsPerCU / (lds ? lds : 1));  // QPs a CU holds
         // measured (tools/smooth_small.py, ms per batch, one wave -> four waves): 4096 QPs of P = 100 (three per CU) 6.3 -> 4.3, of P = 250 (one per CU)

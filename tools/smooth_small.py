@@ -9,7 +9,7 @@ from path_optimizer_amd.abi import INFO_DTYPE  # noqa: E402
 p = binding.default_params(); p.eps_abs = p.eps_rel = 1e-3
 eng = binding.Engine(0, p)
 dist, res, px, py, _ = synth.make_distance_map(3); eng.set_map(dist, res, px, py)
-for kind, P in ((0, 100), (0, 150), (0, 250), (2, 60), (2, 100), (2, 250)):
+for kind, P in ((1, 100), (1, 250)) if os.environ.get("KIND1") else ((0, 100), (0, 150), (0, 250), (2, 60), (2, 100), (2, 250)):
     base = synth.make_smooth_inputs(30, 256, P=P, kind=kind)
     for B in (1, 768, 4096):
         rep = {k: (None if v is None else np.concatenate([v] * ((B + 255) // 256))[:B]) for k, v in base.items()}
