@@ -677,17 +677,32 @@ template <int NWV> __device__ __forceinline__ double blk_max(double v, double *r
     }
     return v;
 }
-template <int NWV> __device__ __forceinline__ double blk_sum(double v, double *red) {
-    v = wave_sum(v);
+// sum over j < n of term(j), in an order that does not depend on the number of waves: the terms of class w = (j / 64) mod 8 are added up in ascending j per
+// lane and reduced over the lanes (s_w), then s_0 + s_1 + ... + s_7 left to right.  A block of 1, 4 or 8 waves owns 8, 2 or 1 classes per thread, so a QP's
+// iterates are bit-identical whichever variant the launcher picks for its batch.  term(j) is called exactly once per j, by thread j mod (64 NWV) (side
+// effects — stores to row j, running maxima — are fine).
+template <int NWV, class F> __device__ __forceinline__ double blk_sum_rows(int n, int tid, double *red, F term) {
+    constexpr int NC = 8 / NWV;  // classes per thread
+    static_assert(NWV == 1 || NWV == 2 || NWV == 4 || NWV == 8, "eight classes");
+    const int lane = tid & 63, wv = tid >> 6;
+    double t = 0;
+    if constexpr (NWV > 1) __syncthreads();  // (earlier readers of red)
+#pragma unroll 1
+    for (int q = 0; q < NC; ++q) {  // one class at a time: the terms are inlined once, with one accumulator
+        double acc = 0;
+#pragma unroll 1
+        for (int j = 64 * (wv + NWV * q) + lane; j < n; j += 512) acc += term(j);
+        const double sw = wave_sum(acc);
+        if constexpr (NWV == 1) t = q ? t + sw : sw;
+        else if (lane == 0) red[wv + NWV * q] = sw;
+    }
     if constexpr (NWV > 1) {
         __syncthreads();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-        __syncthreads();
-        v = red[0];
+        t = red[0];
 #pragma unroll
-        for (int k = 1; k < NWV; ++k) v += red[k];
+        for (int w = 1; w < 8; ++w) t += red[w];
     }
-    return v;
+    return t;
 }
 
 #define PO_TICK(slot)                                                   \
@@ -846,18 +861,17 @@ template <int KIND, int NWV, int WPE> __global__ __launch_bounds__(64 * NWV, WPE
             pb.Ev[r] *= er;
         }
         __syncthreads();
-        double csum = 0, qn = 0;  // cost scaling: mean column norm of P vs ||q||_inf
-        for (int j = lane; j < n; j += NTS) {
+        double qn = 0;  // cost scaling: mean column norm of P vs ||q||_inf
+        double csum = blk_sum_rows<NWV>(n, lane, red_, [&](int j) {
             double cn = 0;
 #pragma unroll
             for (int d = 0; d <= WP; ++d) {
                 cn = fmax(cn, fabs(pb.Lb[j * LS + d]));
                 if (d > 0 && j - d >= 0) cn = fmax(cn, fabs(pb.Lb[(j - d) * LS + d]));
             }
-            csum += cn;
             qn = fmax(qn, fabs(pb.q[j]));
-        }
-        csum = blk_sum<NWV>(csum, red_) / n;
+            return cn;
+        }) / n;
         qn = lim_scaling(blk_max<NWV>(qn, red_));
         double ct = csum > qn ? csum : qn;
         ct = 1.0 / lim_scaling(ct);
@@ -986,17 +1000,17 @@ template <int KIND, int NWV, int WPE> __global__ __launch_bounds__(64 * NWV, WPE
             const bool prim_ok = pri_res < eps_prim, dual_ok = dua_res < eps_dual;  // strict, as OSQP
             bool prim_inf = false, dual_inf = false;
             if (!prim_ok) {  // is_primal_infeasible on delta y
-                double ndy = 0, lhs = 0;
-                for (int r = lane; r < m; r += NTS) {
+                double ndy = 0;
+                const double lhs = blk_sum_rows<NWV>(m, lane, red_, [&](int r) {
                     double d = pb.tm[r];
                     const bool uinf = pb.u[r] > kInfThresh, linf = pb.l[r] < -kInfThresh;
                     if (uinf) d = linf ? 0.0 : fmin(d, 0.0);
                     else if (linf) d = fmax(d, 0.0);
                     pb.tm[r] = d;
                     ndy = fmax(ndy, pb.Ev[r] * fabs(d));
-                    lhs += (uinf ? 0.0 : pb.u[r] * fmax(d, 0.0)) + (linf ? 0.0 : pb.l[r] * fmin(d, 0.0));
-                }
-                ndy = blk_max<NWV>(ndy, red_); lhs = blk_sum<NWV>(lhs, red_);
+                    return (uinf ? 0.0 : pb.u[r] * fmax(d, 0.0)) + (linf ? 0.0 : pb.l[r] * fmin(d, 0.0));
+                });
+                ndy = blk_max<NWV>(ndy, red_);
                 __syncthreads();
                 if (ndy > a.eps_pinf && lhs < -a.eps_pinf * ndy) {
                     double na = 0;
@@ -1013,9 +1027,12 @@ template <int KIND, int NWV, int WPE> __global__ __launch_bounds__(64 * NWV, WPE
                 }
             }
             if (!dual_ok && !prim_inf) {  // is_dual_infeasible on delta x
-                double ndx = 0, qdx = 0;
-                for (int j = lane; j < n; j += NTS) { ndx = fmax(ndx, pb.Dv[j] * fabs(pb.wk[j])); qdx += pb.q[j] * pb.wk[j]; }
-                ndx = blk_max<NWV>(ndx, red_); qdx = blk_sum<NWV>(qdx, red_);
+                double ndx = 0;
+                const double qdx = blk_sum_rows<NWV>(n, lane, red_, [&](int j) {
+                    ndx = fmax(ndx, pb.Dv[j] * fabs(pb.wk[j]));
+                    return pb.q[j] * pb.wk[j];
+                });
+                ndx = blk_max<NWV>(ndx, red_);
                 if (ndx > a.eps_dinf && qdx < -cscale * a.eps_dinf * ndx) {
                     double npdx = 0;
                     for (int j = lane; j < n; j += NTS) {
@@ -1072,17 +1089,15 @@ template <int KIND, int NWV, int WPE> __global__ __launch_bounds__(64 * NWV, WPE
     __syncthreads();
 
     // ---- unscale, objective, outputs ----
-    double obj = 0;
-    for (int j = lane; j < n; j += NTS) {
+    const double obj = cinv * blk_sum_rows<NWV>(n, lane, red_, [&](int j) {
         double px = 0;
 #pragma unroll
         for (int d = 0; d <= WP; ++d) {
             if (j + d < n) px += pb.Pb[(size_t)d * n + j] * pb.x[j + d];
             if (d > 0 && j - d >= 0) px += pb.Pb[(size_t)d * n + j - d] * pb.x[j - d];
         }
-        obj += (0.5 * px + pb.q[j]) * pb.x[j];
-    }
-    obj = blk_sum<NWV>(obj, red_) * cinv;
+        return (0.5 * px + pb.q[j]) * pb.x[j];
+    });
     for (int j = lane; j < n; j += NTS) pb.wk[j] = pb.x[j] * pb.Dv[j];
     __syncthreads();
     if (a.raw) {

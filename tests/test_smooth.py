@@ -299,3 +299,33 @@ def test_device_pointer_entry_large_batch_and_determinism(engine):
     host = engine.smooth_batch(kind, inp)
     assert torch.equal(outs[0]["x"], outs[1]["x"]) and torch.equal(outs[0]["s"], outs[1]["s"])
     assert np.array_equal(outs[0]["x"].cpu().numpy()[:64], host[0]) and np.array_equal(outs[0]["x"].cpu().numpy()[64:128], host[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,P", [(0, 100), (0, 250), (1, 100), (2, 60), (2, 100), (2, 250)])
+def test_device_waves_per_qp_agree(engine, oracle, omap, kind, P, monkeypatch):
+    """One, four and eight waves per QP (the launcher picks by LDS footprint and batch size; PO_SMOOTH_WAVES forces one) and both LDS layouts of the
+    partitioned substitution give the same iterates bit for bit; the one-wave result is checked against the oracle."""
+    inp = synth.make_smooth_inputs(31, 12, P=P, kind=kind, ragged=True, jitter_ds=True)
+    inp["n_points"][0] = P
+    res = {}
+    for tag, env in (("1", {"PO_SMOOTH_WAVES": "1"}), ("4", {"PO_SMOOTH_WAVES": "4"}), ("8", {"PO_SMOOTH_WAVES": "8"}), ("auto", {}),
+                     ("natural", {"PO_SMOOTH_WAVES": "1", "PO_SMOOTH_NOPAD": "1"}), ("single-lane", {"PO_SMOOTH_WAVES": "4", "PO_SMOOTH_SEQ": "1"})):
+        for k in ("PO_SMOOTH_WAVES", "PO_SMOOTH_NOPAD", "PO_SMOOTH_SEQ"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        res[tag] = engine.smooth_batch(kind, inp, want_raw=True)
+    for k in ("PO_SMOOTH_WAVES", "PO_SMOOTH_NOPAD", "PO_SMOOTH_SEQ"):
+        monkeypatch.delenv(k, raising=False)
+    ref = res["1"]
+    for tag in ("4", "8", "auto"):
+        assert np.array_equal(res[tag][4], ref[4]), tag
+        assert np.array_equal(res[tag][3]["iters"], ref[3]["iters"]) and np.array_equal(res[tag][3]["status"], ref[3]["status"]), tag
+        assert np.array_equal(res[tag][0], ref[0]) and np.array_equal(res[tag][2], ref[2]), tag
+    for tag in ("natural", "single-lane"):  # same arithmetic per row up to the order of a sum
+        assert np.array_equal(res[tag][3]["status"], ref[3]["status"]), tag
+        same = res[tag][3]["iters"] == ref[3]["iters"]  # (a residual within round-off of eps may flip one termination check)
+        assert same.mean() >= 0.9 and np.abs(res[tag][4][same] - ref[4][same]).max() < 1e-6, tag
+    orc = oracle.smooth_batch(kind, oracle.default_params(), inp, m_map=omap, want_raw=True)
+    _compare(kind, ref, orc, inp)
