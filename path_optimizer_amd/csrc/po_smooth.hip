@@ -242,6 +242,44 @@ template <int KIND, int NWV = 1> __device__ void factorise(Prob<KIND> &pb, doubl
         for (int d = 0; d <= W; ++d) pb.Lb[bj + d] = col[d]; }
     }
     __syncthreads();
+    if constexpr (W <= 4) {
+        // Narrow bands: ONE lane carries the active window (the current column and the W columns it updates) in registers and takes one new column from
+        // LDS per step, requested before the division it hides behind.  The multi-lane loop below pays two LDS round trips and two barriers per column
+        // (440 cycles per column measured); here a column costs the division and one dependent FMA (same expressions, same results).
+        if (lane == 0) {
+            double cur[W + 1], win[W][W + 1];
+#pragma unroll
+            for (int e = 0; e <= W; ++e) cur[e] = pb.Lb[pb.lcol(0) + e];
+#pragma unroll
+            for (int a = 0; a < W; ++a) {
+                const int ba = pb.lcol(1 + a);
+#pragma unroll
+                for (int e = 0; e <= W; ++e) win[a][e] = pb.Lb[ba + e];
+            }
+            for (int j = 0; j < n; ++j) {
+                double nxt[W + 1];
+                const int bn = pb.lcol(j + W + 1), bj = pb.lcol(j);  // (column j + W + 1 < np has not been touched yet: updates reach W columns ahead)
+#pragma unroll
+                for (int e = 0; e <= W; ++e) nxt[e] = pb.Lb[bn + e];
+                const double dinv = 1.0 / cur[0];
+#pragma unroll
+                for (int a = 1; a <= W; ++a) {
+#pragma unroll
+                    for (int b = a; b <= W; ++b) win[a - 1][b - a] -= cur[a] * dinv * cur[b];
+                }
+                pb.Lb[bj] = dinv;
+#pragma unroll
+                for (int e = 1; e <= W; ++e) pb.Lb[bj + e] = cur[e] * dinv;
+#pragma unroll
+                for (int e = 0; e <= W; ++e) {
+                    cur[e] = win[0][e];
+#pragma unroll
+                    for (int a = 0; a + 1 < W; ++a) win[a][e] = win[a + 1][e];
+                    win[W - 1][e] = nxt[e];
+                }
+            }
+        }
+    } else {
     // lane -> (a, b), 1 <= a <= b <= W
     constexpr int NPAIR = W * (W + 1) / 2;
     int pa = 0, pbb = 0;
@@ -268,6 +306,7 @@ template <int KIND, int NWV = 1> __device__ void factorise(Prob<KIND> &pb, doubl
         if (lane == 0) pb.Lb[bj] = dinv;
         else if (lane <= W) pb.Lb[bj + lane] = mine * dinv;
         band_sync<NWV>();
+    }
     }
     if constexpr (NWV > 1) __syncthreads();  // the trailing updates of the last columns land in the padding columns cleared below
     for (int j = n + tid; j < pb.np; j += nts) {  // padding columns: the trailing updates of the last columns spilled into them
