@@ -329,3 +329,19 @@ def test_device_waves_per_qp_agree(engine, oracle, omap, kind, P, monkeypatch):
         assert same.mean() >= 0.9 and np.abs(res[tag][4][same] - ref[4][same]).max() < 1e-6, tag
     orc = oracle.smooth_batch(kind, oracle.default_params(), inp, m_map=omap, want_raw=True)
     _compare(kind, ref, orc, inp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [0, 2])
+def test_device_chunk_layout_transitions(engine, oracle, omap, kind):
+    """Sizes either side of every change in the partitioned substitution: single-lane window (tiny QPs), natural layout (fewer than 6 rows per lane),
+    chunk-padded layout with even and odd chunk lengths (W = 3), and the steps of the rows-per-lane count."""
+    sizes = [3, 4, 5, 16, 17, 33, 64, 65, 97, 128, 129, 161, 192, 193, 225] if kind == 0 else [4, 5, 6, 21, 22, 43, 64, 65, 100, 128, 129, 150, 192, 193, 230]
+    for P in sizes:
+        inp = synth.make_smooth_inputs(40 + P, 3, P=P, kind=kind, jitter_ds=True)
+        dev = engine.smooth_batch(kind, inp, want_raw=True)
+        orc = oracle.smooth_batch(kind, oracle.default_params(), inp, m_map=omap, want_raw=True)
+        try:
+            _compare(kind, dev, orc, inp, frac=0.6)
+        except AssertionError as e:
+            raise AssertionError(f"P = {P}: {e}") from e
