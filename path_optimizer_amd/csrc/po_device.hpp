@@ -289,6 +289,22 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// exponent all ones: Inf or NaN.  An integer test on purpose: the build uses -fno-honor-nans, under which `v != v` folds to false, and the
+// residual norms are fmax-accumulated (fmax drops a NaN operand), so a non-finite iterate would otherwise read as "converged".
+// The high word goes through an empty asm: otherwise the optimiser recognises the mask-and-compare as is.fpclass(v, inf | nan) and, the producing
+// instruction carrying `nnan`, narrows it to an Inf test (measured: NaN iterates came back "solved").
+__device__ __forceinline__ int nonfinite_bits(double v) {
+    int hi = __double2hiint(v);
+    asm volatile("" : "+v"(hi));
+    return (hi & 0x7ff00000) == 0x7ff00000;
+}
+
+__device__ __forceinline__ int nan_bits(double v) {  // NaN only (an infinite clearance is a legitimate "no bound")
+    int hi = __double2hiint(v), lo = __double2loint(v);
+    asm volatile("" : "+v"(hi), "+v"(lo));
+    return (hi & 0x7ff00000) == 0x7ff00000 && ((hi & 0x000fffff) | lo) != 0;
+}
+
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));

@@ -842,17 +842,32 @@ template <int KIND, int NWV, int WPE> __global__ __launch_bounds__(64 * NWV, WPE
 
     // ---- data validation (OSQP validate_data: l <= u, else setup fails and the reference's initSolver() returns false) ----
     {
-        double bad = 0;
-        for (int r = lane; r < m; r += NTS) bad = fmax(bad, pb.l[r] > pb.u[r] ? 1.0 : 0.0);
+        // ... and a NaN anywhere in the assembled data (non-finite inputs): a NaN bound would vanish silently (fmin / fmax drop a NaN operand: the row would
+        // act as unbounded and the QP come back "solved"); flagged PO_STATUS_NON_FINITE, like the path QP does
+        double bad = 0, nonfin = 0;
+        for (int r = lane; r < m; r += NTS) {
+            bad = fmax(bad, pb.l[r] > pb.u[r] ? 1.0 : 0.0);
+            int nf = nan_bits(pb.l[r]) | nan_bits(pb.u[r]);
+#pragma unroll
+            for (int s = 0; s < KA; ++s) nf |= nonfinite_bits(pb.Av[s * m + r]);
+            if (nf) nonfin = 1.0;
+        }
+        for (int j = lane; j < n; j += NTS) {
+            int nf = nonfinite_bits(pb.q[j]);
+#pragma unroll
+            for (int d = 0; d <= WP; ++d) nf |= nonfinite_bits(pb.Lb[j * LS + d]);
+            if (nf) nonfin = 1.0;
+        }
         bad = blk_max<NWV>(bad, red_);
-        if (bad > 0) {
+        nonfin = blk_max<NWV>(nonfin, red_);
+        if (bad > 0 || nonfin > 0) {
             for (int i = lane; i < a.P; i += NTS) {
                 a.out_x[o + i] = 0;
                 if (a.out_y) a.out_y[o + i] = 0;
                 if (a.out_s) a.out_s[o + i] = 0;
             }
             if (a.raw) for (int j = lane; j < a.raw_stride; j += NTS) a.raw[(size_t)b * a.raw_stride + j] = 0;
-            info.status = PO_STATUS_PRIMAL_INFEASIBLE;
+            info.status = nonfin > 0 ? PO_STATUS_NON_FINITE : PO_STATUS_PRIMAL_INFEASIBLE;
             info.rho = a.rho0;
             if (lane == 0) a.info[b] = info;
             return;
@@ -999,11 +1014,13 @@ template <int KIND, int NWV, int WPE> __global__ __launch_bounds__(64 * NWV, WPE
 
         // ---- update_info: residuals, unscaled (termination) and scaled (rho estimate) ----
         double pr = 0, nz = 0, nAx = 0, prs = 0, nzs = 0, nAxs = 0;
+        int bad = 0;  // a non-finite primal or dual residual term: fmax drops a NaN operand, so NaN iterates (non-finite inputs) would otherwise read as converged
         for (int r = lane; r < m; r += NTS) {
             double ax = 0;
 #pragma unroll
             for (int s = 0; s < KA; ++s) ax += pb.Av[s * m + r] * pb.x[pb.Ac[s * m + r]];
             const double z = clipd(pb.v[r], pb.l[r], pb.u[r]);
+            bad |= nonfinite_bits(ax - z);
             const double ei = 1.0 / pb.Ev[r];
             prs = fmax(prs, fabs(ax - z)); nzs = fmax(nzs, fabs(z)); nAxs = fmax(nAxs, fabs(ax));
             pr = fmax(pr, ei * fabs(ax - z)); nz = fmax(nz, ei * fabs(z)); nAx = fmax(nAx, ei * fabs(ax));
@@ -1025,6 +1042,7 @@ template <int KIND, int NWV, int WPE> __global__ __launch_bounds__(64 * NWV, WPE
             }
             const double qq = pb.q[j], di = 1.0 / pb.Dv[j];
             const double dres = px + qq + aty;
+            bad |= nonfinite_bits(dres);
             dus = fmax(dus, fabs(dres)); nqs = fmax(nqs, fabs(qq)); nAtys = fmax(nAtys, fabs(aty)); nPxs = fmax(nPxs, fabs(px));
             du = fmax(du, di * fabs(dres)); nq = fmax(nq, di * fabs(qq)); nAty = fmax(nAty, di * fabs(aty)); nPx = fmax(nPx, di * fabs(px));
         }
@@ -1033,6 +1051,7 @@ template <int KIND, int NWV, int WPE> __global__ __launch_bounds__(64 * NWV, WPE
         dus = blk_max<NWV>(dus, red_); nqs = blk_max<NWV>(nqs, red_); nAtys = blk_max<NWV>(nAtys, red_); nPxs = blk_max<NWV>(nPxs, red_);
         pri_res = pr;
         dua_res = cinv * du;
+        if (blk_max<NWV>(bad ? 1.0 : 0.0, red_) != 0.0) { status = PO_STATUS_NON_FINITE; break; }
         if (term) {
             const double eps_prim = a.eps_abs + a.eps_rel * fmax(nz, nAx);
             const double eps_dual = a.eps_abs + a.eps_rel * cinv * fmax(fmax(nq, nAty), nPx);

@@ -345,3 +345,24 @@ def test_device_chunk_layout_transitions(engine, oracle, omap, kind):
             _compare(kind, dev, orc, inp, frac=0.6)
         except AssertionError as e:
             raise AssertionError(f"P = {P}: {e}") from e
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", KINDS)
+def test_device_non_finite_input_is_never_solved(engine, kind):
+    """A NaN among one instance's inputs: that instance comes back PO_STATUS_NON_FINITE (the residual norms are fmax-accumulated and would drop it), the
+    others are untouched."""
+    from path_optimizer_amd.abi import PO_STATUS_NON_FINITE
+
+    inp = synth.make_smooth_inputs(50, 6, P=40, kind=kind)
+    clean = engine.smooth_batch(kind, inp)
+    bad = {k: (None if v is None else v.copy()) for k, v in inp.items()}
+    if kind == 2:
+        bad["lb"][2, 7] = np.nan
+    else:
+        bad["x"][2, 7] = np.nan
+    dev = engine.smooth_batch(kind, bad)
+    assert dev[3]["status"][2] == PO_STATUS_NON_FINITE, dev[3]["status"]
+    assert not dev[0][2].any()
+    keep = np.arange(6) != 2
+    assert np.array_equal(dev[3]["status"][keep], clean[3]["status"][keep]) and np.array_equal(dev[0][keep], clean[0][keep])
