@@ -245,7 +245,7 @@ template <int KIND, int NWV = 1> __device__ void factorise(Prob<KIND> &pb, doubl
     if constexpr (W <= 4) {
         // Narrow bands: ONE lane carries the active window (the current column and the W columns it updates) in registers and takes one new column from
         // LDS per step, requested before the division it hides behind.  The multi-lane loop below pays two LDS round trips and two barriers per column
-        // (440 cycles per column measured); here a column costs the division and one dependent FMA (same expressions, same results).
+        // (650 cycles per column measured); here a column costs the reciprocal and two dependent operations.
         if (lane == 0) {
             double cur[W + 1], win[W][W + 1];
 #pragma unroll
@@ -256,20 +256,31 @@ template <int KIND, int NWV = 1> __device__ void factorise(Prob<KIND> &pb, doubl
 #pragma unroll
                 for (int e = 0; e <= W; ++e) win[a][e] = pb.Lb[ba + e];
             }
+            double out[W + 1];  // the finished column, stored one step later: behind the next step's loads, so that the wait for those does not include it
+            int bo = pb.lcol(0);
+#pragma unroll
+            for (int e = 0; e <= W; ++e) out[e] = cur[e];  // (step 0 stores the column as it is; it is overwritten at step 1)
             for (int j = 0; j < n; ++j) {
                 double nxt[W + 1];
                 const int bn = pb.lcol(j + W + 1), bj = pb.lcol(j);  // (column j + W + 1 < np has not been touched yet: updates reach W columns ahead)
 #pragma unroll
+                for (int e = 0; e <= W; ++e) pb.Lb[bo + e] = out[e];
+#pragma unroll
                 for (int e = 0; e <= W; ++e) nxt[e] = pb.Lb[bn + e];
-                const double dinv = 1.0 / cur[0];
+                // 1 / d by v_rcp_f64 and two Newton steps (within an ulp of the quotient): the IEEE division's scale / fix-up sequence is twice as long, and
+                // this chain is what a column waits for
+                double dinv = __builtin_amdgcn_rcp(cur[0]);
+                dinv = fma(fma(-cur[0], dinv, 1.0), dinv, dinv);
+                dinv = fma(fma(-cur[0], dinv, 1.0), dinv, dinv);
 #pragma unroll
                 for (int a = 1; a <= W; ++a) {
 #pragma unroll
                     for (int b = a; b <= W; ++b) win[a - 1][b - a] -= cur[a] * dinv * cur[b];
                 }
-                pb.Lb[bj] = dinv;
+                out[0] = dinv;
 #pragma unroll
-                for (int e = 1; e <= W; ++e) pb.Lb[bj + e] = cur[e] * dinv;
+                for (int e = 1; e <= W; ++e) out[e] = cur[e] * dinv;
+                bo = bj;
 #pragma unroll
                 for (int e = 0; e <= W; ++e) {
                     cur[e] = win[0][e];
@@ -278,6 +289,8 @@ template <int KIND, int NWV = 1> __device__ void factorise(Prob<KIND> &pb, doubl
                     win[W - 1][e] = nxt[e];
                 }
             }
+#pragma unroll
+            for (int e = 0; e <= W; ++e) pb.Lb[bo + e] = out[e];
         }
     } else {
     // lane -> (a, b), 1 <= a <= b <= W
