@@ -317,6 +317,22 @@ def stage_legs_gpu(torch, binding, synth, eng, stream, dbatch, B):
     st["full_pipeline"]["at_osqp_default_eps_1e-3"] = {"ms": ms_p4, "instances_per_s": B / (ms_p4 * 1e-3), "ok_frac": float(po_["ok"].double().mean().item()),
                                                        "qp_iters_mean": float(pinf4["iters"].mean())}
     e4.close()
+    # the same 4096 instances with the path QP's refinement phase (po_params.refine, include/po_hip.h): every path ends at residuals of 1e-6 or keeps its plain point
+    for tag, kw in (("eps_1e-4_refine_rounds3", dict(refine=1, refine_rounds=3)), ("eps_3e-4_refine", dict(refine=1, eps_abs=3e-4, eps_rel=3e-4))):
+        p5 = binding.default_params()
+        for k_, v_ in kw.items():
+            setattr(p5, k_, v_)
+        e5 = binding.Engine(torch.cuda.current_device(), p5); e5.set_map(*scn["map"])
+        e5.plan_batch_device(tp, po_, Np, way_len); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            e5.plan_batch_device(tp, po_, Np, way_len)
+        torch.cuda.synchronize()
+        ms_p5 = (time.perf_counter() - t0) / 3 * 1e3
+        pinf5 = po_["info"].cpu().numpy().view(INFO_DTYPE).reshape(-1)
+        st["full_pipeline"][tag] = {"ms": ms_p5, "instances_per_s": B / (ms_p5 * 1e-3), "ok_frac": float(po_["ok"].double().mean().item()),
+                                    "qp_iters_mean": float(pinf5["iters"].mean()), "qp_iters_max": int(pinf5["iters"].max())}
+        e5.close()
     eng.set_map(d, res, px, py)
     ctx = dict(map=(d, res, px, py), scn=scn, P=P, keys=keys, sm_inputs=sm_inputs, spn=spn, length=length, start=start, Lc=Lc,
                states64=dbatch.out_states[:64].cpu().numpy(), info64=dbatch.info_numpy()[:64])
