@@ -125,21 +125,16 @@ PO_PM_FN double po_patan(double x) {
                  T4 = 9.09088713343650656196e-02, T5 = -7.69187620504482999495e-02, T6 = 6.66107313738753120669e-02, T7 = -5.83357013379057348645e-02,
                  T8 = 4.97687799461593236017e-02, T9 = -3.65315727442169155270e-02, T10 = 1.62858201153657823623e-02;
     const int hx = po_pm_hi(x), ix = hx & 0x7fffffff;
-    int id;
     if (ix >= 0x44100000) return hx > 0 ? hi3 + lo3 : -hi3 - lo3;  /* |x| >= 2^66 */
-    if (ix < 0x3fdc0000) {  /* |x| < 0.4375 */
-        if (ix < 0x3e200000) return x;
-        id = -1;
-    } else {
-        x = po_pm_fabs(x);
-        if (ix < 0x3ff30000) {  /* |x| < 1.1875 */
-            if (ix < 0x3fe60000) { id = 0; x = (2.0 * x - 1.0) / (2.0 + x); }
-            else { id = 1; x = (x - 1.0) / (x + 1.0); }
-        } else {
-            if (ix < 0x40038000) { id = 2; x = (x - 1.5) / (1.0 + 1.5 * x); }
-            else { id = 3; x = -1.0 / x; }
-        }
-    }
+    if (ix < 0x3e200000) return x;
+    /* argument reduction: the interval picks numerator and denominator, ONE division follows (below 0.4375 it is x / 1, exact).  Same operations per
+       interval as the textbook's branch-per-interval form; on a GPU the lanes of a wave fall into different intervals, and four branches with a
+       division each ran one after the other. */
+    const double ax = po_pm_fabs(x);
+    const int id = ix < 0x3fdc0000 ? -1 : (ix < 0x3fe60000 ? 0 : (ix < 0x3ff30000 ? 1 : (ix < 0x40038000 ? 2 : 3)));
+    const double num = id < 0 ? x : (id == 0 ? 2.0 * ax - 1.0 : (id == 1 ? ax - 1.0 : (id == 2 ? ax - 1.5 : -1.0)));
+    const double den = id < 0 ? 1.0 : (id == 0 ? 2.0 + ax : (id == 1 ? ax + 1.0 : (id == 2 ? 1.0 + 1.5 * ax : ax)));
+    x = num / den;
     const double z = x * x, w = z * z;
     const double s1 = z * (T0 + w * (T2 + w * (T4 + w * (T6 + w * (T8 + w * T10)))));
     const double s2 = w * (T1 + w * (T3 + w * (T5 + w * (T7 + w * T9))));

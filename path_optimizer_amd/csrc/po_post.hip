@@ -438,7 +438,12 @@ template <int NW> __global__ __launch_bounds__(64 * NW) void dp_search_kernel(De
             const unsigned long long pm = fmask[i - 1];
             const double ps = ls[i - 1];
             double min_cost = 1.7976931348623157e308;
-            for (int k = wv; k < nlat; k += NW) {
+            // only previous nodes within reach can pass the test below: scan this lane's window of them, in ascending order like the reference's loop
+            // over all of them (ties keep the first index).  The window is a superset by two samples either side; the exact test still decides.
+            int wr = (int)((cur_s - ps) / q.lat_spacing) + 2;
+            wr = wr < nlat ? wr : nlat;
+            const int k0 = lane - wr > 0 ? lane - wr : 0, k1 = lane + wr < nlat - 1 ? lane + wr : nlat - 1;
+            for (int k = k0 + wv; k <= k1; k += NW) {
                 if (!((pm >> k) & 1ull)) continue;
                 if (fabs(lat[k] - my_l) > (cur_s - ps)) continue;
                 const double direction = po_patan2(y - prv[kDpMaxLat + k], x - prv[k]);
