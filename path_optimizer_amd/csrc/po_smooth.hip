@@ -465,17 +465,17 @@ template <int KIND> __device__ __forceinline__ void band_solve_lanes(Prob<KIND> 
 
 
 // L D L' x = wk, in place, PARTITIONED over the lanes of the wave (narrow bands, W <= 4): lane t owns the c consecutive rows [t c, (t + 1) c), c a multiple of W.
-// A banded substitution is a linear recurrence of order W: with the W values before the chunk as incoming state s_in, the chunk's last W values are
-// s_out = p + Phi s_in, where p comes from the chunk's own right-hand side with s_in = 0 and column k of Phi from a unit incoming state and a zero
-// right-hand side.  So: (1) every lane runs the 1 + W recurrences over its own rows with rolling windows (no per-row storage), (2) the affine maps
+// A banded substitution is a linear recurrence of order W: with W values as the state entering a chunk (forward sweep, column form: the W pending sums
+// from the columns before it; backward sweep: the W solution values after it), the state leaving it is s_out = p + Phi s_in, where p comes from the chunk's
+// own right-hand side with s_in = 0 and column k of Phi from a unit incoming state and a zero right-hand side.  So: (1) every lane runs the 1 + W recurrences over its own rows with rolling windows (no per-row storage), (2) the affine maps
 // (Phi_t, p_t) are composed by a Kogge-Stone scan over the lanes, which hands every lane its true incoming state, (3) every lane runs the recurrence once
 // more from that state and stores its rows.  The backward sweep (L' x = z) is the same recurrence from the far end (incoming state from the next
 // lane).  2 x (W + 2) passes over c rows per lane instead of 2 x n dependent columns on one lane: the substitution was 2/3 of a TENSION2 solve.
 // The factor is SPD-banded (P + sigma I + A' rho A): its homogeneous solutions decay, the products of the Phi_t stay bounded.
 template <int W> struct AffW { double M[W][W], p[W]; };
 template <int W> __device__ __forceinline__ AffW<W> aff_compose(const AffW<W> &first, const AffW<W> &second) {  // second o first
-    // k outermost: W (W + 1) independent accumulators take one term each per round.  A wave alone on its SIMD has only its own instruction stream to cover the
-    // latency of a dependent fp64 FMA (about four issue slots); summing each output's W terms back to back ran at a quarter of the issue rate.
+    // k outermost: W (W + 1) independent accumulators take one term each per round (measured: no faster than summing each output's W terms back to back —
+    // the scan is bound by the ds_bpermute traffic and the loads, not by FMA latency — kept for the shorter dependent chains).
     AffW<W> o;
 #pragma unroll
     for (int i = 0; i < W; ++i) {
@@ -716,7 +716,7 @@ template <int KIND, int NWV = 1> __device__ __forceinline__ void band_solve_scan
 }
 
 
-// reductions over the block: NWV waves (the smoothing kernels run one wave per QP in a full batch, four for small batches)
+// reductions over the block: NWV waves per QP (see smooth_kernel)
 template <int NWV> __device__ __forceinline__ double blk_max(double v, double *red) {
     v = wave_max(v);
     if constexpr (NWV > 1) {
