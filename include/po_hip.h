@@ -128,6 +128,13 @@ typedef struct po_params {
                                            refined again, down to eps itself (last round: the full budget).  Every path returned satisfies OSQP's test at eps_abs /
                                            eps_rel or at refine_eps; most never run the slow type-based iteration to the end (BASELINE config 3, R = 3: mean 159
                                            iterations instead of 340, longest path 925 instead of 1 600) */
+    int    probe_iters;                 /* 0 = off.  > 0 (scheduling only, results bit-identical; ignored with refine, two-level shapes only): the solve runs
+                                           in two launch pairs.  The first runs every path for at most this many ADMM iterations; unfinished paths are handed back
+                                           (iterate in the engine's state block).  The host then orders them by the dual residual they had at the hand-back, largest
+                                           first — a fair predictor of the iterations still to go — and the second pair resumes them in that order (a caller-supplied
+                                           po_batch_in.order is used instead when there is one).  For batches whose total work per resident slot exceeds the longest
+                                           path (the planning pipeline's 4096 QPs on 512 slots: iteration counts 125 .. 1 900, half of them above 500): a launch in
+                                           arbitrary order ends with a long tail of half-empty CUs; longest-first packs it.  150 is a good value there. */
 } po_params;
 
 typedef struct po_info {

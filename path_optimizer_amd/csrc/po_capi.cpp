@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -18,6 +19,7 @@
 #include "po_smooth.hpp"
 
 extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out);
+extern "C" hipError_t po_launch_solve_round(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
 extern "C" hipError_t po_launch_polish(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
 extern "C" int po_polish_state_doubles(int form, int N, int C, int keep);
 extern "C" hipError_t po_launch_scale(int form, const po::DevBatch *in, const po::DevParams *P, int passes, double *sc, hipStream_t st);
@@ -77,6 +79,7 @@ struct po_handle_s {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     DevBuf pol_buf;  // per-lane ADMM state handed from the solve kernels to the polish kernel (po_params.polish)
+    DevBuf ord_buf;  // po_params.probe_iters: the launch order of the second round
     DevBuf in_buf, out_buf, asm_buf, scale_buf, dbg_buf, map_buf, post_buf, coef_buf, bnd_buf, smooth_buf, smooth_io, plan_coef, plan_io, plan_arena, plan_host;
     po::DevMap map{};  // obstacle-distance layer (po_set_map); map.d == nullptr until set
     std::mutex mu;
@@ -115,7 +118,7 @@ void po_default_params(po_params *p) {
     p->enable_dynamic_segmentation = 1;
     p->enable_raw_output = 1; p->output_spacing = 0.3; /* planning_flags.cpp:127-129 */
     p->polish = 0; p->polish_delta = 1e-6; p->polish_refine_iter = 3; p->polish_passes = 1;  /* OSQP defaults (polish off) */
-    p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-6; p->refine_rounds = 1;
+    p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-6; p->refine_rounds = 1; p->probe_iters = 0;
 }
 
 int po_problem_dims(int form, int N, int keep, int *n, int *m, int *C) {
@@ -176,6 +179,7 @@ int po_destroy(po_handle h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     h->pol_buf.release();
+    h->ord_buf.release();
     h->in_buf.release(); h->out_buf.release(); h->asm_buf.release(); h->scale_buf.release(); h->dbg_buf.release(); h->map_buf.release(); h->post_buf.release(); h->coef_buf.release(); h->bnd_buf.release(); h->smooth_buf.release(); h->smooth_io.release(); h->plan_coef.release(); h->plan_io.release(); h->plan_arena.release(); h->plan_host.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -214,6 +218,7 @@ static int make_dev_params(const po_handle_s *h, int form, int keep, po::DevPara
     D->pol_passes = p.polish_passes;
     D->refine = p.refine; D->ref_every = p.refine_every > 0 ? p.refine_every : 10; D->ref_max_iter = p.refine_max_iter; D->ref_max_refactor = p.refine_max_refactor;
     D->ref_rho = p.refine_rho; D->ref_eps = p.refine_eps; D->ref_rounds = p.refine_rounds;
+    D->slice = (!p.refine && p.probe_iters > 0) ? p.probe_iters : 0;
     return PO_OK;
 }
 
@@ -270,7 +275,7 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     if ((rc = h->scale_buf.ensure(sizeof(double) * 64 * (size_t)in->B))) return rc;
     D.scale = static_cast<double *>(h->scale_buf.p);
     bool polish = false;
-    if (h->params.polish || h->params.refine) {  // OSQP's polish, opt-in: the solve kernels leave their ADMM state in pol_buf, polish_kernel picks it up
+    if (h->params.polish || h->params.refine || h->params.probe_iters > 0) {  // OSQP's polish, opt-in (the refinement and the sliced solve use the same block): the solve kernels leave their ADMM state in pol_buf, polish_kernel picks it up
         const int sd = po_polish_state_doubles(in->formulation, in->N, C, in->keep);
         if (sd > 0) {  // (shapes on the single-level mapping have no polish kernel: status_polish stays 0 = not attempted)
             if ((rc = h->pol_buf.ensure(sizeof(double) * (size_t)sd * (size_t)in->B))) return rc;
@@ -287,7 +292,34 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     // per-path equilibration (h->params.scaling class-level Ruiz passes; 0 -> identity), then the fused solve
     HIP_TRY(po_launch_scale(in->formulation, &D, &P, h->params.scaling, static_cast<double *>(h->scale_buf.p), h->stream));
-    HIP_TRY(po_launch_solve(in->formulation, &D, &P, h->stream, nullptr));
+    if (P.slice > 0 && D.pol_state != nullptr) {
+        // po_params.probe_iters: probe launch pair, then the unfinished paths longest-first by the dual residual they were handed back with (the caller's own
+        // order hint, when there is one, is kept for both rounds)
+        po::DevBatch rb = D;
+        rb.round = 0;
+        HIP_TRY(po_launch_solve_round(in->formulation, &rb, &P, h->stream));
+        if (D.order == nullptr) {
+            std::vector<po_info> hi((size_t)in->B);
+            HIP_TRY(hipMemcpyAsync(hi.data(), D.out_info, sizeof(po_info) * hi.size(), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            std::vector<int> ord((size_t)in->B);
+            for (int b = 0; b < in->B; ++b) ord[(size_t)b] = b;
+            auto live = [&](int b) { return hi[(size_t)b].status == po::kStatusDeferred - 1; };
+            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
+                const bool la = live(a), lb = live(b);
+                if (la != lb) return la;                       // handed-back paths first
+                return la && hi[(size_t)a].r_dual > hi[(size_t)b].r_dual;  // largest dual residual first
+            });
+            if (int rc2 = h->ord_buf.ensure(sizeof(int) * (size_t)in->B)) return rc2;
+            HIP_TRY(hipMemcpyAsync(h->ord_buf.p, ord.data(), sizeof(int) * ord.size(), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));  // (ord is a local)
+            rb.order = static_cast<const int *>(h->ord_buf.p);
+        }
+        rb.round = 1;
+        HIP_TRY(po_launch_solve_round(in->formulation, &rb, &P, h->stream));
+    } else {
+        HIP_TRY(po_launch_solve(in->formulation, &D, &P, h->stream, nullptr));
+    }
     if (polish && h->params.polish) HIP_TRY(po_launch_polish(in->formulation, &D, &P, h->stream));
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->timed = true;

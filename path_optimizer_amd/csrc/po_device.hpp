@@ -19,6 +19,7 @@ namespace po {
 
 constexpr double kInf = 1e30;        // OsqpEigen::INFTY
 constexpr double kInfThresh = 1e26;  // OSQP_INFTY * MIN_SCALING: "infinite" bound test
+constexpr int kStatusDeferred = -100;  // po_info.status while a solve is in flight: left to the general launch of the round (-100) / handed back to round r (-100 - r)
 constexpr double kRhoMin = 1e-6, kRhoMax = 1e6, kRhoEqOverIneq = 1e3, kRhoTol = 1e-4;
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kPi2 = 1.57079632679489661923;
@@ -35,6 +36,7 @@ struct DevParams {
     double pol_delta;           // OSQP delta
     int polish, pol_refine, pol_passes;
     int refine, ref_every, ref_max_iter, ref_max_refactor, ref_rounds;  // po_params.refine*
+    int slice;              // po_params.probe_iters (0 with refine): iterations of the first launch pair
     double ref_rho, ref_eps;
 };
 

@@ -62,10 +62,11 @@ PO_DECL(po_launch_solve_kp_ref); PO_DECL(po_launch_solve_kpc_ref); PO_DECL(po_la
 
 // Two launches on the same stream for the two-level mapping: the uniform-row-class variant first (solves what it can, defers the rest),
 // then the general variant (po_fast.inc, solve_kernel_fast).
+extern "C" hipError_t po_launch_solve_round(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
 extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out) {
     using namespace po;
     hipError_t e;
-    const bool ref = P->refine != 0 && in->pol_state != nullptr;  // the kernels that carry the refinement phase (two-level shapes; they need the state block)
+    const bool ref = (P->refine != 0 || P->slice > 0) && in->pol_state != nullptr;  // the kernels that carry the refinement phase / hand paths back (two-level shapes; they need the state block)
     if (!ref) {
         if (form == F_KP) { e = po_launch_solve_kp_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kp(in, P, st, lds_out); }
         if (form == F_KPC) { e = po_launch_solve_kpc_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kpc(in, P, st, lds_out); }
@@ -73,17 +74,24 @@ extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po
         return e != hipSuccess ? e : po_launch_solve_k(in, P, st, lds_out);
     }
     // po_params.refine_rounds: one pair of launches per round; a later round finds only the paths the round before handed back (the others leave after one
-    // 4-byte read)
-    const int rounds = P->ref_rounds > 1 ? P->ref_rounds : 1;
+    // 4-byte read).  po_params.probe_iters: two rounds (the engine launches them one by one, po_launch_solve_round, to order the second).
+    const int rounds = P->refine ? (P->ref_rounds > 1 ? P->ref_rounds : 1) : 2;
     DevBatch rb = *in;
     for (int r = 0; r < rounds; ++r) {
         rb.round = r;
-        if (form == F_KP) { e = po_launch_solve_kp_uni_ref(&rb, P, st, lds_out); if (e == hipSuccess) e = po_launch_solve_kp_ref(&rb, P, st, lds_out); }
-        else if (form == F_KPC) { e = po_launch_solve_kpc_uni_ref(&rb, P, st, lds_out); if (e == hipSuccess) e = po_launch_solve_kpc_ref(&rb, P, st, lds_out); }
-        else { e = po_launch_solve_k_uni_ref(&rb, P, st, lds_out); if (e == hipSuccess) e = po_launch_solve_k_ref(&rb, P, st, lds_out); }
+        e = po_launch_solve_round(form, &rb, P, st);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+// one round (in->round) of the kernels that hand paths back: the uniform-row-class launch, then the general one
+extern "C" hipError_t po_launch_solve_round(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st) {
+    using namespace po;
+    hipError_t e;
+    if (form == F_KP) { e = po_launch_solve_kp_uni_ref(in, P, st, nullptr); if (e == hipSuccess) e = po_launch_solve_kp_ref(in, P, st, nullptr); }
+    else if (form == F_KPC) { e = po_launch_solve_kpc_uni_ref(in, P, st, nullptr); if (e == hipSuccess) e = po_launch_solve_kpc_ref(in, P, st, nullptr); }
+    else { e = po_launch_solve_k_uni_ref(in, P, st, nullptr); if (e == hipSuccess) e = po_launch_solve_k_ref(in, P, st, nullptr); }
+    return e;
 }
 
 #define PO_DECLP(name) extern "C" hipError_t name(const po::DevBatch *in, const po::DevParams *P, hipStream_t st)

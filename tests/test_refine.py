@@ -306,3 +306,31 @@ def test_device_refine_config2_against_exact_optima():
             setattr(p, k, v)
         st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
         assert (info["status"] == 1).all() and (_rms(xs, gold, b.N) <= 1e-4).mean() >= bar, kw
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form,cfg,B,probe_iters,max_iter", [(0, 3, 64, 100, 4000), (0, 3, 32, 75, 4000), (0, 2, 48, 60, 4000), (1, 5, 6, 150, 4000), (2, 3, 16, 100, 4000), (0, 3, 24, 100, 250)])
+def test_device_probe_then_longest_first_is_bit_identical(form, cfg, B, probe_iters, max_iter):
+    """po_params.probe_iters only changes the schedule: every path yields after the probe and is resumed by the second launch pair (in the host's predicted
+    longest-first order) from the state block — iterates, iteration counts, refactorisation counts and statuses equal the one-launch solve bit for bit
+    (uniform and general kernel, one- and two-wave shapes, a probe that is no multiple of the check interval, paths that run out of iterations), the
+    polish finds the final state, and a caller-supplied order is honoured."""
+    from path_optimizer_amd import binding
+
+    b = synth.make_batch(cfg, B=B) if form == 0 else synth.make_batch(cfg, B=B, formulation=form)
+    b.bounds[1, b.N // 3, 1, :] = 0.25  # one path with a pinned row: non-uniform classes -> the general kernel
+    p = binding.default_params()
+    p.max_iter = max_iter
+    st0, i0, x0 = binding.Engine(0, p).solve_batch(b, want_x=True)
+    p.probe_iters = probe_iters
+    st1, i1, x1 = binding.Engine(0, p).solve_batch(b, want_x=True)
+    assert i0["iters"].max() > probe_iters  # (the case is one that actually yields)
+    for k in ("status", "iters", "n_refactor", "r_prim", "r_dual", "rho", "obj"):
+        assert np.array_equal(i0[k], i1[k]), (k, i0[k], i1[k])
+    assert np.array_equal(st0, st1) and np.array_equal(x0, x1)
+    if max_iter == 4000:
+        p.polish = 1
+        st3, i3, _ = binding.Engine(0, p).solve_batch(b)
+        p.probe_iters = 0
+        st2, i2, _ = binding.Engine(0, p).solve_batch(b)
+        assert np.array_equal(st2, st3) and np.array_equal(i2["status_polish"], i3["status_polish"])
