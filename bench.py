@@ -318,7 +318,9 @@ def stage_legs_gpu(torch, binding, synth, eng, stream, dbatch, B):
                                                        "qp_iters_mean": float(pinf4["iters"].mean())}
     e4.close()
     # the same 4096 instances with the path QP's refinement phase (po_params.refine, include/po_hip.h): every path ends at residuals of 1e-6 or keeps its plain point
-    for tag, kw in (("eps_1e-4_refine_rounds3", dict(refine=1, refine_rounds=3)), ("eps_3e-4_refine", dict(refine=1, eps_abs=3e-4, eps_rel=3e-4))):
+    # ... and with the probe + longest-first schedule of the path QP (po_params.probe_iters: results bit-identical to the plain leg)
+    for tag, kw in (("eps_1e-4_refine_rounds3", dict(refine=1, refine_rounds=3)), ("eps_3e-4_refine", dict(refine=1, eps_abs=3e-4, eps_rel=3e-4)),
+                    ("probe_150_then_longest_first", dict(probe_iters=150))):
         p5 = binding.default_params()
         for k_, v_ in kw.items():
             setattr(p5, k_, v_)

@@ -328,6 +328,9 @@ def test_device_probe_then_longest_first_is_bit_identical(form, cfg, B, probe_it
     for k in ("status", "iters", "n_refactor", "r_prim", "r_dual", "rho", "obj"):
         assert np.array_equal(i0[k], i1[k]), (k, i0[k], i1[k])
     assert np.array_equal(st0, st1) and np.array_equal(x0, x1)
+    # the caller's own order hint: used for both rounds instead of the prediction
+    st4, i4, x4 = binding.Engine(0, p).solve_batch(b, want_x=True, order=np.arange(b.B)[::-1])
+    assert np.array_equal(st0, st4) and np.array_equal(i0["iters"], i4["iters"]) and np.array_equal(x0, x4)
     if max_iter == 4000:
         p.polish = 1
         st3, i3, _ = binding.Engine(0, p).solve_batch(b)
