@@ -70,7 +70,7 @@ template <int KIND> struct Lds {
             if (scan_padded(scan_chunk<T::W>((int)n))) d += kChunkPad + np + kChunkPad;  // chunk-padded factor, wkp (the partitioned substitution's right-hand side)
         }
         size_t b = d * 8 + ((size_t)T::KA * m + (size_t)kKT * n) * 2 + n * 4 + m + 8;
-        return (b + 15) & ~(size_t)15;
+        return ((b + 15) & ~(size_t)15) + 64;  // + the kernel's static reduction scratch (8 doubles): what the capacity check must see
     }
 };
 
@@ -1204,9 +1204,10 @@ template <int KIND, int NWV, int WPE> __global__ __launch_bounds__(64 * NWV, WPE
 }
 
 template <int KIND, int NWV, int WPE> static hipError_t launch_kind_w(const DevSmooth &a, hipStream_t st, size_t lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&smooth_kernel<KIND, NWV, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t dyn = lds - 64;  // lds = dynamic part + the kernel's 64 static bytes (Lds::bytes)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&smooth_kernel<KIND, NWV, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((smooth_kernel<KIND, NWV, WPE>), dim3(a.B), dim3(64 * NWV), lds, st, a);
+    hipLaunchKernelGGL((smooth_kernel<KIND, NWV, WPE>), dim3(a.B), dim3(64 * NWV), dyn, st, a);
     return hipGetLastError();
 }
 template <int KIND> static hipError_t launch_kind(const DevSmooth &a, hipStream_t st, size_t lds) {
@@ -1249,7 +1250,7 @@ extern "C" size_t po_smooth_scratch_doubles(int kind, int P) {
     }
     return 0;
 }
-extern "C" hipError_t po_launch_smooth(const po::DevSmooth *a, hipStream_t st) {
+extern "C" hipError_t po_launch_smooth(const po::DevSmooth *a, hipStream_t st) {  // (po_smooth_lds_bytes counts the 64 static bytes too: the dynamic part is that minus 64)
     const size_t lds = po_smooth_lds_bytes(a->kind, a->P);
     switch (a->kind) {
         case PO_SMOOTH_TENSION2: return po::launch_kind<PO_SMOOTH_TENSION2>(*a, st, lds);
