@@ -304,12 +304,12 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
             HIP_TRY(hipStreamSynchronize(h->stream));
             std::vector<int> ord((size_t)in->B);
             for (int b = 0; b < in->B; ++b) ord[(size_t)b] = b;
-            auto live = [&](int b) { return hi[(size_t)b].status == po::kStatusDeferred - 1; };
-            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
-                const bool la = live(a), lb = live(b);
-                if (la != lb) return la;                       // handed-back paths first
-                return la && hi[(size_t)a].r_dual > hi[(size_t)b].r_dual;  // largest dual residual first
-            });
+            std::vector<double> key((size_t)in->B);  // handed-back paths: their dual residual (>= 0; a NaN counts as 0); the others: -1, i.e. last
+            for (int b = 0; b < in->B; ++b) {
+                const po_info &o = hi[(size_t)b];
+                key[(size_t)b] = o.status == po::kStatusDeferred - 1 ? ((o.r_dual == o.r_dual && o.r_dual > 0) ? o.r_dual : 0.0) : -1.0;
+            }
+            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return key[(size_t)a] > key[(size_t)b]; });  // largest dual residual first
             if (int rc2 = h->ord_buf.ensure(sizeof(int) * (size_t)in->B)) return rc2;
             HIP_TRY(hipMemcpyAsync(h->ord_buf.p, ord.data(), sizeof(int) * ord.size(), hipMemcpyHostToDevice, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));  // (ord is a local)
