@@ -252,7 +252,7 @@ def stage_legs_gpu(torch, binding, synth, eng, stream, dbatch, B):
                               "workload": f"{B} spline reference paths x 200 states x 4 circles, <= 28 bilinear samples each"},
           "post_check": {"ms": ms_c, "paths_per_s": B / (ms_c * 1e-3), "states_per_s": B * 200 / (ms_c * 1e-3),
                          "ok_frac": float(ok.float().mean().item())}}
-    from path_optimizer_amd.abi import INFO_DTYPE
+    from path_optimizer_amd.abi import INFO_BYTES, INFO_DTYPE
     sm = {}
     sm_inputs = {}
     for name, kind, npts in (("tension2", 0, 100), ("post", 2, 60)):
@@ -260,7 +260,7 @@ def stage_legs_gpu(torch, binding, synth, eng, stream, dbatch, B):
         sm_inputs[name] = (kind, si)
         tt = {k: torch.from_numpy(np.ascontiguousarray(np.concatenate([v] * reps, axis=0)[:B])).cuda() for k, v in si.items() if v is not None}
         so = dict(x=torch.zeros((B, npts), dtype=torch.float64, device="cuda"), y=torch.zeros((B, npts), dtype=torch.float64, device="cuda"),
-                  s=torch.zeros((B, npts), dtype=torch.float64, device="cuda"), info=torch.zeros((B, 48), dtype=torch.uint8, device="cuda"))
+                  s=torch.zeros((B, npts), dtype=torch.float64, device="cuda"), info=torch.zeros((B, INFO_BYTES), dtype=torch.uint8, device="cuda"))
         ms_s = timed(lambda: eng.smooth_batch_device(kind, tt, so))
         inf = so["info"].cpu().numpy().view(INFO_DTYPE).reshape(-1)
         n_q, m_q = binding.smooth_dims(kind, npts)
@@ -292,7 +292,7 @@ def stage_legs_gpu(torch, binding, synth, eng, stream, dbatch, B):
     tp = {k: torch.from_numpy(np.ascontiguousarray(scn[k][perm])).cuda() for k in ("way_x", "way_y", "start", "goal")}
     Np = 320
     po_ = dict(states=torch.zeros((B, Np, 5), dtype=torch.float64, device="cuda"), n_states=torch.zeros(B, dtype=torch.int32, device="cuda"),
-               ok=torch.zeros(B, dtype=torch.int32, device="cuda"), stage=torch.zeros(B, dtype=torch.int32, device="cuda"), info=torch.zeros((B, 48), dtype=torch.uint8, device="cuda"))
+               ok=torch.zeros(B, dtype=torch.int32, device="cuda"), stage=torch.zeros(B, dtype=torch.int32, device="cuda"), info=torch.zeros((B, INFO_BYTES), dtype=torch.uint8, device="cuda"))
     way_len = float(np.hypot(np.diff(scn["way_x"], axis=1), np.diff(scn["way_y"], axis=1)).sum(axis=1).max())
     eng.plan_batch_device(tp, po_, Np, way_len); torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -134,7 +134,14 @@ typedef struct po_params {
                                            first — a fair predictor of the iterations still to go — and the second pair resumes them in that order (a caller-supplied
                                            po_batch_in.order is used instead when there is one).  For batches whose total work per resident slot exceeds the longest
                                            path (the planning pipeline's 4096 QPs on 512 slots: iteration counts 125 .. 1 900, half of them above 500): a launch in
-                                           arbitrary order ends with a long tail of half-empty CUs; longest-first packs it.  150 is a good value there. */
+                                           arbitrary order ends with a long tail of half-empty CUs; longest-first packs it.  150 is a good value there.
+                                           NOTE: with probe_iters > 0 the device-pointer entry is NOT asynchronous (the host reads po_info between the two launch
+                                           pairs and sorts): it blocks, cannot be stream-captured, and po_last_kernel_ms then includes that host time. */
+    int    refine_chain;                /* 1 (default).  refine_rounds > 1 only; scheduling only, results bit-identical.  1: all rounds run inside ONE launch pair —
+                                           a workgroup that does not certify its path pushes it onto a device-side queue and a follow-up workgroup of the same launch
+                                           resumes it, so a later round fills the tail of the one before instead of waiting for its slowest path.  0: one launch pair per
+                                           round (every round ends with a chip-wide barrier). */
+    int    reserved0;
 } po_params;
 
 typedef struct po_info {
@@ -146,6 +153,12 @@ typedef struct po_info {
     double r_dual;      /* ||Px + q + A'y||_inf at exit                 */
     double rho;         /* final rho                                    */
     double obj;         /* 0.5 x'Px at exit                             */
+    int    status_refine; /* po_params.refine: 0 the refinement did not run on this path (refine off, or the path was not solved); 1 CERTIFIED: OSQP's
+                             termination test holds on the returned point at refine_eps (1e-6), i.e. the point is the QP's optimum to that tolerance; -1 the
+                             refinement ran out of its budget before that: the returned point satisfies OSQP's test at eps_abs / eps_rel only (it is the refined
+                             point when its residuals are no worse than the solved point's, else the solved point) — a caller that needs the <= 1e-4 m accuracy
+                             clause per path treats -1 as "not certified" */
+    int    reserved;
 } po_info;
 
 /* One homogeneous batch: B independent paths, each with N points and the same `keep`
@@ -204,11 +217,21 @@ int po_problem_dims(int formulation, int N, int keep, int *n, int *m, int *C);
  * (solver.cpp:22-27 + solver_kp_as_input.cpp:17). Returns keep (>=1) or PO_ERR_INVALID. */
 int po_keep_control_steps(int formulation, const double *ref_s, int N);
 
-/* One handle = one HIP device + one stream; calls on a handle are serialised. */
+/* Number of HIP devices visible to the process (0 when there is none, or no driver): one handle per device is how a batch is spread over the GPUs of a
+ * node (host/include/path_optimizer_amd/solver.hpp: OsqpSolver::solveBatch over several PoEngine). */
+int po_device_count(void);
+/* One handle = one HIP device + one stream; calls on a handle are serialised; distinct handles (same device or not) may be used concurrently
+ * from different host threads. */
 int po_create(int device, const po_params *params, po_handle *out);
 int po_destroy(po_handle h);
 /* Use an existing hipStream_t (e.g. torch's current stream); NULL = the handle's own stream. */
 int po_set_stream(po_handle h, void *hip_stream);
+/* Developer switches for A/B measurements and tests (the library reads NO environment variable; results never depend on these except "split", which
+ * selects an experimental kernel with equal results to rounding).  Keys: "identity_order" (workgroup i solves path i instead of the XCD-aware mixing),
+ * "debug_cycles" (per-phase shader clocks of path 0 on stderr; makes the solve entry synchronous), "split" (stage-split two-wave mapping of the keep-4
+ * kernel; PO_ERR_UNSUPPORTED unless the library was built with `make SPLIT=1`), "smooth_seq", "smooth_waves", "smooth_nopad", "smooth_debug" (smoothing-QP
+ * engine variants), "dp_one_wave" (DP lattice search on one wave per instance whatever the batch size).  Unknown key: PO_ERR_INVALID. */
+int po_debug_set(po_handle h, const char *key, int value);
 
 /* Host-pointer entry: H2D, solve, D2H, synchronous. */
 int po_solve_batch(po_handle h, const po_batch_in *in, const po_batch_out *out);

@@ -15,7 +15,7 @@
 #ifndef PO_PMATH_H_
 #define PO_PMATH_H_
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define PO_PM_FN __host__ __device__ static inline
 #else
 #define PO_PM_FN static inline
@@ -165,7 +165,7 @@ PO_PM_FN double po_patan2(double y, double x) {
     }
 }
 /* x^1.5 for x >= 0 (curvature denominators): x * sqrt(x), two roundings, within one ulp of pow(x, 1.5) */
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define PO_PM_SQRT(x) sqrt(x)
 #else
 #include <math.h>

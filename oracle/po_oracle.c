@@ -95,6 +95,7 @@ void po_oracle_default_params(po_params *p) {
     p->enable_raw_output = 1; p->output_spacing = 0.3; /* planning_flags.cpp:127-129 */
     p->polish = 0; p->polish_delta = 1e-6; p->polish_refine_iter = 3; p->polish_passes = 1; /* OSQP defaults (polish off) */
     p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-6; p->refine_rounds = 1; p->probe_iters = 0;  /* (probe_iters: device scheduling only, no effect on results) */
+    p->refine_chain = 1; /* device scheduling only */
 }
 
 /* tools.hpp:24-35 — recursive in the reference; same fixed point as this loop */
@@ -1243,6 +1244,7 @@ resume_main:
         refine_fac += nfac;
         info->iters = iter + refine_its;
         info->n_refactor = n_refactor + refine_fac;
+        info->status_refine = stop ? 1 : -1; /* certified at refine_eps / out of budget (po_hip.h) */
         if (stop || (pri_res <= pri0 && dua_res <= dua0)) {
             info->r_prim = pri_res;
             info->r_dual = dua_res;

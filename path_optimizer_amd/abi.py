@@ -28,7 +28,7 @@ class PoParams(C.Structure):
         ("mu", C.c_double), ("max_curvature_rate", C.c_double), ("search_lateral_range", C.c_double),
         ("search_long_spacing", C.c_double), ("search_lat_spacing", C.c_double), ("enable_dynamic_segmentation", C.c_int), ("enable_raw_output", C.c_int), ("output_spacing", C.c_double), ("smoothing_method", C.c_int), ("optimization_method", C.c_int), ("enable_exact_position", C.c_int), ("polish", C.c_int),
         ("polish_delta", C.c_double), ("polish_refine_iter", C.c_int), ("polish_passes", C.c_int),
-        ("refine", C.c_int), ("refine_every", C.c_int), ("refine_max_iter", C.c_int), ("refine_max_refactor", C.c_int), ("refine_rho", C.c_double), ("refine_eps", C.c_double), ("refine_rounds", C.c_int), ("probe_iters", C.c_int),
+        ("refine", C.c_int), ("refine_every", C.c_int), ("refine_max_iter", C.c_int), ("refine_max_refactor", C.c_int), ("refine_rho", C.c_double), ("refine_eps", C.c_double), ("refine_rounds", C.c_int), ("probe_iters", C.c_int), ("refine_chain", C.c_int), ("reserved0", C.c_int),
     ]
 
 
@@ -39,7 +39,8 @@ class PoMap(C.Structure):
 
 class PoInfo(C.Structure):
     _fields_ = [("status", C.c_int), ("iters", C.c_int), ("n_refactor", C.c_int), ("status_polish", C.c_int),
-                ("r_prim", C.c_double), ("r_dual", C.c_double), ("rho", C.c_double), ("obj", C.c_double)]
+                ("r_prim", C.c_double), ("r_dual", C.c_double), ("rho", C.c_double), ("obj", C.c_double),
+                ("status_refine", C.c_int), ("reserved", C.c_int)]
 
 
 class PoBatchIn(C.Structure):
@@ -54,7 +55,8 @@ class PoBatchOut(C.Structure):
 
 
 INFO_DTYPE = [("status", "<i4"), ("iters", "<i4"), ("n_refactor", "<i4"), ("status_polish", "<i4"),
-              ("r_prim", "<f8"), ("r_dual", "<f8"), ("rho", "<f8"), ("obj", "<f8")]
+              ("r_prim", "<f8"), ("r_dual", "<f8"), ("rho", "<f8"), ("obj", "<f8"), ("status_refine", "<i4"), ("reserved", "<i4")]
+INFO_BYTES = 56  # sizeof(po_info)
 
 
 class PoBoundsIn(C.Structure):

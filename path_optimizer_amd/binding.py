@@ -11,13 +11,13 @@ import os
 
 import numpy as np
 
-from .abi import (INFO_DTYPE, PO_ERR_HIP, PO_OK, PoBatchIn, PoBatchOut, PoParams)
+from .abi import (INFO_BYTES, INFO_DTYPE, PO_ERR_HIP, PO_OK, PoBatchIn, PoBatchOut, PoParams)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PO_LIB") or os.path.join(_HERE, "libpo_hip.so")  # PO_LIB: dev builds (make dev), A/B experiments
 _LIB = None
 
-EXPORTS = ["po_default_params", "po_problem_dims", "po_keep_control_steps", "po_create", "po_destroy", "po_set_stream",
+EXPORTS = ["po_default_params", "po_problem_dims", "po_keep_control_steps", "po_create", "po_destroy", "po_set_stream", "po_debug_set", "po_device_count",
            "po_solve_batch", "po_solve_batch_device", "po_assemble_batch", "po_scaling_batch", "po_last_kernel_ms", "po_strerror",
            "po_last_hip_error", "po_version", "po_set_map", "po_postcheck_batch", "po_postcheck_batch_device", "po_bounds_batch",
            "po_bounds_batch_device", "po_map_sample", "po_smooth_dims", "po_smooth_batch", "po_smooth_batch_device",
@@ -28,6 +28,10 @@ EXPORTS = ["po_default_params", "po_problem_dims", "po_keep_control_steps", "po_
 
 class PoError(RuntimeError):
     pass
+
+
+_ENV_DEBUG = {"PO_IDENTITY_ORDER": "identity_order", "PO_DEBUG_CYCLES": "debug_cycles", "PO_SPLIT": "split", "PO_SMOOTH_SEQ": "smooth_seq",
+              "PO_SMOOTH_WAVES": "smooth_waves", "PO_SMOOTH_NOPAD": "smooth_nopad", "PO_SMOOTH_DEBUG": "smooth_debug", "PO_DP_ONE_WAVE": "dp_one_wave"}
 
 
 def lib():
@@ -114,6 +118,16 @@ class Engine:
         self.params = params or default_params()
         self._h = C.c_void_p()
         _check(lib().po_create(device, C.byref(self.params), C.byref(self._h)))
+        # developer conveniences of THIS Python plumbing (tools/*.py, A/B runs): PO_* environment variables are translated into po_debug_set calls
+        # here; the C library itself reads no environment variable
+        for env, key in _ENV_DEBUG.items():
+            v = os.environ.get(env)
+            if v not in (None, "", "0"):
+                self.debug_set(key, int(v) if v.lstrip("-").isdigit() else 1)
+
+    def debug_set(self, key: str, value: int):
+        """po_debug_set: developer A/B switches (identity_order, debug_cycles, split, smooth_seq, smooth_waves, smooth_nopad, smooth_debug, dp_one_wave)."""
+        _check(lib().po_debug_set(self._h, key.encode(), int(value)))
 
     def close(self):
         if self._h:
@@ -243,7 +257,7 @@ class Engine:
         return ox, oy, os_, info, raw
 
     def smooth_batch_device(self, kind: int, t: dict, out: dict):
-        """Device-pointer entry: t / out hold torch tensors (keys as above; out: x, y, s [B,P] f64, info [B,48] u8, optional raw)."""
+        """Device-pointer entry: t / out hold torch tensors (keys as above; out: x, y, s [B,P] f64, info [B,sizeof(po_info)] u8, optional raw)."""
         from .abi import PoSmoothIn, PoSmoothOut
 
         B, P = t["s"].shape
@@ -325,7 +339,7 @@ class Engine:
         return states, n, ok, stage, info
 
     def plan_batch_device(self, t: dict, out: dict, N: int, max_length: float):
-        """Device-pointer entry: t: way_x, way_y [B,W], start [B,4], goal [B,3] (+ n_way); out: states [B,N,5], n_states, ok (+ stage, info [B,48] u8)."""
+        """Device-pointer entry: t: way_x, way_y [B,W], start [B,4], goal [B,3] (+ n_way); out: states [B,N,5], n_states, ok (+ stage, info [B,sizeof(po_info)] u8)."""
         from .abi import PoPlanIn, PoPlanOut
 
         B, W = t["way_x"].shape
@@ -360,7 +374,7 @@ class DeviceBatch:
         self.n_points = None if npts is None else torch.from_numpy(np.ascontiguousarray(npts, dtype=np.int32)).to(device)
         n, _, _ = problem_dims(batch.formulation, batch.N, batch.keep)
         self.out_states = torch.zeros((batch.B, batch.N, 5), dtype=torch.float64, device=device)
-        self.out_info = torch.zeros((batch.B, 48), dtype=torch.uint8, device=device)  # sizeof(po_info) == 48
+        self.out_info = torch.zeros((batch.B, INFO_BYTES), dtype=torch.uint8, device=device)  # sizeof(po_info)
         self.out_x = torch.zeros((batch.B, n), dtype=torch.float64, device=device) if want_x else None
         self.order = None  # optional int32 [B] device tensor: scheduling hint (po_batch_in.order), see set_order()
 

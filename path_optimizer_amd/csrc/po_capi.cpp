@@ -20,6 +20,7 @@
 
 extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out);
 extern "C" hipError_t po_launch_solve_round(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
+extern "C" hipError_t po_launch_finalize_status(po_info *info, int B, hipStream_t st);
 extern "C" hipError_t po_launch_polish(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
 extern "C" int po_polish_state_doubles(int form, int N, int C, int keep);
 extern "C" hipError_t po_launch_scale(int form, const po::DevBatch *in, const po::DevParams *P, int passes, double *sc, hipStream_t st);
@@ -35,7 +36,7 @@ extern "C" size_t po_smooth_lds_bytes(int kind, int P);
 extern "C" size_t po_smooth_scratch_doubles(int kind, int P);
 extern "C" hipError_t po_launch_resample(const po::DevSpline *in, const po::DevResample *r, hipStream_t st);
 extern "C" hipError_t po_launch_limits(int B, int N, const int *n_points, const double *v, const double *a, double *max_k, double *max_kp, double mu, double rate, hipStream_t st);
-extern "C" hipError_t po_launch_dp_search(const po::DevMap *m, const po::DevSpline *in, const po::DevSearch *q, hipStream_t st);
+extern "C" hipError_t po_launch_dp_search(const po::DevMap *m, const po::DevSpline *in, const po::DevSearch *q, int one_wave, hipStream_t st);
 extern "C" size_t po_dp_lds_bytes(int K, int L);
 extern "C" size_t po_spline_lds_bytes(int K);
 extern "C" hipError_t po_launch_map_sample(const po::DevMap *m, int n, const double *xy, double *dist, int *inside, hipStream_t st);
@@ -80,6 +81,11 @@ struct po_handle_s {
     bool timed = false;
     DevBuf pol_buf;  // per-lane ADMM state handed from the solve kernels to the polish kernel (po_params.polish)
     DevBuf ord_buf;  // po_params.probe_iters: the launch order of the second round
+    DevBuf rq_buf;   // po_params.refine_chain: the two device-side queues of a chained-rounds solve
+    // developer switches (po_debug_set; the library reads no environment variable): identity_order (block i solves path i), debug_cycles (per-phase shader
+    // clocks of path 0 on stderr; synchronises), split (experimental stage-split mapping, only in builds made with `make SPLIT=1`), smoothing / DP-search A/B switches
+    bool env_identity = false, env_cycles = false, env_split = false, env_smooth_seq = false, env_smooth_nopad = false, env_smooth_debug = false, env_dp_one_wave = false;
+    int env_smooth_waves = 0;
     DevBuf in_buf, out_buf, asm_buf, scale_buf, dbg_buf, map_buf, post_buf, coef_buf, bnd_buf, smooth_buf, smooth_io, plan_coef, plan_io, plan_arena, plan_host;
     po::DevMap map{};  // obstacle-distance layer (po_set_map); map.d == nullptr until set
     std::mutex mu;
@@ -119,6 +125,7 @@ void po_default_params(po_params *p) {
     p->enable_raw_output = 1; p->output_spacing = 0.3; /* planning_flags.cpp:127-129 */
     p->polish = 0; p->polish_delta = 1e-6; p->polish_refine_iter = 3; p->polish_passes = 1;  /* OSQP defaults (polish off) */
     p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-6; p->refine_rounds = 1; p->probe_iters = 0;
+    p->refine_chain = 1;
 }
 
 int po_problem_dims(int form, int N, int keep, int *n, int *m, int *C) {
@@ -153,6 +160,11 @@ int po_keep_control_steps(int form, const double *ref_s, int N) {
     return k > 1 ? k : 1;
 }
 
+int po_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 int po_create(int device, const po_params *params, po_handle *out) {
     if (!params || !out) return PO_ERR_INVALID;
     if (params->scaling < 0 || params->scaling > 100) return PO_ERR_INVALID;
@@ -180,11 +192,34 @@ int po_destroy(po_handle h) {
     (void)hipStreamSynchronize(h->stream);
     h->pol_buf.release();
     h->ord_buf.release();
+    h->rq_buf.release();
     h->in_buf.release(); h->out_buf.release(); h->asm_buf.release(); h->scale_buf.release(); h->dbg_buf.release(); h->map_buf.release(); h->post_buf.release(); h->coef_buf.release(); h->bnd_buf.release(); h->smooth_buf.release(); h->smooth_io.release(); h->plan_coef.release(); h->plan_io.release(); h->plan_arena.release(); h->plan_host.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
+    return PO_OK;
+}
+
+int po_debug_set(po_handle h, const char *key, int value) {
+    if (!h || !key) return PO_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    const std::string k(key);
+    if (k == "identity_order") h->env_identity = value != 0;
+    else if (k == "debug_cycles") h->env_cycles = value != 0;
+    else if (k == "split") {
+#ifdef PO_WITH_SPLIT
+        h->env_split = value != 0;
+#else
+        if (value != 0) return PO_ERR_UNSUPPORTED;  // built without `make SPLIT=1`
+#endif
+    }
+    else if (k == "smooth_seq") h->env_smooth_seq = value != 0;
+    else if (k == "smooth_waves") h->env_smooth_waves = value;
+    else if (k == "smooth_nopad") h->env_smooth_nopad = value != 0;
+    else if (k == "smooth_debug") h->env_smooth_debug = value != 0;
+    else if (k == "dp_one_wave") h->env_dp_one_wave = value != 0;
+    else return PO_ERR_INVALID;
     return PO_OK;
 }
 
@@ -233,7 +268,7 @@ static int validate(const po_batch_in *in, int *n, int *m, int *C) {
     return PO_OK;
 }
 
-static void fill_dev_batch(po::DevBatch *D, const po_batch_in *in, const po_batch_out *out, int n, int m, int C) {
+static void fill_dev_batch(const po_handle_s *h, po::DevBatch *D, const po_batch_in *in, const po_batch_out *out, int n, int m, int C) {
     D->B = in->B; D->N = in->N; D->keep = in->keep; D->C = C;
     D->ref_x = in->ref_x; D->ref_y = in->ref_y; D->ref_z = in->ref_z; D->ref_k = in->ref_k; D->ref_s = in->ref_s;
     D->bounds = in->bounds; D->x0 = in->x0; D->goal_z = in->goal_z; D->max_k = in->max_k; D->max_kp = in->max_kp;
@@ -245,12 +280,13 @@ static void fill_dev_batch(po::DevBatch *D, const po_batch_in *in, const po_batc
     D->dbg_cycles = nullptr;
     D->only_deferred = 0;
     D->perm_bits = 0;  // block -> path permutation (PO_IDENTITY_ORDER=1: blockIdx order, dev tool)
-    if (!std::getenv("PO_IDENTITY_ORDER") && in->B > 8)
+    if (!h->env_identity && in->B > 8)
         while ((1 << D->perm_bits) < in->B) ++D->perm_bits;
     D->scale = nullptr;
     D->pol_state = nullptr; D->pol_stride = 0;
     D->use_split = 0;
     D->round = 0;
+    D->rq = nullptr; D->rq_rounds = 1;
     D->n = n; D->m = m;
 }
 
@@ -265,8 +301,8 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     po::DevParams P;
     make_dev_params(h, in->formulation, in->keep, &P);
     po::DevBatch D;
-    fill_dev_batch(&D, in, out, n, m, C);
-    const bool dbg = std::getenv("PO_DEBUG_CYCLES") != nullptr;
+    fill_dev_batch(h, &D, in, out, n, m, C);
+    const bool dbg = h->env_cycles;
     if (dbg) {
         if ((rc = h->dbg_buf.ensure(sizeof(long long) * 16 * (size_t)in->B))) return rc;
         D.dbg_cycles = static_cast<long long *>(h->dbg_buf.p);
@@ -286,8 +322,14 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     }
     {   // EXPERIMENTAL, off by default: the stage-split two-wave mapping of the keep-4 kernel (two waves per SIMD; DESIGN.md §9: correct, but measured 30 % slower
         // than the one-wave mapping — seven LDS hand-offs per iteration).  PO_SPLIT=1 selects it (A/B runs, tests); never together with the polish (state layout).
-        const char *e = std::getenv("PO_SPLIT");
-        D.use_split = (e && e[0] == '1' && !polish) ? 1 : 0;
+        D.use_split = (h->env_split && !polish) ? 1 : 0;
+    }
+    po::DevBatch DS = D;  // what the solve launches see (the polish launch keeps D: B workgroups, no queue)
+    if (h->params.refine && h->params.refine_rounds > 1 && h->params.refine_rounds < 64 && h->params.refine_chain && D.pol_state != nullptr && in->B < (1 << 24)) {
+        const size_t qints = 4 + (size_t)(h->params.refine_rounds - 1) * (size_t)in->B;
+        if ((rc = h->rq_buf.ensure(sizeof(int) * 2 * qints))) return rc;
+        DS.rq = static_cast<int *>(h->rq_buf.p);
+        DS.rq_rounds = h->params.refine_rounds;
     }
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     // per-path equilibration (h->params.scaling class-level Ruiz passes; 0 -> identity), then the fused solve
@@ -318,8 +360,9 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
         rb.round = 1;
         HIP_TRY(po_launch_solve_round(in->formulation, &rb, &P, h->stream));
     } else {
-        HIP_TRY(po_launch_solve(in->formulation, &D, &P, h->stream, nullptr));
+        HIP_TRY(po_launch_solve(in->formulation, &DS, &P, h->stream, nullptr));
     }
+    if (D.pol_state != nullptr && (h->params.refine || P.slice > 0)) HIP_TRY(po_launch_finalize_status(D.out_info, in->B, h->stream));
     if (polish && h->params.polish) HIP_TRY(po_launch_polish(in->formulation, &D, &P, h->stream));
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
@@ -440,7 +483,7 @@ int po_assemble_batch(po_handle h, const po_batch_in *in, double *l, double *u, 
     po::DevParams P;
     make_dev_params(h, in->formulation, in->keep, &P);
     po::DevBatch D;
-    fill_dev_batch(&D, &din, nullptr, n, m, C);
+    fill_dev_batch(h, &D, &din, nullptr, n, m, C);
     HIP_TRY(po_launch_assemble(in->formulation, &D, &P, dl, du, dd, h->stream));
     HIP_TRY(hipMemcpyAsync(l, dl, sizeof(double) * B * (size_t)m, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(u, du, sizeof(double) * B * (size_t)m, hipMemcpyDeviceToHost, h->stream));
@@ -468,7 +511,7 @@ int po_scaling_batch(po_handle h, const po_batch_in *in, double *out) {
     po::DevParams P;
     make_dev_params(h, in->formulation, in->keep, &P);
     po::DevBatch D;
-    fill_dev_batch(&D, &din, nullptr, n, m, C);
+    fill_dev_batch(h, &D, &din, nullptr, n, m, C);
     HIP_TRY(po_launch_scale(in->formulation, &D, &P, h->params.scaling, static_cast<double *>(h->scale_buf.p), h->stream));
     HIP_TRY(hipMemcpyAsync(out, h->scale_buf.p, sizeof(double) * 64 * B, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -691,12 +734,10 @@ int po_smooth_batch_device(po_handle h, const po_smooth_in *in, const po_smooth_
     D.scratch = static_cast<double *>(h->smooth_buf.p);
     D.map = h->map;
     D.perm_bits = 0;
-    { const char *e = std::getenv("PO_SMOOTH_SEQ"); D.seq_band = (e && e[0] == '1') ? 1 : 0; }
-    { const char *e = std::getenv("PO_SMOOTH_WAVES"); D.waves = e ? std::atoi(e) : 0; }
-    { const char *e = std::getenv("PO_SMOOTH_NOPAD"); D.nopad = (e && e[0] == '1') ? 1 : 0; }
-    if (!std::getenv("PO_IDENTITY_ORDER") && in->B > 8)
+    D.seq_band = h->env_smooth_seq ? 1 : 0; D.waves = h->env_smooth_waves; D.nopad = h->env_smooth_nopad ? 1 : 0;  // developer A/B switches (read once at po_create)
+    if (!h->env_identity && in->B > 8)
         while ((1 << D.perm_bits) < in->B) ++D.perm_bits;
-    const bool dbg = std::getenv("PO_SMOOTH_DEBUG") != nullptr;  // dev tool: per-phase cycle totals of instance 0..B-1 printed to stderr
+    const bool dbg = h->env_smooth_debug;  // dev tool: per-phase cycle totals of instance 0..B-1 printed to stderr
     if (dbg) {
         if (int rc = h->dbg_buf.ensure(sizeof(long long) * 8 * (size_t)in->B)) return rc;
         D.dbg_cycles = static_cast<long long *>(h->dbg_buf.p);
@@ -809,7 +850,7 @@ int po_dp_search_batch_device(po_handle h, const po_spline_in *in, const double 
     po::DevSpline D{};
     if (int rc = make_dev_spline(h, in, &D)) return rc;
     po::DevSearch Q{p.search_lateral_range, p.search_long_spacing, p.search_lat_spacing, start, L, layer_s, lb, ub, l0, n_layers};
-    HIP_TRY(po_launch_dp_search(&h->map, &D, &Q, h->stream));
+    HIP_TRY(po_launch_dp_search(&h->map, &D, &Q, h->env_dp_one_wave ? 1 : 0, h->stream));
     return PO_OK;
 }
 

@@ -58,6 +58,8 @@ struct DevBatch {
     int use_split;          // launcher hint: take the stage-split two-wave mapping where it exists (keep 4, one-wave shapes; not with polish)
     double *pol_state;      // polish only: [B][pol_stride] per-lane ADMM state left by the solve kernels for polish_kernel (or nullptr)
     int pol_stride;
+    int rq_rounds;          // chained refinement rounds: the grid holds B * rq_rounds workgroups (see rq_wait in po_fast.inc)
+    int *rq;                // ... and this launch's device-side queue [4 + (rq_rounds - 1) * B] (nullptr: one launch pair per round)
 };
 
 template <int F> struct FormTraits;

@@ -63,6 +63,21 @@ PO_DECL(po_launch_solve_kp_ref); PO_DECL(po_launch_solve_kpc_ref); PO_DECL(po_la
 // Two launches on the same stream for the two-level mapping: the uniform-row-class variant first (solves what it can, defers the rest),
 // then the general variant (po_fast.inc, solve_kernel_fast).
 extern "C" hipError_t po_launch_solve_round(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
+namespace po {
+// the two queues of a chained-rounds solve: tail = 0, pending = B, error = 0, entries = -1
+__global__ void rq_init_kernel(int *rq, int qints, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * qints) return;
+    const int k = i % qints;
+    rq[i] = k == 1 ? B : (k < 4 ? 0 : -1);
+}
+// After the launches of a solve that hands paths from launch to launch (refinement rounds, probe): no internal "in flight" status may reach the caller
+// (a path that a malformed caller-side order skipped, a chained follow-up block that gave up waiting): anything at or below kStatusDeferred becomes UNSOLVED.
+__global__ void finalize_status_kernel(po_info *info, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && info[b].status <= kStatusDeferred) { info[b].status = PO_STATUS_UNSOLVED; info[b].status_polish = 0; }
+}
+}  // namespace po
 extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out) {
     using namespace po;
     hipError_t e;
@@ -77,12 +92,31 @@ extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po
     // 4-byte read).  po_params.probe_iters: two rounds (the engine launches them one by one, po_launch_solve_round, to order the second).
     const int rounds = P->refine ? (P->ref_rounds > 1 ? P->ref_rounds : 1) : 2;
     DevBatch rb = *in;
+    if (P->refine && rounds > 1 && in->rq != nullptr) {
+        // chained rounds (po_params.refine_chain): ONE launch pair, rounds * B workgroups each; in->rq = the two queues ([0]: uniform-variant launch, [1]: general
+        // one), in->rq_rounds = rounds.  See rq_wait in po_fast.inc.
+        const int qints = 4 + (rounds - 1) * in->B;
+        hipLaunchKernelGGL(rq_init_kernel, dim3((2 * qints + 255) / 256), dim3(256), 0, st, in->rq, qints, in->B);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        rb.round = 0; rb.rq_rounds = rounds;
+        if (form == F_KP) { e = po_launch_solve_kp_uni_ref(&rb, P, st, nullptr); rb.rq = in->rq + qints; if (e == hipSuccess) e = po_launch_solve_kp_ref(&rb, P, st, nullptr); }
+        else if (form == F_KPC) { e = po_launch_solve_kpc_uni_ref(&rb, P, st, nullptr); rb.rq = in->rq + qints; if (e == hipSuccess) e = po_launch_solve_kpc_ref(&rb, P, st, nullptr); }
+        else { e = po_launch_solve_k_uni_ref(&rb, P, st, nullptr); rb.rq = in->rq + qints; if (e == hipSuccess) e = po_launch_solve_k_ref(&rb, P, st, nullptr); }
+        return e;
+    }
+    rb.rq = nullptr;
     for (int r = 0; r < rounds; ++r) {
         rb.round = r;
         e = po_launch_solve_round(form, &rb, P, st);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+// no internal "in flight" status reaches the caller (po_fast.inc, finalize_status_kernel)
+extern "C" hipError_t po_launch_finalize_status(po_info *info, int B, hipStream_t st) {
+    hipLaunchKernelGGL(po::finalize_status_kernel, dim3((B + 255) / 256), dim3(256), 0, st, info, B);
+    return hipGetLastError();
 }
 // one round (in->round) of the kernels that hand paths back: the uniform-row-class launch, then the general one
 extern "C" hipError_t po_launch_solve_round(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st) {

@@ -880,10 +880,12 @@ extern "C" hipError_t po_launch_bounds(const po::DevMap *m, const po::DevBounds 
 }
 
 extern "C" size_t po_spline_lds_bytes(int K) { return sizeof(double) * 15 * (size_t)K; }
-extern "C" size_t po_dp_lds_bytes(int K, int L) {  // (with the 8-wave variant's reduction scratch: the upper bound the capacity check uses)
+// LDS of the one-wave variant (what the capacity check uses: the launcher falls back to it when the 8-wave variant's reduction scratch does not fit)
+extern "C" size_t po_dp_lds_bytes(int K, int L) {
     const size_t LM = (size_t)(L < po::kDpMaxLayers ? L : po::kDpMaxLayers);
-    return sizeof(double) * (15 * (size_t)K + LM + 2 * 4 * po::kDpMaxLat + po::kDpMaxLat) + 8 * LM + LM * po::kDpMaxLat + LM + 32 + sizeof(double) * 8 * 3 * 64;
+    return sizeof(double) * (15 * (size_t)K + LM + 2 * 4 * po::kDpMaxLat + po::kDpMaxLat) + 8 * LM + LM * po::kDpMaxLat + LM + 32;
 }
+static const size_t kDpEightWaveScratch = sizeof(double) * 8 * 3 * 64;
 extern "C" hipError_t po_launch_resample(const po::DevSpline *in, const po::DevResample *r, hipStream_t st) {
     hipLaunchKernelGGL(po::resample_kernel, dim3(in->B), dim3(64), po_spline_lds_bytes(in->K), st, *in, *r);
     return hipGetLastError();
@@ -894,10 +896,11 @@ extern "C" hipError_t po_launch_limits(int B, int N, const int *n_points, const 
     hipLaunchKernelGGL(po::limits_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, N, n_points, v, a, max_k, max_kp, mu, rate);
     return hipGetLastError();
 }
-extern "C" hipError_t po_launch_dp_search(const po::DevMap *m, const po::DevSpline *in, const po::DevSearch *q, hipStream_t st) {
-    const size_t lds4 = po_dp_lds_bytes(in->K, q->L), lds1 = lds4 - sizeof(double) * 8 * 3 * 64;
+extern "C" hipError_t po_launch_dp_search(const po::DevMap *m, const po::DevSpline *in, const po::DevSearch *q, int one_wave, hipStream_t st) {
+    const size_t lds1 = po_dp_lds_bytes(in->K, q->L), lds4 = lds1 + kDpEightWaveScratch;
     // few instances (a planner's own call: B = 1): eight waves per instance share the edge evaluations of a layer; a full batch keeps one wave per instance
-    if (in->B <= 512 && !std::getenv("PO_DP_ONE_WAVE")) {
+    // (one_wave: the caller's A/B switch, read once at po_create)
+    if (in->B <= 512 && !one_wave && lds4 <= 160 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&po::dp_search_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(po::dp_search_kernel<8>, dim3(in->B), dim3(512), lds4, st, *m, *in, *q);

@@ -94,7 +94,7 @@ namespace po {
 template <class K> hipError_t launch1(K kern, const DevBatch *in, const DevParams *P, int nt, size_t lds, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(in->B), dim3(nt), lds, st, *in, *P);
+    hipLaunchKernelGGL(kern, dim3(in->rq != nullptr ? in->B * in->rq_rounds : in->B), dim3(nt), lds, st, *in, *P);
     return hipGetLastError();
 }
 // thread-block shape: NT threads x SPL stages per thread must cover N, and NT >= C (one control per thread).
@@ -146,6 +146,7 @@ template <int F, bool UNI, bool REF> hipError_t launch_form(const DevBatch *in_,
     if constexpr (UNI) {
         if (!has_uni_variant<F>(s)) return hipSuccess;
     }
+#ifdef PO_WITH_SPLIT
     if constexpr (UNI && F != F_K) {
         // keep == 4 on one-wave blocks (BASELINE configs 1-3): the stage-split two-wave mapping (Fast<..., NW = 2>): 2 stages per lane, <= 256 registers, two waves per SIMD
         if (in->use_split && s.two && s.spl == 4 && s.nt == 64 && in->keep == 4) {
@@ -154,6 +155,7 @@ template <int F, bool UNI, bool REF> hipError_t launch_form(const DevBatch *in_,
             if (lds2 <= 160 * 1024) return launch1(&solve_kernel_split<F>, in, P, 128, lds2, st);
         }
     }
+#endif
 #ifdef PO_DEV_HEADLINE  // dev builds: only the BASELINE config-3 variant (seconds to compile); -DPO_DEV_SPL=k: the one-wave variant of keep k instead
 #ifndef PO_DEV_SPL
 #define PO_DEV_SPL 4

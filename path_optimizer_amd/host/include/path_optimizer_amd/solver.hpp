@@ -3,16 +3,20 @@
 //   reference                                                    here
 //   OsqpSolver::create(type, ref, vehicle, horizon)              same signature, same "K"/"KP"/"KPC" strings (solver.cpp:30-44)
 //   virtual bool OsqpSolver::solve(std::vector<State>*)          same: true iff the QP status is `solved` (solver.cpp:46-77)
-//   (none: one path per call)                                    OsqpSolver::solveBatch(): many independent planning instances
+//   (none: one path per call)                                    OsqpSolver::solveBatch(): many independent planning instances, on one device or — given
+//                                                                several engines — split over the GPUs of the node (contiguous shards,
+//                                                                one host thread + one handle + one stream per device, no collective)
 //
 // Differences, on purpose: an unknown type still yields nullptr like the reference, but solveBatch
 // reports it as an error instead of silently producing an empty "successful" path; parameters are captured in a
 // po_params block at construction instead of being read from gflags globals during assembly.
 #pragma once
+#include <chrono>
 #include <cstddef>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "po_hip.h"  // repo-root include/ on the include path
@@ -44,6 +48,16 @@ class PoEngine {
     po_handle handle() const { return h_; }
     const po_params &params() const { return params_; }
     static PoEngine &instance() { static PoEngine e; return e; }
+    // One engine per visible HIP device (device 0 first), created once per process with the default parameters: what the multi-device solveBatch takes.
+    static std::vector<PoEngine *> allDevices() {
+        static std::vector<std::unique_ptr<PoEngine>> own;
+        static std::vector<PoEngine *> view;
+        if (view.empty()) {
+            const int n = po_device_count();
+            for (int d = 0; d < n; ++d) { own.emplace_back(new PoEngine(d)); view.push_back(own.back().get()); }
+        }
+        return view;
+    }
  private:
     po_handle h_{};
     po_params params_{};
@@ -90,13 +104,59 @@ class OsqpSolver {
                           std::vector<po_info> *info, PoEngine *engine = nullptr) {
         if (!inst || !paths || !info || horizon < 2) return PO_ERR_INVALID;
         PoEngine *eng = engine ? engine : &PoEngine::instance();
-        const size_t N = horizon;
+        paths->assign(B, {});
+        info->assign(B, po_info{});
+        int keep = 0;
+        return B == 0 ? PO_OK : solveShard(formulation, inst, 0, B, horizon, paths, info->data(), eng, &keep);
+    }
+
+    // New: the same batch split over several devices.  Engine g of G solves the contiguous shard [g B / G, (g + 1) B / G) (the first B % G
+    // shards one path longer: the split of path_optimizer_amd/shard.py and bench.py) on its own host thread, handle and stream; paths are independent QPs, so
+    // there is no exchange between devices and the results — states and po_info, written in place — are bit-identical to the single-engine call.
+    // device_ms (optional): wall time of each shard's pack + H2D + solve + D2H, for the load-imbalance figure max / mean.
+    // One batch = one (horizon, keep_control_steps_): PO_ERR_INVALID otherwise, as for one engine.  The first error of any shard is returned.
+    static int solveBatch(int formulation, const PlanningInstance *inst, size_t B, size_t horizon, std::vector<std::vector<State>> *paths,
+                          std::vector<po_info> *info, const std::vector<PoEngine *> &engines, std::vector<double> *device_ms = nullptr) {
+        if (!inst || !paths || !info || horizon < 2 || engines.empty()) return PO_ERR_INVALID;
+        for (PoEngine *e : engines) if (!e) return PO_ERR_INVALID;
+        const size_t G = engines.size();
+        paths->assign(B, {});
+        info->assign(B, po_info{});
+        if (device_ms) device_ms->assign(G, 0.0);
+        if (B == 0) return PO_OK;
+        std::vector<int> rc(G, PO_OK), keep(G, 0);
+        std::vector<size_t> lo(G), hi(G);
+        for (size_t g = 0; g < G; ++g) { const size_t base = B / G, rem = B % G; lo[g] = g * base + (g < rem ? g : rem); hi[g] = lo[g] + base + (g < rem ? 1 : 0); }
+        auto work = [&](size_t g) {
+            const auto t0 = std::chrono::steady_clock::now();
+            if (hi[g] > lo[g]) rc[g] = solveShard(formulation, inst, lo[g], hi[g], horizon, paths, info->data(), engines[g], &keep[g]);
+            if (device_ms) (*device_ms)[g] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        };
+        std::vector<std::thread> th;
+        for (size_t g = 1; g < G; ++g) th.emplace_back(work, g);
+        work(0);
+        for (auto &t : th) t.join();
+        int k0 = 0;
+        for (size_t g = 0; g < G; ++g) {
+            if (rc[g] != PO_OK) return rc[g];
+            if (hi[g] > lo[g]) { if (k0 == 0) k0 = keep[g]; else if (keep[g] != k0) return PO_ERR_INVALID; }  // one batch = one keep_control_steps_
+        }
+        return PO_OK;
+    }
+
+ private:
+    // paths [lo, hi) of the batch on one engine; results written in place ((*paths)[b], info[b])
+    static int solveShard(int formulation, const PlanningInstance *inst, size_t lo, size_t hi, size_t horizon, std::vector<std::vector<State>> *paths,
+                          po_info *info, PoEngine *eng, int *keep_out) {
+        const size_t N = horizon, B = hi - lo;
         std::vector<double> rx(B * N), ry(B * N), rz(B * N), rk(B * N), rs(B * N), bd(B * N * 8), x0(B * 3), gz(B), mk, mkp;
         if (formulation == PO_KPC) { mk.resize(B * N); mkp.resize(B * N); }
         int keep = 0;
         for (size_t b = 0; b < B; ++b) {  // AoS -> SoA pack
-            const auto &st = inst[b].reference_path->getReferenceStates();
-            const auto &bnd = inst[b].reference_path->getBounds();
+            const PlanningInstance &pi = inst[lo + b];
+            if (!pi.reference_path || !pi.vehicle_state) return PO_ERR_INVALID;
+            const auto &st = pi.reference_path->getReferenceStates();
+            const auto &bnd = pi.reference_path->getBounds();
             if (st.size() < N || bnd.size() < N) return PO_ERR_INVALID;
             for (size_t i = 0; i < N; ++i) {
                 const size_t o = b * N + i;
@@ -105,32 +165,32 @@ class OsqpSolver {
                 for (int j = 0; j < 4; ++j) { bd[o * 8 + 2 * j] = c[j]->lb; bd[o * 8 + 2 * j + 1] = c[j]->ub; }
             }
             if (formulation == PO_KPC) {
-                const auto &a = inst[b].reference_path->getMaxKList();
-                const auto &c = inst[b].reference_path->getMaxKpList();
+                const auto &a = pi.reference_path->getMaxKList();
+                const auto &c = pi.reference_path->getMaxKpList();
                 if (a.size() < N || c.size() < N) return PO_ERR_INVALID;
                 for (size_t i = 0; i < N; ++i) { mk[b * N + i] = a[i]; mkp[b * N + i] = c[i]; }
             }
-            const auto e = inst[b].vehicle_state->getInitError();
-            x0[b * 3] = e[0]; x0[b * 3 + 1] = e[1]; x0[b * 3 + 2] = inst[b].vehicle_state->getStartState().k;
-            gz[b] = inst[b].vehicle_state->getEndState().z;
+            const auto e = pi.vehicle_state->getInitError();
+            x0[b * 3] = e[0]; x0[b * 3 + 1] = e[1]; x0[b * 3 + 2] = pi.vehicle_state->getStartState().k;
+            gz[b] = pi.vehicle_state->getEndState().z;
             const int kb = po_keep_control_steps(formulation, &rs[b * N], (int)N);  // solver.cpp:22-27 + solver_kp_as_input.cpp:17
             if (kb < 0) return kb;
             if (b == 0) keep = kb;
             else if (kb != keep) return PO_ERR_INVALID;  // one batch = one (N, keep)
         }
+        *keep_out = keep;
         int n, m, C;
         int rc = po_problem_dims(formulation, (int)N, keep, &n, &m, &C);
         if (rc) return rc;
         po_batch_in in{formulation, (int)B, (int)N, keep, rx.data(), ry.data(), rz.data(), rk.data(), rs.data(), bd.data(), x0.data(), gz.data(),
-                       formulation == PO_KPC ? mk.data() : nullptr, formulation == PO_KPC ? mkp.data() : nullptr, nullptr};
+                       formulation == PO_KPC ? mk.data() : nullptr, formulation == PO_KPC ? mkp.data() : nullptr, nullptr, nullptr};
         std::vector<double> states(B * N * 5);
-        info->assign(B, po_info{});
-        po_batch_out out{states.data(), info->data(), nullptr};
+        po_batch_out out{states.data(), info + lo, nullptr};
         rc = po_solve_batch(eng->handle(), &in, &out);
         if (rc) return rc;
-        paths->assign(B, {});
         for (size_t b = 0; b < B; ++b) {
-            auto &p = (*paths)[b];
+            auto &p = (*paths)[lo + b];
+            p.clear();
             p.reserve(N);
             for (size_t i = 0; i < N; ++i) {
                 const double *s = &states[(b * N + i) * 5];

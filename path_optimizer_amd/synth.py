@@ -60,7 +60,7 @@ CONFIGS = {
 }
 
 
-def _one_path(config_id: int, path_id: int, N: int, kind: str, form: int):
+def _one_path(config_id: int, path_id: int, N: int, kind: str, form: int, DS: float = DS):
     rng = np.random.default_rng(np.random.SeedSequence([SEED0, config_id, path_id]))
     a1 = rng.uniform(0.0, 0.06)
     a2 = rng.uniform(0.0, 0.03)
@@ -116,9 +116,23 @@ def _one_path(config_id: int, path_id: int, N: int, kind: str, form: int):
     return x, y, z, k, s, bounds, x0, z[-1] + dgoal, max_k, max_kp
 
 
+def keep_control_steps(form: int, ref_s: np.ndarray) -> int:
+    """keep_control_steps_ exactly as the reference computes it (solver.cpp:19,22-27; solver_kp_as_input.cpp:17: truncating cast)."""
+    if form == PO_KPC:
+        return 4
+    if form == PO_K:
+        return 1
+    interval = 0.0
+    for i in range(1, min(len(ref_s), 10)):
+        interval = max(interval, float(ref_s[i]) - float(ref_s[i - 1]))
+    return max(int(1.2 / interval), 1)
+
+
 def make_batch(config_id: int, B: int | None = None, first_path: int = 0, N: int | None = None,
-               formulation: int | None = None) -> Batch:
-    """Batch of `B` paths of BASELINE config `config_id`, path ids first_path..first_path+B-1."""
+               formulation: int | None = None, ds: float = DS) -> Batch:
+    """Batch of `B` paths of BASELINE config `config_id`, path ids first_path..first_path+B-1.
+    ds: arc-length spacing (default 0.25 m as SURVEY.md §8d: keep_control_steps_ = 4).  ds = 0.3 with N = 231 is the shape the reference's
+    own pipeline hands the QP (re-sampled spacing 0.3 m: 1.2 / 0.30000000000000004 truncates to keep = 3, solver_kp_as_input.cpp:17)."""
     form, B0, N0, kind = CONFIGS[config_id]
     if formulation is not None:
         form = formulation
@@ -132,11 +146,11 @@ def make_batch(config_id: int, B: int | None = None, first_path: int = 0, N: int
     mk = np.empty((B, N)) if form == PO_KPC else None
     mkp = np.empty((B, N)) if form == PO_KPC else None
     for b in range(B):
-        x, y, z, k, s, bnd, xi, g, a, c = _one_path(config_id, first_path + b, N, "fixed" if kind == "fixed" else "obstacles", form)
+        x, y, z, k, s, bnd, xi, g, a, c = _one_path(config_id, first_path + b, N, "fixed" if kind == "fixed" else "obstacles", form, ds)
         rx[b], ry[b], rz[b], rk[b], rs[b], bd[b], x0[b], gz[b] = x, y, z, k, s, bnd, xi, g
         if form == PO_KPC:
             mk[b], mkp[b] = a, c
-    keep = 1 if form == PO_K else 4
+    keep = keep_control_steps(form, rs[0]) if B > 0 else 4
     return Batch(form, B, N, keep, rx, ry, rz, rk, rs, bd, x0, gz, mk, mkp)
 
 

@@ -139,7 +139,7 @@ def test_baseline_configs_match_oracle(binding, oracle, cfg, B):
     eng = binding.Engine(0)
     st, info, xs = eng.solve_batch(b, want_x=True)
     ost, oinfo, oxs = oracle.solve_batch(b, oracle.device_equivalent_params())
-    same = _compare_every_path(info, oinfo, xs, oxs, st, ost, 0.9)
+    same = _compare_every_path(info, oinfo, xs, oxs, st, ost, 0.98)
     ey = (xs - oxs)[:, 0:3 * b.N:3]
     rms = np.sqrt((ey ** 2).mean(axis=1))
     assert rms[same].max() < 1e-6 and rms.max() < 1e-4, rms  # bar: <= 1e-4 m lateral-offset RMS vs the oracle at identical settings; measured ~1e-9
@@ -162,7 +162,7 @@ def test_device_matches_literal_ruiz(binding, oracle, form, name):
     po = oracle.default_params(); assert po.scaling == 10
     ost, oinfo, oxs = oracle.solve_batch(b, po)
     assert (info["status"] == 1).all() and np.array_equal(info["status"], oinfo["status"])
-    _compare_every_path(info, oinfo, xs, oxs, st, ost, 0.9)
+    _compare_every_path(info, oinfo, xs, oxs, st, ost, 0.98)
 
 
 @pytest.mark.parametrize("form,name", [(T.PO_KP, "KP"), (T.PO_KPC, "KPC")])
@@ -183,7 +183,7 @@ def test_mixed_uniform_and_general_paths(binding, oracle, form, name):
     st, info, xs = binding.Engine(0).solve_batch(b, want_x=True)
     ost, oinfo, oxs = oracle.solve_batch(b, oracle.device_equivalent_params())
     assert np.array_equal(info["status"], oinfo["status"]), (info["status"], oinfo["status"])
-    same = _compare_every_path(info, oinfo, xs, oxs, st, ost, 0.85)
+    same = _compare_every_path(info, oinfo, xs, oxs, st, ost, 0.98)
     assert same[0::2].sum() >= 7 and same[1::2].sum() >= 6  # both kinds of path are covered by the comparison
 
 
@@ -351,6 +351,31 @@ def test_host_side_cpp_mirror(binding):
         assert "smoothing stages ok" in r.stdout  # TensionSmoother2 / graphSearchDp / postSmooth / buildReferenceFromSpline / updateLimits mirrors
 
 
+def test_host_side_cpp_multi_device_solve_batch(binding):
+    """OsqpSolver::solveBatch over several engines (SURVEY.md §8e: contiguous shards, one host thread + handle + stream per device, results in place) returns
+    states and po_info bit-identical to the one-engine call: G = hipGetDeviceCount() engines (1 on a single-GPU box, 8 on a full node), and — so that the split,
+    the threads and the in-place writes run on a single-GPU box too — 1 / 3 / 5 engines on device 0 with a batch that does not divide evenly."""
+    import os
+    import re
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "path_optimizer_amd", "host")], stdout=subprocess.DEVNULL)
+    exe = os.path.join(root, "path_optimizer_amd", "host", "host_test")
+    for form, nb, shards in (("KP", "13", None), ("KP", "13", "3"), ("KPC", "7", "5"), ("K", "4", "8"), ("KP", "2", "1")):
+        env = dict(os.environ)
+        env.pop("PO_HOST_TEST_SHARDS", None)
+        if shards:
+            env["PO_HOST_TEST_SHARDS"] = shards
+        r = subprocess.run([exe, form, "60", nb], capture_output=True, text=True, env=env)
+        m = re.search(r"multi-device rc=(-?\d+) engines=(\d+) \(visible devices (\d+)\) bit_identical=(\d)", r.stdout)
+        assert m, r.stdout + r.stderr
+        assert m.group(1) == "0" and m.group(4) == "1", r.stdout
+        assert int(m.group(2)) == max(int(m.group(3)), int(shards or 0)), r.stdout
+        assert r.stdout.count("device shard") == int(m.group(2))
+        assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_deterministic_and_device_pointer_entry(binding):
     """Same inputs twice -> bit-identical outputs; the device-pointer entry (inputs resident in HBM, caller's stream)
     returns exactly what the host-pointer entry returns."""
@@ -467,14 +492,21 @@ def test_order_hint_changes_scheduling_only(binding):
     assert np.array_equal(x2, x3) and np.array_equal(info2["status_polish"], info3["status_polish"])
 
 
-def test_stage_split_two_wave_mapping_matches_oracle():
-    """The experimental stage-split mapping of the keep-4 kernel (PO_SPLIT=1: chunk stages 0-1 on wave A, 2-3 + the control on wave B, two waves per SIMD;
+def test_stage_split_two_wave_mapping_matches_oracle(binding):
+    """The experimental stage-split mapping of the keep-4 kernel (`make SPLIT=1` builds only; po_debug_set "split" / PO_SPLIT=1 through the binding: chunk stages 0-1 on wave A, 2-3 + the control on wave B, two waves per SIMD;
     csrc/po_fast.inc Fast<..., NW = 2>) computes the same iteration: same counts as the oracle, same solution, for path lengths on every residue of the chunk
     structure (N - 1 = 1 mod 4 is handed to the one-wave general kernel), one and several DPP rows of chunks, and fewer chunks than a hand-off slot has words."""
     import os
     import subprocess
     import sys
 
+    probe = binding.Engine(0)
+    try:
+        probe.debug_set("split", 1)
+    except binding.PoError:
+        pytest.skip("libpo_hip.so was built without `make SPLIT=1` (the experimental mapping is not part of the default build)")
+    finally:
+        probe.close()
     code = r"""
 import sys, numpy as np
 sys.path.insert(0, '.')

@@ -69,7 +69,7 @@ def test_device_polish_matches_oracle_and_optimum(oracle, passes):
     assert np.array_equal(xs[~ok], xs0[~ok]) and np.array_equal(st[~ok], st0[~ok])  # rejected: the ADMM solution, untouched
     same_admm = info["iters"] == oinfo["iters"]
     both = ok & ook & same_admm
-    assert (ok == ook)[same_admm].mean() >= 0.9, (ok.sum(), ook.sum())
+    assert np.array_equal(ok[same_admm], ook[same_admm]), (ok.sum(), ook.sum(), np.where((ok != ook) & same_admm)[0])  # adopt / reject: the same decision on every path whose ADMM run agrees
     assert both.sum() >= 0.6 * b.B
     # condensed block LDL' (device) vs full quasi-definite LDL' (oracle): same polished point
     assert np.abs(xs[both] - oxs[both]).max() < 1e-6, np.abs(xs[both] - oxs[both]).max()
@@ -94,7 +94,7 @@ def test_device_polish_other_formulations(oracle, form, cfg, B):
     ost, oinfo, oxs = oracle.solve_batch(b, po)
     ok, ook = info["status_polish"] == 1, oinfo["status_polish"] == 1
     same = info["iters"] == oinfo["iters"]
-    assert ok.mean() >= 0.5 and (ok == ook)[same].mean() >= 0.85
+    assert ok.mean() >= 0.5 and np.array_equal(ok[same], ook[same]), np.where((ok != ook) & same)[0]
     both = ok & ook & same
     assert np.abs(xs[both] - oxs[both]).max() < 1e-6
     assert (info["r_prim"][ok] < 1e-7).all()
@@ -120,6 +120,6 @@ def test_device_polish_on_ragged_batches_and_other_keep_values(oracle):
         assert np.array_equal(info["status"], oinfo["status"])
         same = (info["iters"] == oinfo["iters"]) & (info["status"] == 1)
         ok, ook = info["status_polish"] == 1, oinfo["status_polish"] == 1
-        assert (ok == ook)[same].mean() >= 0.8, (keep, ok, ook)
+        assert np.array_equal(ok[same], ook[same]), (keep, ok, ook)
         both = ok & ook & same
         assert both.sum() >= 3 and np.abs(xs[both] - oxs[both]).max() < 1e-6 and np.abs(st[both] - ost[both]).max() < 1e-6, keep

@@ -337,3 +337,71 @@ def test_device_probe_then_longest_first_is_bit_identical(form, cfg, B, probe_it
         p.probe_iters = 0
         st2, i2, _ = binding.Engine(0, p).solve_batch(b)
         assert np.array_equal(st2, st3) and np.array_equal(i2["status_polish"], i3["status_polish"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form,cfg,B,rounds,kw", [(0, 3, 256, 3, {}), (0, 3, 96, 2, {}), (0, 3, 33, 4, {}), (0, 3, 1, 3, {}), (1, 5, 8, 3, {}), (2, 3, 16, 3, {}),
+                                                  (0, 3, 64, 3, {"N": 231, "ds": 0.3})])
+def test_device_chained_rounds_are_bit_identical_to_one_launch_per_round(form, cfg, B, rounds, kw):
+    """po_params.refine_chain (default 1): all refinement rounds inside ONE launch pair — a workgroup that does not certify its path pushes it onto a
+    device-side queue and a follow-up workgroup of the same launch resumes it (csrc/po_fast.inc: rq_wait / rq_push).  Scheduling only: every output — raw
+    solution, states, every po_info field — is bit-identical to the version with one launch pair per round, also with a caller-supplied order and on a
+    ragged batch with paths the uniform-variant launch defers to the general one."""
+    from path_optimizer_amd import binding
+
+    b = synth.make_batch(cfg, B=B, formulation=form, **kw)
+    if form == 0 and B >= 33:  # ragged + some paths with non-uniform row classes (free rows on a few stages): both launches of the pair have work
+        b.n_points = np.full(B, b.N, dtype=np.int32); b.n_points[1::5] = b.N - 7; b.n_points[2::7] = b.N // 2
+        b.bounds[3::4, 30:45, 0, :] = (-1e30, 1e30)
+    res = {}
+    for chain in (0, 1):
+        p = binding.default_params()
+        assert p.refine_chain == 1
+        p.refine, p.refine_rounds, p.refine_chain = 1, rounds, chain
+        eng = binding.Engine(0, p)
+        res[chain] = eng.solve_batch(b, want_x=True)
+        if chain == 1 and B > 2:
+            order = np.random.default_rng(B).permutation(B)
+            res["order"] = eng.solve_batch(b, want_x=True, order=order)
+            res["again"] = eng.solve_batch(b, want_x=True)  # the queue is re-initialised by every call
+        eng.close()
+    st0, i0, x0 = res[0]
+    assert (i0["status"] == 1).all() and set(np.unique(i0["status_refine"])) <= {1, -1}
+    for key in [k for k in res if k != 0]:
+        st1, i1, x1 = res[key]
+        assert i0.tobytes() == i1.tobytes(), (key, np.where(i0["iters"] != i1["iters"])[0])
+        assert np.array_equal(x0, x1) and np.array_equal(st0, st1), key
+
+
+@pytest.mark.gpu
+def test_device_status_refine_says_what_was_certified(oracle):
+    """po_info.status_refine: 0 without the refinement, 1 exactly on the paths whose returned point satisfies OSQP's test at refine_eps (as the phase evaluated it),
+    -1 on the others; same flags as the oracle wherever the two ran the same number of iterations; non-finite / infeasible paths never carry a 1."""
+    from path_optimizer_amd import binding
+
+    b = synth.make_batch(3, B=128)
+    st, info, xs = binding.Engine(0).solve_batch(b, want_x=True)
+    assert (info["status_refine"] == 0).all() and (info["reserved"] == 0).all()
+    for kw in (dict(refine=1), dict(refine=1, refine_rounds=3), dict(refine=1, refine_max_iter=20)):
+        p = binding.default_params()
+        for k, v in kw.items():
+            setattr(p, k, v)
+        st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
+        ost, oinfo, oxs = oracle.solve_batch(b, oracle.device_equivalent_params(p))
+        assert set(np.unique(info["status_refine"])) <= {1, -1} and (info["status"] == 1).all()
+        cert = info["status_refine"] == 1
+        # certified <=> the residuals the phase left satisfy refine_eps (1e-6) relative criteria: in particular both are below 1e-6 (1 + norm) ~ 1e-5 ...
+        assert (info["r_prim"][cert] < 1e-5).all() and (info["r_dual"][cert] < 1e-5).all()
+        # ... and a path whose residuals are still at the solve's level is never flagged certified
+        assert not (cert & ((info["r_prim"] > 1e-5) | (info["r_dual"] > 1e-5))).any()
+        same = info["iters"] == oinfo["iters"]
+        assert same.mean() >= 0.7 and np.array_equal(info["status_refine"][same], oinfo["status_refine"][same])
+        if "refine_max_iter" in kw:
+            assert (info["status_refine"] == -1).any()  # a 20-iteration budget leaves paths uncertified: that is what the flag is for
+    bad = synth.make_batch(3, B=4)
+    bad.bounds[1, 50, 2, 0] = np.nan
+    p = binding.default_params(); p.refine, p.refine_rounds = 1, 3
+    st, info, xs = binding.Engine(0, p).solve_batch(bad, want_x=True)
+    assert info["status"][1] == binding.PO_STATUS_NON_FINITE if hasattr(binding, "PO_STATUS_NON_FINITE") else info["status"][1] == -8
+    assert info["status_refine"][1] == 0 and (st[1] == 0).all() and (xs[1] == 0).all()  # defined outputs (zeros), never the buffer's previous content
+    assert (info["status"][[0, 2, 3]] == 1).all()

@@ -15,6 +15,7 @@ import scipy.sparse as sp
 import scipy.sparse.linalg as spl
 
 from path_optimizer_amd import synth
+from path_optimizer_amd.abi import INFO_BYTES
 from path_optimizer_amd.abi import PO_ERR_INVALID, PO_ERR_UNSUPPORTED, PO_STATUS_PRIMAL_INFEASIBLE, PO_STATUS_SOLVED
 
 HAVE_REF = os.path.isdir("/root/reference")
@@ -292,7 +293,7 @@ def test_device_pointer_entry_large_batch_and_determinism(engine):
     outs = []
     for _ in range(2):
         out = dict(x=torch.zeros((B, 100), dtype=torch.float64, device="cuda"), y=torch.zeros((B, 100), dtype=torch.float64, device="cuda"),
-                   s=torch.zeros((B, 100), dtype=torch.float64, device="cuda"), info=torch.zeros((B, 48), dtype=torch.uint8, device="cuda"))
+                   s=torch.zeros((B, 100), dtype=torch.float64, device="cuda"), info=torch.zeros((B, INFO_BYTES), dtype=torch.uint8, device="cuda"))
         engine.smooth_batch_device(kind, t, out)
         torch.cuda.synchronize()
         outs.append(out)
@@ -303,21 +304,21 @@ def test_device_pointer_entry_large_batch_and_determinism(engine):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,P", [(0, 100), (0, 250), (1, 100), (2, 60), (2, 100), (2, 250)])
-def test_device_waves_per_qp_agree(engine, oracle, omap, kind, P, monkeypatch):
-    """One, four and eight waves per QP (the launcher picks by LDS footprint and batch size; PO_SMOOTH_WAVES forces one) and both LDS layouts of the
+def test_device_waves_per_qp_agree(engine, oracle, omap, kind, P):
+    """One, four and eight waves per QP (the launcher picks by LDS footprint and batch size; po_debug_set "smooth_waves" forces one) and both LDS layouts of the
     partitioned substitution give the same iterates bit for bit; the one-wave result is checked against the oracle."""
     inp = synth.make_smooth_inputs(31, 12, P=P, kind=kind, ragged=True, jitter_ds=True)
     inp["n_points"][0] = P
     res = {}
-    for tag, env in (("1", {"PO_SMOOTH_WAVES": "1"}), ("4", {"PO_SMOOTH_WAVES": "4"}), ("8", {"PO_SMOOTH_WAVES": "8"}), ("auto", {}),
-                     ("natural", {"PO_SMOOTH_WAVES": "1", "PO_SMOOTH_NOPAD": "1"}), ("single-lane", {"PO_SMOOTH_WAVES": "4", "PO_SMOOTH_SEQ": "1"})):
-        for k in ("PO_SMOOTH_WAVES", "PO_SMOOTH_NOPAD", "PO_SMOOTH_SEQ"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        res[tag] = engine.smooth_batch(kind, inp, want_raw=True)
-    for k in ("PO_SMOOTH_WAVES", "PO_SMOOTH_NOPAD", "PO_SMOOTH_SEQ"):
-        monkeypatch.delenv(k, raising=False)
+    try:
+        for tag, sw in (("1", {"smooth_waves": 1}), ("4", {"smooth_waves": 4}), ("8", {"smooth_waves": 8}), ("auto", {}),
+                        ("natural", {"smooth_waves": 1, "smooth_nopad": 1}), ("single-lane", {"smooth_waves": 4, "smooth_seq": 1})):
+            for k in ("smooth_waves", "smooth_nopad", "smooth_seq"):
+                engine.debug_set(k, sw.get(k, 0))
+            res[tag] = engine.smooth_batch(kind, inp, want_raw=True)
+    finally:
+        for k in ("smooth_waves", "smooth_nopad", "smooth_seq"):
+            engine.debug_set(k, 0)
     ref = res["1"]
     for tag in ("4", "8", "auto"):
         assert np.array_equal(res[tag][4], ref[4]), tag

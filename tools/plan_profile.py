@@ -7,6 +7,7 @@ import torch
 
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from path_optimizer_amd import binding, synth  # noqa: E402
+from path_optimizer_amd.abi import INFO_BYTES
 from path_optimizer_amd.abi import INFO_DTYPE  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
@@ -24,7 +25,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "periodic":
 tp = {k: torch.from_numpy(np.ascontiguousarray(scn[k][perm])).cuda() for k in ("way_x", "way_y", "start", "goal")}
 Np = 320
 out = dict(states=torch.zeros((B, Np, 5), dtype=torch.float64, device="cuda"), n_states=torch.zeros(B, dtype=torch.int32, device="cuda"),
-           ok=torch.zeros(B, dtype=torch.int32, device="cuda"), stage=torch.zeros(B, dtype=torch.int32, device="cuda"), info=torch.zeros((B, 48), dtype=torch.uint8, device="cuda"))
+           ok=torch.zeros(B, dtype=torch.int32, device="cuda"), stage=torch.zeros(B, dtype=torch.int32, device="cuda"), info=torch.zeros((B, INFO_BYTES), dtype=torch.uint8, device="cuda"))
 way_len = float(np.hypot(np.diff(scn["way_x"], axis=1), np.diff(scn["way_y"], axis=1)).sum(axis=1).max())
 eng.plan_batch_device(tp, out, Np, way_len); torch.cuda.synchronize()
 t0 = time.perf_counter()

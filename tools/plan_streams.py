@@ -10,6 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from path_optimizer_amd import binding, synth  # noqa: E402
+from path_optimizer_amd.abi import INFO_BYTES
 
 B = 4096
 scn = synth.make_planning_scenes(2, 64)
@@ -23,7 +24,7 @@ for T in (1, 2, 3, 4):
     for _ in range(T):
         e = binding.Engine(0); e.set_map(*scn["map"]); engs.append(e)
         outs.append(dict(states=torch.zeros((B, Np, 5), dtype=torch.float64, device="cuda"), n_states=torch.zeros(B, dtype=torch.int32, device="cuda"),
-                         ok=torch.zeros(B, dtype=torch.int32, device="cuda"), stage=torch.zeros(B, dtype=torch.int32, device="cuda"), info=torch.zeros((B, 48), dtype=torch.uint8, device="cuda")))
+                         ok=torch.zeros(B, dtype=torch.int32, device="cuda"), stage=torch.zeros(B, dtype=torch.int32, device="cuda"), info=torch.zeros((B, INFO_BYTES), dtype=torch.uint8, device="cuda")))
         e.plan_batch_device(tp, outs[-1], Np, way_len)
     torch.cuda.synchronize()
     K = 3  # batches per thread

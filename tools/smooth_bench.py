@@ -7,6 +7,7 @@ import torch
 
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from path_optimizer_amd import binding, synth  # noqa: E402
+from path_optimizer_amd.abi import INFO_BYTES
 from path_optimizer_amd.abi import INFO_DTYPE  # noqa: E402
 
 B = 4096
@@ -19,7 +20,7 @@ for eps in (1e-3, 1e-4):
         rep = {k: (None if v is None else np.concatenate([v] * (B // 256))) for k, v in inp.items()}
         t = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in rep.items() if v is not None}
         out = dict(x=torch.zeros((B, P), dtype=torch.float64, device="cuda"), y=torch.zeros((B, P), dtype=torch.float64, device="cuda"),
-                   s=torch.zeros((B, P), dtype=torch.float64, device="cuda"), info=torch.zeros((B, 48), dtype=torch.uint8, device="cuda"))
+                   s=torch.zeros((B, P), dtype=torch.float64, device="cuda"), info=torch.zeros((B, INFO_BYTES), dtype=torch.uint8, device="cuda"))
         eng.smooth_batch_device(kind, t, out); torch.cuda.synchronize()
         t0 = time.time()
         for _ in range(3):

@@ -4,6 +4,7 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from path_optimizer_amd import binding, synth  # noqa: E402
+from path_optimizer_amd.abi import INFO_BYTES
 from path_optimizer_amd.abi import INFO_DTYPE  # noqa: E402
 
 p = binding.default_params(); p.eps_abs = p.eps_rel = 1e-3
@@ -18,7 +19,7 @@ for kind, P in ((1, 100), (1, 250)) if os.environ.get("KIND1") else ((0, 100), (
         for one in ("1", "4", "8", "0", "n1", "n4"):
             os.environ["PO_SMOOTH_WAVES"] = one.lstrip("n"); os.environ["PO_SMOOTH_NOPAD"] = "1" if one[0] == "n" else "0"
             out = dict(x=torch.zeros((B, P), dtype=torch.float64, device="cuda"), y=torch.zeros((B, P), dtype=torch.float64, device="cuda"),
-                       s=torch.zeros((B, P), dtype=torch.float64, device="cuda"), info=torch.zeros((B, 48), dtype=torch.uint8, device="cuda"))
+                       s=torch.zeros((B, P), dtype=torch.float64, device="cuda"), info=torch.zeros((B, INFO_BYTES), dtype=torch.uint8, device="cuda"))
             eng.smooth_batch_device(kind, t, out); torch.cuda.synchronize()
             t0 = time.time()
             for _ in range(5): eng.smooth_batch_device(kind, t, out)
