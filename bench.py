@@ -11,8 +11,12 @@ synthetic planning instances already resident in HBM:
   N>1   BASELINE config 4: the same generator, 4096 paths per GPU (contiguous shard of path ids), no data-path collective
         (paths are independent); RCCL carries the barrier, the reduction of a few statistics and (--gather) the result gather.
 `value` is what SURVEY.md §8d prescribes: K single-batch solves issued one after the other on ONE stream, timed between two
-barriers (max over ranks); `single_batch` holds the per-step hipEvent figures (median of K).  The throughput of independent batches
-overlapped on 3 handles/streams is reported beside it as `pipelined_3_streams`, never as `value`.
+barriers (max over ranks), at the HEADLINE setting — the fastest setting at which EVERY path of the batch is within 1e-4 m (lateral-offset
+RMS) of its exact optimum AND satisfies OSQP's termination test at eps 1e-4 (`config.accuracy` carries the count, measured
+in the run against tests/golden/tight_full_c3.npz).  The OSQP-faithful default (no extension) is timed beside it as `osqp_default`.
+`single_batch` holds the per-step hipEvent figures (median of K).  Everything bulky (other configs, stage legs, the table of settings) goes
+to the details file (--details, default bench_details.json next to this script when writable); the printed line stays short enough for
+the driver's record.
 Rank 0 prints ONE JSON line.  `roofline` is the fp64 VALU issue roof (the solver state is LDS/register resident: HBM is not the
 binding resource); SURVEY §8d's algorithmic-bytes contract figure is kept as `roofline.algorithmic_hbm_equivalent`.
 `parity` is computed in the run: device vs the CPU oracle at identical settings on the CPU-baseline sample, and the lateral-offset
@@ -143,84 +147,93 @@ def config_legs(torch, binding, synth, dev, stream, steps=3):
             eng.close()
         out["c1_real_scene"] = {"workload": "the reference's benchmark scene: obstacles_for_benchmark.png (495 x 497 cells at 0.2 m), 100 way points, PathOptimizer::solve "
                                             "(bSpline -> TENSION2 QP -> DP search -> post QP -> re-sampling -> bounds -> KP QP, 132 states -> collision check), B = 1, "
-                                            "host pointers in and out (po_plan_batch)", **rows,
-                                "reference_note": "the reference-compiled PathOptimizer (test build, -O0, OSQP stood in by the oracle's ADMM) takes ~44 ms for the same call"}
+                                            "host pointers in and out (po_plan_batch)", **rows}
     return out
 
 
-def accuracy_legs(torch, binding, synth, batch, dev, stream, cpu_sample):
-    """Device side of the `parity` block: (a) the first `cpu_sample` paths solved with the raw QP solution kept (compared with the oracle
-    after the GPU legs), (b) lateral-offset RMS against the exact optimum of the first 256 paths (tests/golden/tight_c3.npz) at the
-    benchmarked setting, with the opt-in polish step, and at tighter eps; each setting timed as single-batch launches of the full batch."""
-    from path_optimizer_amd.abi import PoParams
+HEADLINE = {"label": "eps 1e-4 + refine (3 rounds + 2 below eps, chained in one launch pair; refine_eps 1e-7)",
+            "params": dict(refine=1, refine_rounds=3, refine_extra_rounds=2)}
+OSQP_DEFAULT = {"label": "eps 1e-4, OSQP defaults only (no extension)", "params": {}}
 
-    gold = None
-    gpath = os.path.join(ROOT, "tests", "golden", "tight_c3.npz")
-    if batch.formulation == 0 and batch.N == 200 and os.path.exists(gpath):
-        gold = np.load(gpath)["e_y"]
-    ns = max(min(cpu_sample, batch.B), min(256, batch.B))
-    sample = batch.slice(0, ns)
-    sdb = binding.DeviceBatch(sample, device=dev, want_x=True)
-    full = binding.DeviceBatch(batch, device=dev)
-    N = batch.N
-    res = {"x_sample": None, "info_sample": None, "settings": []}
 
-    def run(label, mutate):
-        p = binding.default_params()
-        mutate(p)
-        eng = binding.Engine(torch.cuda.current_device(), p)
-        eng.set_stream(stream.cuda_stream)
-        eng.solve_batch_device(sdb)
-        torch.cuda.synchronize()
-        x = sdb.out_x.cpu().numpy().copy()
-        info = sdb.info_numpy().copy()
-        eng.solve_batch_device(full)
-        torch.cuda.synchronize()
-        _, ms = time_serial(torch, eng, stream, full, 3, torch.cuda.synchronize)
-        finfo = full.info_numpy()
-        row = {"setting": label, "ms": float(np.median(ms)), "paths_per_s": batch.B / (float(np.median(ms)) * 1e-3),
-               "iters_mean": float(finfo["iters"].mean()), "iters_max": int(finfo["iters"].max()), "unsolved": int((finfo["status"] != 1).sum())}
-        row["polished"] = int((finfo["status_polish"] == 1).sum())
-        row["polish_unsuccessful"] = int((finfo["status_polish"] == -1).sum())
+def make_params(binding, kw):
+    p = binding.default_params()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def e_y_of(form, N, x):
+    return x[:, 1:2 * N:2] if form == 2 else x[:, 0:3 * N:3]  # K orders the state pair (e_phi, e_y)
+
+
+def gold_for(batch, first_path=0):
+    """Exact optima (tests/golden/tight_full_*.npz, generator make_tight_full.py) of the paths of `batch` when they are a prefix of a golden set, else None."""
+    name = None
+    if batch.formulation == 0 and batch.N == 200 and batch.keep == 4:
+        name = "c3"
+    elif batch.formulation == 0 and batch.N == 120:
+        name = "c2"
+    elif batch.formulation == 1 and batch.N == 400:
+        name = "c5"
+    elif batch.formulation == 2 and batch.N == 200:
+        name = "k"
+    elif batch.formulation == 0 and batch.N == 231 and batch.keep == 3:
+        name = "keep3"
+    path = None if name is None else os.path.join(ROOT, "tests", "golden", f"tight_full_{name}.npz")
+    if path is None or not os.path.exists(path) or first_path != 0:
+        return None, None
+    return np.load(path)["e_y"].astype(np.float64), name
+
+
+def accuracy_of(x, info, batch, gold):
+    """Per-path lateral-offset RMS against the exact optimum: the accuracy clause of the metric (<= 1e-4 m per path), as counts."""
+    ng = min(len(gold), len(x))
+    rms = np.sqrt(np.mean((e_y_of(batch.formulation, batch.N, x[:ng]) - gold[:ng]) ** 2, axis=1))
+    sr = info["status_refine"][:ng]
+    return {"paths": int(ng), "n_gt_1e-4_m": int((rms > 1e-4).sum()), "max_m": float(rms.max()), "p99_m": float(np.percentile(rms, 99)), "median_m": float(np.median(rms)),
+            "certified_at_refine_eps": int((sr == 1).sum()), "not_certified": int((sr == -1).sum()), "max_m_certified": float(rms[sr == 1].max()) if (sr == 1).any() else None}
+
+
+def run_setting(torch, binding, stream, db_x, kw, steps=3):
+    """One setting on a batch resident in HBM (db_x keeps the raw QP solution): warm-up, `steps` timed single-batch solves, outputs of the last one."""
+    eng = binding.Engine(torch.cuda.current_device(), make_params(binding, kw))
+    eng.set_stream(stream.cuda_stream)
+    eng.solve_batch_device(db_x)
+    torch.cuda.synchronize()
+    _, ms = time_serial(torch, eng, stream, db_x, steps, torch.cuda.synchronize)
+    info = db_x.info_numpy().copy()
+    x = db_x.out_x.cpu().numpy()
+    eng.close()
+    med = float(np.median(ms))
+    row = {"ms": med, "paths_per_s": db_x.B / (med * 1e-3), "iters_mean": float(info["iters"].mean()), "iters_max": int(info["iters"].max()),
+           "unsolved": int((info["status"] != 1).sum()), "path_iters_per_s": float(info["iters"].sum()) / (med * 1e-3)}
+    return row, x, info
+
+
+def settings_table(torch, binding, batch, dev, stream, gold):
+    """The table of settings on the full batch (details file): time, iterations and the accuracy counts of each."""
+    db = binding.DeviceBatch(batch, device=dev, want_x=True)
+    rows = []
+    for label, kw in (("eps 1e-4 (OSQP defaults only)", {}),
+                      ("eps 1e-4 + polish (OSQP: 1 pass)", dict(polish=1)),
+                      ("eps 1e-4 + polish (active-set passes <= 6)", dict(polish=1, polish_passes=6)),
+                      ("eps 1e-4 + refine (1 round)", dict(refine=1)),
+                      ("eps 1e-4 + refine, 3 rounds, one launch pair per round", dict(refine=1, refine_rounds=3, refine_chain=0)),
+                      ("eps 1e-4 + refine, 3 rounds, chained", dict(refine=1, refine_rounds=3)),
+                      ("eps 1e-4 + refine, 3 rounds + 2 below eps, one launch pair per round", dict(refine=1, refine_rounds=3, refine_extra_rounds=2, refine_chain=0)),
+                      (HEADLINE["label"], HEADLINE["params"]),
+                      ("eps 1e-4 + refine, 3 + 2 rounds, refine_adapt off", dict(refine=1, refine_rounds=3, refine_extra_rounds=2, refine_adapt=0)),
+                      ("eps 1e-4 + refine, 3 + 2 rounds, refine_eps 1e-6", dict(refine=1, refine_rounds=3, refine_extra_rounds=2, refine_eps=1e-6)),
+                      ("eps 1e-3 (OSQP's own default, what the reference runs) + refine 3 + 3 rounds", dict(refine=1, refine_rounds=3, refine_extra_rounds=3, eps_abs=1e-3, eps_rel=1e-3)),
+                      ("eps 1e-5, max_iter 20000", dict(eps_abs=1e-5, eps_rel=1e-5, max_iter=20000)),
+                      ("eps 1e-6, max_iter 20000", dict(eps_abs=1e-6, eps_rel=1e-6, max_iter=20000))):
+        row, x, info = run_setting(torch, binding, stream, db, kw)
+        row = {"setting": label, **row}
         if gold is not None:
-            ng = min(len(gold), ns)
-            rms = np.sqrt(np.mean((x[:ng, 0:3 * N:3] - gold[:ng]) ** 2, axis=1))
-            row["e_y_rms_vs_exact_optimum_m"] = {"paths": int(ng), "median": float(np.median(rms)), "p95": float(np.percentile(rms, 95)), "max": float(rms.max()),
-                                                 "frac_le_1e-4": float((rms <= 1e-4).mean())}
-        eng.close()
-        return row, x, info
-
-    row, x, info = run("eps 1e-4 (benchmarked)", lambda p: None)
-    res["settings"].append(row)
-    res["x_sample"], res["info_sample"], res["sample"] = x, info, sample
-    has_polish = any(f[0] == "polish" for f in PoParams._fields_)
-    if has_polish:
-        def pol(p, passes):
-            p.polish = 1
-            p.polish_passes = passes
-        res["settings"].append(run("eps 1e-4 + polish (OSQP: 1 pass)", lambda p: pol(p, 1))[0])
-        res["settings"].append(run("eps 1e-4 + polish (active-set passes <= 6)", lambda p: pol(p, 6))[0])
-    if any(f[0] == "refine" for f in PoParams._fields_):  # activity-weighted continuation of the ADMM iteration (po_params.refine), alone and before the polish
-        def ref(p, eps, passes):
-            p.eps_abs = p.eps_rel = eps
-            p.refine = 1
-            if passes:
-                p.polish, p.polish_passes = 1, passes
-        res["settings"].append(run("eps 1e-4 + refine", lambda p: ref(p, 1e-4, 0))[0])
-        res["settings"].append(run("eps 1e-4 + refine + polish (<= 6 passes)", lambda p: ref(p, 1e-4, 6))[0])
-        res["settings"].append(run("eps 2e-4 + refine", lambda p: ref(p, 2e-4, 0))[0])
-        res["settings"].append(run("eps 3e-4 + refine", lambda p: ref(p, 3e-4, 0))[0])
-        res["settings"].append(run("eps 3e-4 + refine + polish (<= 6 passes)", lambda p: ref(p, 3e-4, 6))[0])
-        res["settings"].append(run("eps 1e-3 (OSQP's default) + refine", lambda p: ref(p, 1e-3, 0))[0])
-    for eps in (1e-5, 1e-6, 1e-7):
-        def tight(p, eps=eps):
-            p.eps_abs = p.eps_rel = eps
-            p.max_iter = 20000
-            if has_polish:
-                p.polish = 1
-                p.polish_passes = 6
-        res["settings"].append(run(f"eps {eps:g}" + (" + polish (<= 6 passes)" if has_polish else "") + ", max_iter 20000", tight)[0])
-    return res
+            row["e_y_rms_vs_exact_optimum"] = accuracy_of(x, info, batch, gold)
+        rows.append(row)
+    return rows
 
 
 def stage_legs_gpu(torch, binding, synth, eng, stream, dbatch, B):
@@ -377,9 +390,9 @@ def stage_legs_cpu(st, ctx):
 
 
 def live_traffic(batch_paths, timeout_s=150):
-    """HBM traffic (and the VALU instruction count) of the solve kernel measured IN THIS RUN: three rocprofv3 PMC child passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU — separate passes, counters only, as
-    MI355X_MICROARCH.md prescribes) over `bench.py --traffic-child` (3 solves of the same batch).  Returns None when rocprofv3 is missing, fails or times out
-    (the bench line then falls back to the committed profiles/traffic_latest.json)."""
+    """HBM traffic, VALU instruction count and fp64 flop of the solve kernel measured IN THIS RUN: rocprofv3 PMC child passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU,
+    then the four SQ_INSTS_VALU_*_F64 counters — separate passes, counters only, as MI355X_MICROARCH.md prescribes) over `bench.py --traffic-child` (3 solves of the
+    same batch at the headline setting).  Returns None when rocprofv3 is missing, fails or times out (the bench line then keeps the committed fallback values)."""
     import csv
     import glob
     import shutil
@@ -390,24 +403,41 @@ def live_traffic(batch_paths, timeout_s=150):
     if not exe:
         return None
     vals = {}
+
+    def one_pass(ctrs):
+        d = tempfile.mkdtemp(prefix="po_pmc_", dir="/tmp")
+        cmd = [exe, "--output-format", "csv", "--pmc", *ctrs, "-d", d, "-o", "t", "--", sys.executable, os.path.abspath(__file__), "--traffic-child", "--batch", str(batch_paths)]
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+        tot, disp = {c: 0.0 for c in ctrs}, set()
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                # the uniform-row-class solve kernel of BASELINE config 3 (KP, 4 stages per lane, one wave), with or without the refinement phase
+                if "solve_kernel_fast<0, 4, 64, true, true" in row.get("Kernel_Name", "") and row.get("Counter_Name") in tot:
+                    tot[row["Counter_Name"]] += float(row["Counter_Value"]); disp.add(row["Dispatch_Id"])
+        shutil.rmtree(d, ignore_errors=True)
+        if r.returncode != 0 or not disp:
+            return None
+        return {c: v / len(disp) for c, v in tot.items()}
+
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
-            d = tempfile.mkdtemp(prefix="po_pmc_", dir="/tmp")
-            cmd = [exe, "--output-format", "csv", "--pmc", ctr, "-d", d, "-o", "t", "--", sys.executable, os.path.abspath(__file__), "--traffic-child", "--batch", str(batch_paths)]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
-            tot, disp = 0.0, set()
-            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    if "solve_kernel_fast<0, 4, 64, true, true" in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
-                        tot += float(row["Counter_Value"]); disp.add(row["Dispatch_Id"])
-            shutil.rmtree(d, ignore_errors=True)
-            if r.returncode != 0 or not disp:
+            got = one_pass([ctr])
+            if got is None:
                 return None
-            vals[ctr] = tot / len(disp) * (1.0 if ctr.startswith("SQ_") else 1024.0)  # FETCH / WRITE in KB units
-        return {"hbm_bytes_per_launch": 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "fetch_bytes_raw": vals["FETCH_SIZE"], "write_bytes": vals["WRITE_SIZE"],
-                "valu_wave_instr_per_launch": vals["SQ_INSTS_VALU"],
-                "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM section)",
-                "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes over 3 solves of the same batch"}
+            vals[ctr] = got[ctr] * (1.0 if ctr.startswith("SQ_") else 1024.0)  # FETCH / WRITE in KB units
+        res = {"hbm_bytes_per_launch": 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "fetch_bytes_raw": vals["FETCH_SIZE"], "write_bytes": vals["WRITE_SIZE"],
+               "valu_wave_instr_per_launch": vals["SQ_INSTS_VALU"],
+               "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM section)",
+               "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes over 3 solves of the same batch"}
+        try:
+            f64 = one_pass(["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"])
+        except Exception:
+            f64 = None
+        if f64 is not None and f64["SQ_INSTS_VALU_FMA_F64"] > 0:
+            res["fp64_wave_instr_per_launch"] = sum(f64.values())
+            res["fp64_flop_per_launch"] = 64.0 * (f64["SQ_INSTS_VALU_ADD_F64"] + f64["SQ_INSTS_VALU_MUL_F64"] + 2.0 * f64["SQ_INSTS_VALU_FMA_F64"] + f64["SQ_INSTS_VALU_TRANS_F64"])
+            res["fp64_counters"] = f64
+        return res
     except Exception:
         return None
 
@@ -419,44 +449,66 @@ def _cpu_slice(arg):
     """Worker of the all-cores CPU baseline leg (oracle, test infrastructure)."""
     from oracle import oracle_py
 
-    batch, native = arg
+    batch, native, kw = arg
     if native:
         oracle_py.use_native()
-    oracle_py.solve_batch(batch, oracle_py.device_equivalent_params(), want_x=False)
+    p = oracle_py.device_equivalent_params()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    oracle_py.solve_batch(batch, p, want_x=False)
     return batch.B
 
 
-def cpu_legs(out, batch, acc, cpu_sample):
+def _vs_oracle(dx, dinfo, oxs, oinfo, eps=1e-4):
+    n_ = min(len(dx), len(oxs))
+    dx, dinfo, oxs, oinfo = dx[:n_], dinfo[:n_], oxs[:n_], oinfo[:n_]
+    same = dinfo["iters"] == oinfo["iters"]
+    err = np.abs(dx - oxs).max(axis=1)
+    return {"paths": int(n_), "status_equal": int((dinfo["status"] == oinfo["status"]).sum()), "iteration_count_equal": int(same.sum()),
+            "max_abs_dx_equal_count": float(err[same].max()) if same.any() else None,
+            "max_abs_dx_other": float(err[~same].max()) if (~same).any() else 0.0,
+            "other_within_10_eps": int((err[~same] <= 10 * eps).sum()) if (~same).any() else 0,
+            "status_refine_equal": int((dinfo["status_refine"] == oinfo["status_refine"]).sum())}
+
+
+def cpu_legs(out, details, batch, dev_samples, cpu_sample):
+    """CPU legs (after the GPU legs).  dev_samples: {"headline": (x, info), "osqp_default": (x, info)} = the device's raw solutions of the first paths."""
     from oracle import oracle_py  # CPU baseline / checker legs only
 
     native = oracle_py.use_native()  # gcc -O3 -march=native build of the same source on THIS box (SURVEY §8d); False: portable build
     B = batch.B
     ns = min(cpu_sample, B)
     sample = batch.slice(0, ns)
-    oracle_py.solve_batch(sample.slice(0, 2), oracle_py.device_equivalent_params())  # warm the ordering cache
+    build = "gcc -O3" + (" -march=native, built on this box" if native else ", portable x86-64 build")
+
+    def opar(kw):
+        p = oracle_py.device_equivalent_params()
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+    oracle_py.solve_batch(sample.slice(0, 2), opar({}))  # warm the ordering cache
+    # (i) the SAME setting as `value` (the oracle implements the refinement and its rounds too): the cpu_baseline of the line
     c0 = time.perf_counter()
-    _, oinfo, oxs = oracle_py.solve_batch(sample, oracle_py.device_equivalent_params(), want_x=True)
+    _, hinfo, hxs = oracle_py.solve_batch(sample, opar(HEADLINE["params"]), want_x=True)
     c1 = time.perf_counter()
     out["cpu_baseline"] = {"value": ns / (c1 - c0), "unit": "paths/s", "cores": 1, "kind": "port",
-                           "sample": f"first {ns} paths of the same batch, oracle (OSQP-style ADMM, sparse LDL', gcc -O3"
-                                     f"{' -march=native, built on this box' if native else ', portable x86-64 build'}), {c1 - c0:.1f} s, mean iters {float(oinfo['iters'].mean()):.1f}",
+                           "sample": f"first {ns} paths of the same batch at the same setting as `value`, oracle (OSQP-style ADMM + the same refinement, sparse LDL', {build}), "
+                                     f"{c1 - c0:.1f} s, mean iters {float(hinfo['iters'].mean()):.1f}",
                            "host_cpus": os.cpu_count()}
-    # ---- parity (i): device vs oracle at identical settings on that sample ----
-    if acc is not None and acc.get("x_sample") is not None:
-        n_ = min(ns, len(acc["x_sample"]))
-        dx, dinfo = acc["x_sample"][:n_], acc["info_sample"][:n_]
-        same = dinfo["iters"] == oinfo["iters"][:n_]
-        err = np.abs(dx - oxs[:n_]).max(axis=1)
-        eps = 1e-4
-        par = out.setdefault("parity", {})
-        par["device_vs_oracle"] = {
-            "paths": int(n_), "settings": "identical (OSQP defaults, eps 1e-4, class-level Ruiz, adaptive rho every 100 it)",
-            "status_equal": int((dinfo["status"] == oinfo["status"][:n_]).sum()),
-            "iteration_count_equal": int(same.sum()), "iteration_count_mismatch": int((~same).sum()),
-            "max_abs_dx_same_count": float(err[same].max()) if same.any() else None,
-            "max_abs_dx_mismatching_paths": float(err[~same].max()) if (~same).any() else 0.0,
-            "mismatching_paths_within_10_eps": int((err[~same] <= 10 * eps).sum()) if (~same).any() else 0,
-            "note": "a residual within round-off of eps flips one termination check (25 iterations); those paths are compared at 10 x eps instead of being dropped"}
+    # (ii) the OSQP-faithful default on a quarter of that sample
+    nd = max(1, ns // 4)
+    c0 = time.perf_counter()
+    _, dinfo_o, dxs_o = oracle_py.solve_batch(sample.slice(0, nd), opar({}), want_x=True)
+    c1 = time.perf_counter()
+    out["osqp_default"]["cpu_baseline"] = {"value": nd / (c1 - c0), "unit": "paths/s", "cores": 1, "kind": "port", "sample": f"first {nd} paths, {c1 - c0:.1f} s, mean iters {float(dinfo_o['iters'].mean()):.1f}"}
+    # ---- parity: device vs oracle at identical settings, inside `config` so that the driver's parsed record keeps it ----
+    if dev_samples.get("osqp_default") is not None:
+        out["config"]["device_vs_oracle"] = {"osqp_default": _vs_oracle(*dev_samples["osqp_default"], dxs_o, dinfo_o)}
+        if dev_samples.get("headline") is not None:
+            out["config"]["device_vs_oracle"]["headline"] = _vs_oracle(*dev_samples["headline"], hxs, hinfo)
+        out["config"]["device_vs_oracle"]["note"] = ("identical settings on both sides; equal iteration count -> |dx| at round-off level; a residual within round-off of a threshold flips one "
+                                                     "check (25 it) or one refinement block (10 it): those paths are compared at 10 x eps, not dropped")
     # the reference's OWN solver classes (oracle/_ref/libpo_ref.so = src/solver/*.cpp compiled where they lie; OSQP itself stood in by the oracle's ADMM)
     try:
         from oracle import ref_py
@@ -471,11 +523,11 @@ def cpu_legs(out, batch, acc, cpu_sample):
             for b_ in range(nr):
                 ref_py.solve("KP", inst(b_), rp)
             r1 = time.perf_counter()
-            out["cpu_baseline_reference_code"] = {"value": nr / (r1 - r0), "unit": "paths/s", "cores": 1, "kind": "reference",
-                                                  "sample": f"first {nr} paths through the reference's OsqpSolver::create(\"KP\")->solve() compiled from its own sources "
-                                                            f"(18.9 MB dense scratch per solve) with the oracle's ADMM in place of OSQP, {r1 - r0:.1f} s"}
+            details["cpu_baseline_reference_code"] = {"value": nr / (r1 - r0), "unit": "paths/s", "cores": 1, "kind": "reference",
+                                                      "sample": f"first {nr} paths through the reference's OsqpSolver::create(\"KP\")->solve() compiled from its own sources "
+                                                                f"(18.9 MB dense scratch per solve) with the oracle's ADMM in place of OSQP, {r1 - r0:.1f} s"}
     except Exception as e:
-        out["cpu_baseline_reference_code"] = {"error": repr(e)}
+        details["cpu_baseline_reference_code"] = {"error": repr(e)}
     try:  # the same sample on every host core, one path slice per process (the reference itself is single-threaded)
         import multiprocessing as mp
 
@@ -484,15 +536,14 @@ def cpu_legs(out, batch, acc, cpu_sample):
         sample = batch.slice(0, nmt)
         parts = [(lo_, min(nmt, lo_ + -(-nmt // nproc))) for lo_ in range(0, nmt, -(-nmt // nproc))]
         with mp.get_context("spawn").Pool(len(parts)) as pool:  # spawn (not fork): the parent holds a live HIP context
-            pool.map_async(_cpu_slice, [(sample.slice(a, a + 2), native) for a, _ in parts], chunksize=1).get(timeout=180)  # warm
+            pool.map_async(_cpu_slice, [(sample.slice(a, a + 2), native, HEADLINE["params"]) for a, _ in parts], chunksize=1).get(timeout=180)  # warm
             m0 = time.perf_counter()
-            pool.map_async(_cpu_slice, [(sample.slice(a, b_), native) for a, b_ in parts], chunksize=1).get(timeout=180)
+            pool.map_async(_cpu_slice, [(sample.slice(a, b_), native, HEADLINE["params"]) for a, b_ in parts], chunksize=1).get(timeout=180)
             m1 = time.perf_counter()
-        out["cpu_baseline_all_cores"] = {"value": nmt / (m1 - m0), "unit": "paths/s", "cores": len(parts), "kind": "port",
-                                         "sample": f"first {nmt} paths of the batch split over {len(parts)} processes "
-                                                   f"(one oracle instance per host core, capped at 64), {m1 - m0:.2f} s"}
+        out["cpu_baseline"]["all_cores"] = {"value": nmt / (m1 - m0), "cores": len(parts),
+                                            "sample": f"first {nmt} paths split over {len(parts)} processes (one oracle instance per host core, capped at 64), {m1 - m0:.2f} s"}
     except Exception as e:  # never let the optional leg break the bench line
-        out["cpu_baseline_all_cores"] = {"error": repr(e)}
+        out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -535,17 +586,18 @@ def main():
     ap.add_argument("--gather", action="store_true", help="N>1: gather every rank's states and info on rank 0 (SURVEY §8e collective 1) and report its time")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 PMC child passes that measure `roofline.traffic` in this run")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--details", default=os.path.join(ROOT, "bench_details.json"), help="file for the bulky legs (other configs, stages, table of settings); '' = do not write")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: gloo backend, faked device times; exercises the shard split, reductions, gather and JSON "
                     "assembly of the N>1 branch (tests/test_multi_process.py)")
     args = ap.parse_args()
 
     import torch
 
-    if args.traffic_child:  # profiled by live_traffic(): three solves of the batch, nothing else
+    if args.traffic_child:  # profiled by live_traffic(): three solves of the batch at the headline setting, nothing else
         from path_optimizer_amd import binding, synth
 
         db = binding.DeviceBatch(synth.make_batch(3, B=args.batch))
-        eng = binding.Engine(0)
+        eng = binding.Engine(0, make_params(binding, HEADLINE["params"]))
         for _ in range(3):
             eng.solve_batch_device(db)
         torch.cuda.synchronize()
@@ -603,7 +655,7 @@ def main():
         S = max(1, args.streams)
         engs, streams, dbs = [], [], []
         for i in range(S):
-            e = binding.Engine(local_rank)
+            e = binding.Engine(local_rank, make_params(binding, HEADLINE["params"]))
             st = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream shared by torch events and the engine
             e.set_stream(st.cuda_stream)
             engs.append(e); streams.append(st)
@@ -644,7 +696,15 @@ def main():
             if dry:
                 gather["path_ids_in_order"] = bool((all_states[:, 0, 0].numpy() == np.arange(world * B)).all())
 
-    out = None
+    # N > 1: which devices the ranks actually ran on (so that the first SCALE record can be checked)
+    ranks_seen = None
+    if world > 1:
+        names = [None] * world
+        me = {"rank": rank, "local_rank": local_rank, "device": "dry-run (cpu)" if dry else torch.cuda.get_device_name(local_rank), "paths": [lo, hi], "elapsed_s": elapsed}
+        dist.all_gather_object(names, me)
+        ranks_seen = {"backend": dist.get_backend(), "world": world, "rccl_ranks_seen": len([n for n in names if n is not None]), "ranks": names}
+
+    out, details = None, {}
     if rank == 0:
         paths_per_s = world * B * args.steps / elapsed_max
         it_rank = float(info["iters"].sum())
@@ -655,6 +715,7 @@ def main():
         path_it_s = it_rank / (med_ms * 1e-3)
         achieved_tf = None if fp64_per_it is None else path_it_s * fp64_per_it * 128.0 / 1e12
         traffic = (_load_json(os.path.join(ROOT, "profiles", "traffic_latest.json")) or {}).get("hbm_bytes_per_launch")
+        sr = info["status_refine"]
         out = {
             "metric": "QP paths/sec at N=200 pts, batch=4096; ADMM iters to 1e-4",
             "value": paths_per_s,
@@ -668,90 +729,118 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic" + (" (DRY RUN: no GPU, faked device times)" if dry else ""),
-            "config": {"workload": f"BASELINE config {cfg}: KP, B={B} paths/GPU x {world} GPU, N={N} points, "
-                                   "per-path random obstacle clearances, OSQP defaults (scaling 10, adaptive rho every 100 it) at eps_abs=eps_rel=1e-4; "
-                                   "one batch after the other on one stream",
+            "config": {"workload": f"BASELINE config {cfg}: KP, B={B} paths/GPU x {world} GPU, N={N} points, per-path random obstacle clearances; one batch after the other on one stream",
+                       "setting": HEADLINE["label"] + ": OSQP defaults (scaling 10, adaptive rho every 100 it, check every 25) at eps_abs = eps_rel = 1e-4 plus the activity-set "
+                                  "refinement, so that every path is within 1e-4 m of its exact optimum (accuracy clause of the metric) — see `accuracy`; `osqp_default` = without it",
                        "batch_per_gpu": B, "points": N, "formulation": "KP", "parallelism": f"batch-split x{world}",
                        "rank_time_max_over_mean": rank_time_max_over_mean},
             "single_batch": {"median_ms": med_ms, "min_ms": float(np.min(step_ms)), "max_ms": float(np.max(step_ms)), "paths_per_s": B / (med_ms * 1e-3),
-                             "note": "hipEvents on the engine's stream around each step (equilibration kernel + uniform-variant launch + general-variant launch), rank 0"},
+                             "note": "hipEvents on the engine's stream around each step (equilibration + uniform-variant launch + general-variant launch + status sweep), rank 0"},
             "admm": {"iters_mean": iters_sum_all / (world * B), "iters_max": iters_max, "unsolved": int(unsolved_all),
                      "refactorisations": int(refac_all), "path_iters_per_s": iters_sum_all * args.steps / elapsed_max,
-                     "iters_min": int(info["iters"].min()), "iters_median": float(np.median(info["iters"])),
-                     "iters_p95": float(np.percentile(info["iters"], 95)),
-                     "schedule": "termination check every 25 it, adaptive rho every 100 it (by iteration count), max_iter 4000"},
+                     "iters_min": int(info["iters"].min()), "iters_median": float(np.median(info["iters"])), "iters_p95": float(np.percentile(info["iters"], 95)),
+                     "certified_at_refine_eps": int((sr == 1).sum()), "not_certified": int((sr == -1).sum())},
             "roofline": {
                 "bound": "fp64_valu", "unit": "TFLOP/s", "peak": FP64_VALU_PEAK_TFLOPS,
                 "achieved": achieved_tf, "frac": None if achieved_tf is None else achieved_tf / FP64_VALU_PEAK_TFLOPS,
-                "achieved_def": "issued fp64 VALU wave-instructions x 128 flop (64 lanes x FMA) / single-batch time: fp64 wave-instructions per path-iteration "
-                                "from profiles/valu_latest.json (ISA histogram of the hot loop weighted by SQ_INSTS_VALU of the rocprofv3 PMC pass of this tree) "
-                                "x path-iterations/s measured in this run",
+                "achieved_def": "fp64 VALU flop issued per launch / single-batch time.  Fallback (this value, when the live PMC passes are unavailable): "
+                                "fp64 wave-instructions per plain path-iteration from profiles/valu_latest.json x 128 flop x path-iterations/s of this run",
                 "peak_source": "MI355X fp64 vector peak = 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GHz (half the 157.3 TF fp32 vector peak in MI355X_MICROARCH.md)",
-                "fp64_wave_instr_per_path_iter": fp64_per_it, "valu_wave_instr_per_path_iter": valu.get("valu_wave_instr_per_path_iter"),
-                "occupancy_waves_per_simd": valu.get("occupancy_waves_per_simd"),
-                "frac_of_measured_issue_ceiling": None if achieved_tf is None else {k: achieved_tf / v for k, v in FP64_VALU_MEASURED_CEILING.items()},
-                "useful_flop_basis": {"achieved": path_it_s * 1.0e5 / 1e12, "note": "0.1 MFLOP per path-iteration (SURVEY.md §8a10)"},
-                "kernel": "po::solve_kernel_fast<KP,SPL=4,NT=64,two-level,uniform-row-classes>", "kernel_ms": med_ms,
+                "kernel": "po::solve_kernel_fast<KP,SPL=4,NT=64,two-level,uniform-row-classes,with-refinement>", "kernel_ms": med_ms,
                 "traffic": traffic,
-                "traffic_note": "HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from the rocprofv3 PMC passes committed under profiles/ (traffic_latest.json); "
-                                "not re-measured inside this run",
+                "traffic_note": "HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE, fallback value from profiles/traffic_latest.json (replaced below when the live PMC passes run)",
                 "algorithmic_hbm_equivalent": {"GB_per_s": abytes / (med_ms * 1e-3) / 1e9, "frac_of_8TBps": abytes / (med_ms * 1e-3) / 1e9 / 8000.0,
                                                "algorithmic_bytes_per_path_iter": b_iter,
-                                               "note": "SURVEY.md §8d contract figure (8 (128N+13C+9) B per path-iteration + compulsory I/O); NOT a roofline: the state is "
-                                                       "LDS/register resident and never moves through HBM"}},
+                                               "note": "SURVEY.md §8d contract figure; NOT a roofline: the state is LDS/register resident and never moves through HBM"}},
         }
+        if ranks_seen is not None:
+            out["config"]["ranks"] = ranks_seen
         if gather is not None:
             out["gather"] = gather
 
     # ---- secondary GPU legs (rank 0, N = 1) ----
-    acc = None
+    dev_samples = {}
     if not dry and world == 1:
+        gold, gold_name = gold_for(batch, lo)
+        ns = max(1, min(args.cpu_sample if args.cpu_sample > 0 else 256, B))
+        full_x = binding.DeviceBatch(batch, device=dev, want_x=True)
+        # the headline setting once more with the raw QP solution kept: accuracy of EVERY path of the batch `value` was measured on
+        hrow, hx, hinfo = run_setting(torch, binding, streams[0], full_x, HEADLINE["params"], steps=1)
+        dev_samples["headline"] = (hx[:ns].copy(), hinfo[:ns].copy())
+        if gold is not None:
+            out["config"]["accuracy"] = {"yardstick": f"exact optimum of every path (tests/golden/tight_full_{gold_name}.npz, KKT residuals <= 3e-14), lateral-offset RMS per path, bar 1e-4 m",
+                                         **accuracy_of(hx, hinfo, batch, gold)}
+            out["config"]["accuracy_clause_met"] = bool(out["config"]["accuracy"]["n_gt_1e-4_m"] == 0 and hrow["unsolved"] == 0 and len(gold) >= B)
+        # the OSQP-faithful default (no extension), same batch, same K steps, timed the same way
+        e0 = binding.Engine(local_rank); e0.set_stream(streams[0].cuda_stream)
+        time_serial(torch, e0, streams[0], dbatch, 1, barrier)
+        del_, dms = time_serial(torch, e0, streams[0], dbatch, args.steps, barrier)
+        dinfo_full = dbatch.info_numpy().copy()
+        e0.close()
+        drow, dx, dinfo = run_setting(torch, binding, streams[0], full_x, {}, steps=1)
+        dev_samples["osqp_default"] = (dx[:ns].copy(), dinfo[:ns].copy())
+        out["osqp_default"] = {"setting": OSQP_DEFAULT["label"], "value": B * args.steps / del_, "ms_per_step": del_ / args.steps * 1e3, "median_ms": float(np.median(dms)),
+                               "iters_mean": float(dinfo_full["iters"].mean()), "iters_max": int(dinfo_full["iters"].max()), "unsolved": int((dinfo_full["status"] != 1).sum()),
+                               "path_iters_per_s": float(dinfo_full["iters"].sum()) / (float(np.median(dms)) * 1e-3)}
+        if gold is not None:
+            out["osqp_default"]["accuracy"] = accuracy_of(dx, dinfo, batch, gold)
+        time_serial(torch, engs[0], streams[0], dbatch, 1, barrier)  # (dbatch holds the headline outputs again for the stage legs below)
+        info = dbatch.info_numpy()
         if args.streams > 1:
             time_pipelined(torch, engs, streams, dbs, min(args.steps, 3), barrier)
             pel, pms = time_pipelined(torch, engs, streams, dbs, args.steps, barrier)
-            out["pipelined_3_streams" if S == 3 else f"pipelined_{S}_streams"] = {
+            details["pipelined_3_streams" if S == 3 else f"pipelined_{S}_streams"] = {
                 "paths_per_s": B * args.steps / pel, "ms_per_step": pel / args.steps * 1e3, "launch_ms_mean": float(np.mean(pms)),
                 "note": f"the same K steps issued round-robin on {S} handles/streams (independent batches overlap: the stragglers of one drain under the next); NOT `value`"}
-        # the same batch with the caller-side scheduling hint po_batch_in.order = paths sorted by the PREVIOUS solve's iteration counts, longest first.
-        # A launch ends with its longest path; a receding-horizon planner re-solves nearly the same problems every cycle, so last cycle's counts are a
-        # good predictor.  Here the inputs of consecutive steps are IDENTICAL, i.e. the hint is perfect: an upper bound of what the hint buys, never `value`.
+            out["pipelined_streams"] = {"streams": S, "paths_per_s": B * args.steps / pel}
+        # caller-side scheduling hint po_batch_in.order = paths sorted by the PREVIOUS solve's iteration counts, longest first (identical inputs step to step: an upper bound)
         dbatch.set_order(np.argsort(-info["iters"].astype(np.int64), kind="stable"))
         time_serial(torch, engs[0], streams[0], dbatch, 1, barrier)
         hel, hms = time_serial(torch, engs[0], streams[0], dbatch, args.steps, barrier)
         dbatch.set_order(None)
-        out["single_batch_with_order_hint"] = {
-            "paths_per_s": B * args.steps / hel, "median_ms": float(np.median(hms)),
-            "note": "po_batch_in.order = argsort(-iters of the previous solve): longest path first; identical inputs step to step make the hint perfect here "
-                    "(upper bound); results are bit-identical with and without the hint"}
+        out["single_batch_with_order_hint"] = {"paths_per_s": B * args.steps / hel, "median_ms": float(np.median(hms)),
+                                               "note": "po_batch_in.order = argsort(-iters of the previous solve); results bit-identical; never `value`"}
         if not args.no_configs:
-            out["configs"] = config_legs(torch, binding, synth, dev, streams[0])
+            details["configs"] = config_legs(torch, binding, synth, dev, streams[0])
+            out["configs"] = {k: {kk: v[kk] for kk in ("ms", "paths_per_s", "iters_mean", "iters_max", "unsolved", "solve_ms_host_to_host") if kk in v} for k, v in details["configs"].items()}
         if not args.no_parity:
-            acc = accuracy_legs(torch, binding, synth, batch, dev, streams[0], args.cpu_sample)
-            out["parity"] = {"accuracy": acc["settings"],
-                             "accuracy_note": "lateral offset e_y of the first 256 paths vs their exact optimum (tests/golden/tight_c3.npz: active-set solution, KKT residuals "
-                                              "<= 1e-13); north-star bar: RMS <= 1e-4 m"}
-            ok99 = [s for s in acc["settings"] if s.get("e_y_rms_vs_exact_optimum_m", {}).get("frac_le_1e-4", 0) >= 0.99]
-            out["parity"]["first_setting_with_99pct_within_1e-4_m"] = ok99[0]["setting"] if ok99 else None
-            out["parity"]["paths_per_s_at_that_setting"] = ok99[0]["paths_per_s"] if ok99 else None
-            best = max(ok99, key=lambda s: s["paths_per_s"]) if ok99 else None
-            out["parity"]["fastest_setting_with_99pct_within_1e-4_m"] = None if best is None else {
-                "setting": best["setting"], "paths_per_s": best["paths_per_s"], "cost_vs_benchmarked_setting": best["paths_per_s"] / acc["settings"][0]["paths_per_s"] - 1.0}
+            details["settings"] = settings_table(torch, binding, batch, dev, streams[0], gold)
+            ok_all = [r for r in details["settings"] if r.get("e_y_rms_vs_exact_optimum", {}).get("n_gt_1e-4_m", 1) == 0 and r["unsolved"] == 0]
+            best = max(ok_all, key=lambda r: r["paths_per_s"]) if ok_all else None
+            out["config"]["fastest_setting_with_every_path_within_1e-4_m"] = None if best is None else {"setting": best["setting"], "paths_per_s": best["paths_per_s"], "ms": best["ms"]}
         stage_ctx = None
         if not args.no_stages:
-            out["stages"], stage_ctx = stage_legs_gpu(torch, binding, synth, engs[0], streams[0], dbatch, B)
+            details["stages"], stage_ctx = stage_legs_gpu(torch, binding, synth, engs[0], streams[0], dbatch, B)
+            fp = details["stages"].get("full_pipeline", {})
+            out["stages"] = {"bounds_ms": details["stages"]["bounds_producer"]["ms"], "post_check_ms": details["stages"]["post_check"]["ms"],
+                             "full_pipeline_instances_per_s": fp.get("instances_per_s"), "full_pipeline_ms": fp.get("ms")}
         if not args.no_live_traffic:
             lt = live_traffic(B)
             if lt is not None:
-                out["roofline"]["traffic"] = lt["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_note"] = lt["source"] + f" (FETCH_SIZE {lt['fetch_bytes_raw'] / 1e6:.1f} MB x 2 + WRITE_SIZE {lt['write_bytes'] / 1e6:.1f} MB; compulsory I/O {8 * (18 * N + 8) * B / 1e6:.1f} MB)"
-                out["roofline"]["traffic_GBps"] = lt["hbm_bytes_per_launch"] / (out["single_batch"]["median_ms"] * 1e-3) / 1e9
-                out["roofline"]["valu_wave_instr_per_path_iter"] = lt["valu_wave_instr_per_launch"] / float(info["iters"].sum())  # SQ_INSTS_VALU of this run
+                rf = out["roofline"]
+                rf["traffic"] = lt["hbm_bytes_per_launch"]
+                rf["traffic_note"] = lt["source"] + f" (FETCH_SIZE {lt['fetch_bytes_raw'] / 1e6:.1f} MB x 2 + WRITE_SIZE {lt['write_bytes'] / 1e6:.1f} MB; compulsory I/O {8 * (18 * N + 8) * B / 1e6:.1f} MB)"
+                rf["traffic_GBps"] = lt["hbm_bytes_per_launch"] / (out["single_batch"]["median_ms"] * 1e-3) / 1e9
+                rf["valu_wave_instr_per_path_iter"] = lt["valu_wave_instr_per_launch"] / float(info["iters"].sum())  # SQ_INSTS_VALU of this run
+                if lt.get("fp64_flop_per_launch"):
+                    rf["achieved"] = lt["fp64_flop_per_launch"] / (out["single_batch"]["median_ms"] * 1e-3) / 1e12
+                    rf["frac"] = rf["achieved"] / FP64_VALU_PEAK_TFLOPS
+                    rf["fp64_wave_instr_per_path_iter"] = lt["fp64_wave_instr_per_launch"] / float(info["iters"].sum())
+                    rf["achieved_def"] = ("fp64 VALU flop per launch measured in this run (rocprofv3 --pmc SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 of the solve kernel: wave-instructions x 64 lanes, "
+                                          "FMA x 2) / single-batch time (hipEvents, median of the timed steps)")
+                rf["frac_of_measured_issue_ceiling"] = {k: rf["achieved"] / v for k, v in FP64_VALU_MEASURED_CEILING.items()} if rf.get("achieved") else None
         torch.cuda.synchronize()
         out["gpu_done_s"] = time.time()  # everything after this timestamp is host-only (CPU baseline / checker legs)
         if args.cpu_sample > 0:
-            cpu_legs(out, batch, acc, args.cpu_sample)
+            cpu_legs(out, details, batch, dev_samples, args.cpu_sample)
             if stage_ctx is not None:
-                stage_legs_cpu(out["stages"], stage_ctx)
+                stage_legs_cpu(details["stages"], stage_ctx)
+    if rank == 0 and details and args.details:
+        try:
+            json.dump(details, open(args.details, "w"), indent=1)
+            out["details_file"] = os.path.relpath(args.details, ROOT)
+        except OSError:
+            pass
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

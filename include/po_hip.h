@@ -122,7 +122,9 @@ typedef struct po_params {
     int    refine_max_refactor;         /* 40: free re-derivation for the first half of this budget, then active rows stay active (the set only grows, which
                                            ends any flip-flopping); when it is spent the vector goes back to the bound types at refine_rho */
     double refine_rho;                  /* 10 (scaled problem, like rho0) */
-    double refine_eps;                  /* 1e-6: eps_abs = eps_rel of the termination test of this phase */
+    double refine_eps;                  /* 1e-7: eps_abs = eps_rel of the termination test of this phase (what po_info.status_refine = 1 certifies).  Measured on all 4096
+                                           paths of BASELINE config 3 against their exact optima: certified at 1e-7 -> max e_y RMS error 1e-5 m; at 1e-6 seven certified
+                                           paths were 1e-4 .. 4e-4 m away (these QPs are flat: e_y is the double integral of the curvature) */
     int    refine_rounds;               /* 1.  R > 1: the solve first stops at 10^(R-1) x (eps_abs, eps_rel) and is refined from there (budget refine_max_iter / 4);
                                            a path the refinement does not certify at refine_eps goes back to the type-based iteration at a 10 x tighter eps and is
                                            refined again, down to eps itself (last round: the full budget).  Every path returned satisfies OSQP's test at eps_abs /
@@ -141,7 +143,15 @@ typedef struct po_params {
                                            a workgroup that does not certify its path pushes it onto a device-side queue and a follow-up workgroup of the same launch
                                            resumes it, so a later round fills the tail of the one before instead of waiting for its slowest path.  0: one launch pair per
                                            round (every round ends with a chip-wide barrier). */
-    int    reserved0;
+    int    refine_extra_rounds;         /* 0.  E > 0: a path that the last regular round does not certify at refine_eps continues BELOW eps — type-based iteration at
+                                           eps / 10, refinement again, eps / 100, ... — for up to E more rounds (full refinement budget each).  A path returned after
+                                           them is certified, or satisfies OSQP's test at eps / 10^E.  For the handful of nearly flat QPs on which the activity-set
+                                           iteration cycles (BASELINE config 3: 11 of 4096 paths): they are the ones left > 0.1 m from the optimum at eps. */
+    int    refine_adapt;                /* 1.  OSQP's adaptive-rho rule (balance of the relative residuals, applied when the estimate leaves [rho / adapt_tol, rho x adapt_tol])
+                                           on the refinement's own rho, after a block of refine_every iterations that kept its step vector.  Once the activity set has
+                                           settled the phase is dual ascent on the active rows; with a fixed refine_rho a multiplier that must grow to O(1) takes
+                                           thousands of iterations (primal residual stuck at 1e-4 while the dual one is 1e-10).  0: refine_rho stays fixed. */
+    int    reserved1;
 } po_params;
 
 typedef struct po_info {

@@ -94,8 +94,9 @@ void po_oracle_default_params(po_params *p) {
     p->enable_dynamic_segmentation = 1;
     p->enable_raw_output = 1; p->output_spacing = 0.3; /* planning_flags.cpp:127-129 */
     p->polish = 0; p->polish_delta = 1e-6; p->polish_refine_iter = 3; p->polish_passes = 1; /* OSQP defaults (polish off) */
-    p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-6; p->refine_rounds = 1; p->probe_iters = 0;  /* (probe_iters: device scheduling only, no effect on results) */
+    p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-7; p->refine_rounds = 1; p->probe_iters = 0;  /* (probe_iters: device scheduling only, no effect on results) */
     p->refine_chain = 1; /* device scheduling only */
+    p->refine_extra_rounds = 0; p->refine_adapt = 1;
 }
 
 /* tools.hpp:24-35 — recursive in the reference; same fixed point as this loop */
@@ -1038,6 +1039,9 @@ int po_oracle_qp_solve_ext(int n, int m, const int *Pp0, const int *Pi0, const d
     /* po_params.refine_rounds = R > 1: the type-based iteration first stops at 10^(R-1) x eps and hands over to the refinement; a path that one does not
      * certify comes back here (resume_main) at a 10 x tighter eps, down to eps itself */
     const int rounds = prm->refine ? (prm->refine_rounds > 1 ? prm->refine_rounds : 1) : 1;
+    /* refine_extra_rounds = E: a path the LAST regular round does not certify goes on below eps — type-based iteration at eps / 10, refinement, eps / 100, ...
+     * up to E more rounds (each with the full refinement budget) */
+    const int rounds_total = rounds + (prm->refine && prm->refine_extra_rounds > 0 ? prm->refine_extra_rounds : 0);
     int round = 0, refine_its = 0, refine_fac = 0;
     double eps_mul = 1.0;
     for (int r_ = 1; r_ < rounds; ++r_) eps_mul *= 10.0;
@@ -1172,7 +1176,8 @@ resume_main:
     info->rho = rho;
     /* ---- refinement (po_params.refine; extension, not OSQP): the same ADMM iteration continued with the step vector set by activity (see po_hip.h) ---- */
     if (prm->refine && info->status == PO_STATUS_SOLVED) {
-        const double rb = prm->refine_rho < OSQP_RHO_MIN ? OSQP_RHO_MIN : (prm->refine_rho > OSQP_RHO_MAX ? OSQP_RHO_MAX : prm->refine_rho);
+        double rb = prm->refine_rho < OSQP_RHO_MIN ? OSQP_RHO_MIN : (prm->refine_rho > OSQP_RHO_MAX ? OSQP_RHO_MAX : prm->refine_rho);
+        double rb_next = rb;
         const int every = prm->refine_every > 0 ? prm->refine_every : 10;
         int nfac = 0, it2 = 0, frozen = 0, stop = 0;
         const int cap_it = round + 1 < rounds ? (prm->refine_max_iter / 4 > every ? prm->refine_max_iter / 4 : every) : prm->refine_max_iter;
@@ -1185,7 +1190,9 @@ resume_main:
             /* step vector from the bound type (as set_rho_vec) and, for inequality rows, from activity: z at a bound with a multiplier of the matching sign.
              * Once the refactorisation budget is spent (an active set that keeps flipping) the vector goes back to the type-based one and stays. */
             int changed = 0;
-            if (!frozen) {
+            const double rb_old = rb;
+            rb = rb_next;
+            if (!frozen || rb != rb_old) {
                 if (nfac >= prm->refine_max_refactor) frozen = 1;
                 for (int i = 0; i < m; ++i) {
                     double r;
@@ -1196,7 +1203,7 @@ resume_main:
                          * that it moves v off the bound by less than 1e-9 (1 + |bound|) counts as zero: its sign is rounding noise) */
                         const double v = z[i] + rho_inv[i] * y[i];
                         const double tl_ = 1e-9 * (1.0 + fabs(l[i])), tu_ = 1e-9 * (1.0 + fabs(u[i])); /* a numerically zero multiplier is no multiplier */
-                        r = (frozen || v < l[i] - tl_ || v > u[i] + tu_ || (2 * nfac >= prm->refine_max_refactor && rho_vec[i] == rb)) ? rb : OSQP_RHO_MIN;
+                        r = (frozen || v < l[i] - tl_ || v > u[i] + tu_ || (2 * nfac >= prm->refine_max_refactor && rho_vec[i] == rb_old)) ? rb : OSQP_RHO_MIN;
                     }
                     if (r != rho_vec[i]) { rho_vec[i] = r; changed = 1; }
                 }
@@ -1239,6 +1246,18 @@ resume_main:
                 stop = pri_res < prm->refine_eps + prm->refine_eps * (nz > nAx ? nz : nAx) && dua_res < prm->refine_eps + prm->refine_eps * cinv * dn;
             }
             if (stop || it2 >= cap_it) break;
+            if (prm->refine_adapt && !changed) {
+                /* refine_adapt: OSQP's rho estimate (compute_rho_estimate's balance of the relative residuals; here on the unscaled ones this test has just
+                 * evaluated) applied to the phase's own rho, after a block that kept its step vector.  With the activity set settled the iteration is dual
+                 * ascent on the active rows: a multiplier that has to grow to O(1) at refine_rho = 10 x (a violation of 1e-4) per iteration takes thousands
+                 * of iterations (primal residual stuck at 1e-4, dual at 1e-10: BASELINE config 3, path 1857 — 6 425 iterations without this, 285 with) */
+                const double nz_ = vnorm_inf_scaled(Einv, z, m), nAx_ = vnorm_inf_scaled(Einv, Axv, m);
+                const double nAty_ = vnorm_inf_scaled(Dinv, Aty, n), nPx_ = vnorm_inf_scaled(Dinv, Pxv, n);
+                const double pr = pri_res / ((nz_ > nAx_ ? nz_ : nAx_) + 1e-10), dr = dua_res / (cinv * (nAty_ > nPx_ ? nAty_ : nPx_) + 1e-10);
+                double rn = rb * sqrt(pr / (dr + 1e-10));
+                rn = rn < OSQP_RHO_MIN ? OSQP_RHO_MIN : (rn > OSQP_RHO_MAX ? OSQP_RHO_MAX : rn);
+                if (rn > prm->adapt_tol * rb || rn < rb / prm->adapt_tol) rb_next = rn;
+            }
         }
         refine_its += it2;
         refine_fac += nfac;
@@ -1256,7 +1275,7 @@ resume_main:
             dua_res = dua0;
         }
         free(snap);
-        if (!stop && round + 1 < rounds) { /* not certified at refine_eps: back to the type-based iteration (its own rho) at a 10 x tighter eps, then again */
+        if (!stop && round + 1 < rounds_total) { /* not certified at refine_eps: back to the type-based iteration (its own rho) at a 10 x tighter eps, then again */
             ++round;
             eps_mul *= 0.1;
             for (int i = 0; i < m; ++i) {

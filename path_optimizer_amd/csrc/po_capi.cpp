@@ -124,8 +124,8 @@ void po_default_params(po_params *p) {
     p->enable_dynamic_segmentation = 1;
     p->enable_raw_output = 1; p->output_spacing = 0.3; /* planning_flags.cpp:127-129 */
     p->polish = 0; p->polish_delta = 1e-6; p->polish_refine_iter = 3; p->polish_passes = 1;  /* OSQP defaults (polish off) */
-    p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-6; p->refine_rounds = 1; p->probe_iters = 0;
-    p->refine_chain = 1;
+    p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-7; p->refine_rounds = 1; p->probe_iters = 0;
+    p->refine_chain = 1; p->refine_extra_rounds = 0; p->refine_adapt = 1;
 }
 
 int po_problem_dims(int form, int N, int keep, int *n, int *m, int *C) {
@@ -253,6 +253,7 @@ static int make_dev_params(const po_handle_s *h, int form, int keep, po::DevPara
     D->pol_passes = p.polish_passes;
     D->refine = p.refine; D->ref_every = p.refine_every > 0 ? p.refine_every : 10; D->ref_max_iter = p.refine_max_iter; D->ref_max_refactor = p.refine_max_refactor;
     D->ref_rho = p.refine_rho; D->ref_eps = p.refine_eps; D->ref_rounds = p.refine_rounds;
+    D->ref_extra = (p.refine && p.refine_extra_rounds > 0) ? p.refine_extra_rounds : 0; D->ref_adapt = p.refine_adapt;
     D->slice = (!p.refine && p.probe_iters > 0) ? p.probe_iters : 0;
     return PO_OK;
 }
@@ -325,11 +326,12 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
         D.use_split = (h->env_split && !polish) ? 1 : 0;
     }
     po::DevBatch DS = D;  // what the solve launches see (the polish launch keeps D: B workgroups, no queue)
-    if (h->params.refine && h->params.refine_rounds > 1 && h->params.refine_rounds < 64 && h->params.refine_chain && D.pol_state != nullptr && in->B < (1 << 24)) {
-        const size_t qints = 4 + (size_t)(h->params.refine_rounds - 1) * (size_t)in->B;
+    const int rounds_total = (h->params.refine_rounds > 1 ? h->params.refine_rounds : 1) + P.ref_extra;
+    if (h->params.refine && rounds_total > 1 && rounds_total < 64 && h->params.refine_chain && D.pol_state != nullptr && in->B < (1 << 24)) {
+        const size_t qints = 4 + (size_t)(rounds_total - 1) * (size_t)in->B;
         if ((rc = h->rq_buf.ensure(sizeof(int) * 2 * qints))) return rc;
         DS.rq = static_cast<int *>(h->rq_buf.p);
-        DS.rq_rounds = h->params.refine_rounds;
+        DS.rq_rounds = rounds_total;
     }
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     // per-path equilibration (h->params.scaling class-level Ruiz passes; 0 -> identity), then the fused solve

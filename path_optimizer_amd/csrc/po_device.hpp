@@ -35,7 +35,7 @@ struct DevParams {
     int max_iter, check_every, adapt_every, end_heading;
     double pol_delta;           // OSQP delta
     int polish, pol_refine, pol_passes;
-    int refine, ref_every, ref_max_iter, ref_max_refactor, ref_rounds;  // po_params.refine*
+    int refine, ref_every, ref_max_iter, ref_max_refactor, ref_rounds, ref_extra, ref_adapt;  // po_params.refine*
     int slice;              // po_params.probe_iters (0 with refine): iterations of the first launch pair
     double ref_rho, ref_eps;
 };

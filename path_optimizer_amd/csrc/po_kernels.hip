@@ -90,7 +90,7 @@ extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po
     }
     // po_params.refine_rounds: one pair of launches per round; a later round finds only the paths the round before handed back (the others leave after one
     // 4-byte read).  po_params.probe_iters: two rounds (the engine launches them one by one, po_launch_solve_round, to order the second).
-    const int rounds = P->refine ? (P->ref_rounds > 1 ? P->ref_rounds : 1) : 2;
+    const int rounds = P->refine ? (P->ref_rounds > 1 ? P->ref_rounds : 1) + P->ref_extra : 2;  // (with the rounds below eps, po_params.refine_extra_rounds)
     DevBatch rb = *in;
     if (P->refine && rounds > 1 && in->rq != nullptr) {
         // chained rounds (po_params.refine_chain): ONE launch pair, rounds * B workgroups each; in->rq = the two queues ([0]: uniform-variant launch, [1]: general

@@ -87,5 +87,9 @@ def test_bench_n_gt_1_branch_dry_run():
     ids = np.arange(2 * 96)
     it = 25 * (1 + (ids * 2654435761 % 61))
     assert d["admm"]["iters_mean"] == it.mean() and d["admm"]["iters_max"] == it.max() and d["admm"]["refactorisations"] == int((it // 400).sum())
+    # which ranks took part and what they ran on (so that the first real SCALE record can be checked the same way)
+    rk = d["config"]["ranks"]
+    assert rk["world"] == 2 and rk["rccl_ranks_seen"] == 2 and rk["backend"] == "gloo"
+    assert [r["rank"] for r in rk["ranks"]] == [0, 1] and [r["paths"] for r in rk["ranks"]] == [[0, 96], [96, 192]]
     g = d["gather"]
     assert g["paths_on_root"] == 192 and g["iters_sum_on_root"] == float(it.sum()) and g["path_ids_in_order"] is True

@@ -21,7 +21,7 @@ def _rms(xs, gold, N):
 
 def test_oracle_refine_defaults_and_off_is_identity(oracle):
     p = oracle.default_params()
-    assert (p.refine, p.refine_every, p.refine_max_iter, p.refine_max_refactor, p.refine_rho, p.refine_eps, p.refine_rounds) == (0, 10, 400, 40, 10.0, 1e-6, 1)
+    assert (p.refine, p.refine_every, p.refine_max_iter, p.refine_max_refactor, p.refine_rho, p.refine_eps, p.refine_rounds) == (0, 10, 400, 40, 10.0, 1e-7, 1)
     b = synth.make_batch(3, B=4)
     _, i0, x0 = oracle.solve_batch(b, oracle.device_equivalent_params())
     q = oracle.device_equivalent_params()
@@ -121,7 +121,7 @@ def test_device_refine_matches_oracle_and_optimum(oracle):
     b = synth.make_batch(3, B=128)
     gold = np.load(GOLD)["e_y"]
     p = binding.default_params()
-    assert (p.refine, p.refine_every, p.refine_max_iter, p.refine_max_refactor, p.refine_rho, p.refine_eps, p.refine_rounds) == (0, 10, 400, 40, 10.0, 1e-6, 1)
+    assert (p.refine, p.refine_every, p.refine_max_iter, p.refine_max_refactor, p.refine_rho, p.refine_eps, p.refine_rounds) == (0, 10, 400, 40, 10.0, 1e-7, 1)
     st0, i0, x0 = binding.Engine(0, p).solve_batch(b, want_x=True)
     p.refine = 1
     st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)

@@ -15,12 +15,13 @@ from path_optimizer_amd import binding
 
 SETTINGS = [
     ("eps 1e-4 (OSQP-faithful default)", {}),
-    ("eps 1e-4 + refine", dict(refine=1)),
-    ("eps 1e-4 + refine, rounds 3, one launch per round", dict(refine=1, refine_rounds=3, refine_chain=0)),
-    ("eps 1e-4 + refine, rounds 3, chained", dict(refine=1, refine_rounds=3, refine_chain=1)),
-    ("eps 1e-4 + refine, rounds 2, chained", dict(refine=1, refine_rounds=2, refine_chain=1)),
-    ("eps 1e-4 + refine, rounds 4, chained", dict(refine=1, refine_rounds=4, refine_chain=1)),
-    ("eps 3e-4 + refine", dict(refine=1, eps_abs=3e-4, eps_rel=3e-4)),
+    ("refine, rounds 3, one launch per round", dict(refine=1, refine_rounds=3, refine_chain=0)),
+    ("refine, rounds 3, chained", dict(refine=1, refine_rounds=3, refine_chain=1)),
+    ("refine, rounds 3 + 2 below eps, one launch per round", dict(refine=1, refine_rounds=3, refine_extra_rounds=2, refine_chain=0)),
+    ("refine, rounds 3 + 2 below eps, chained (headline)", dict(refine=1, refine_rounds=3, refine_extra_rounds=2)),
+    ("refine, rounds 2 + 3 below eps, chained", dict(refine=1, refine_rounds=2, refine_extra_rounds=3)),
+    ("refine, rounds 4 + 2 below eps, chained", dict(refine=1, refine_rounds=4, refine_extra_rounds=2)),
+    ("refine, 1 round + 2 below eps, chained", dict(refine=1, refine_rounds=1, refine_extra_rounds=2)),
 ]
 
 
