@@ -1169,8 +1169,8 @@ resume_main:
         if (info->status == PO_STATUS_UNSOLVED) info->status = PO_STATUS_MAX_ITER;
     }
     (void)checked_this_iter;
-    info->iters = iter;
-    info->n_refactor = n_refactor;
+    info->iters = iter + refine_its;          /* (refinement iterations / refactorisations of earlier rounds: po_params.refine_rounds) */
+    info->n_refactor = n_refactor + refine_fac;
     info->r_prim = pri_res;
     info->r_dual = dua_res;
     info->rho = rho;

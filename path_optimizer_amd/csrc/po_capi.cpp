@@ -376,8 +376,12 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
             std::vector<long long> all(16 * (size_t)in->B);
             HIP_TRY(hipMemcpy(all.data(), D.dbg_cycles, sizeof(long long) * all.size(), hipMemcpyDeviceToHost));
             long long nf = 0, nb = 0;
-            for (int b = 0; b < in->B; ++b) { nf += all[16 * (size_t)b + 13]; nb += all[16 * (size_t)b + 14]; }
-            std::fprintf(stderr, "[po] batch of %d (form %d, N %d, keep %d): %lld scan factorisations, %lld fell back to the sequential chain\n", in->B, in->formulation, in->N, in->keep, nf, nb);
+            double worst = 0;
+            for (int b = 0; b < in->B; ++b) {
+                nf += all[16 * (size_t)b + 13]; nb += all[16 * (size_t)b + 14];
+                double w; std::memcpy(&w, &all[16 * (size_t)b + 15], sizeof(w)); worst = std::fmax(worst, w);
+            }
+            std::fprintf(stderr, "[po] batch of %d (form %d, N %d, keep %d): %lld scan factorisations, %lld fell back to the sequential chain; worst relative disagreement scan vs recursion %.3e\n", in->B, in->formulation, in->N, in->keep, nf, nb, worst);
         }
         std::fprintf(stderr, "[po] path0 cycles: rhs %lld solve %lld update %lld over %lld iterations | solve phases F1 %lld F2 %lld F3B1 %lld B2 %lld B3 %lld | first factorisation: blocks %lld chain %lld | uniform row classes %lld | scan factorisations %lld, fell back to the sequential chain %lld\n",
                      c4[0], c4[1], c4[2], c4[3], c4[4], c4[5], c4[6], c4[7], c4[8], c4[10], c4[11], c4[12], c4[13], c4[14]);
