@@ -151,7 +151,11 @@ typedef struct po_params {
                                            on the refinement's own rho, after a block of refine_every iterations that kept its step vector.  Once the activity set has
                                            settled the phase is dual ascent on the active rows; with a fixed refine_rho a multiplier that must grow to O(1) takes
                                            thousands of iterations (primal residual stuck at 1e-4 while the dual one is 1e-10).  0: refine_rho stays fixed. */
-    int    reserved1;
+    int    refine_speculate;            /* 1.  Chained rounds only; scheduling only, results bit-identical.  k >= 0: from round k on, while a workgroup refines a
+                                           solved path another one already runs the NEXT round's type-based iteration from the same solved point — which is what the
+                                           path does anyway when the refinement fails (it then returns to that point).  A refinement that certifies (or improves) the
+                                           point cancels the continuation; one that fails hands the path to it.  Takes the failed attempts of the hardest paths — up to
+                                           600 refinement iterations each on BASELINE config 3 — off the launch's critical path.  -1: off. */
 } po_params;
 
 typedef struct po_info {
@@ -240,8 +244,13 @@ int po_set_stream(po_handle h, void *hip_stream);
  * selects an experimental kernel with equal results to rounding).  Keys: "identity_order" (workgroup i solves path i instead of the XCD-aware mixing),
  * "debug_cycles" (per-phase shader clocks of path 0 on stderr; makes the solve entry synchronous), "split" (stage-split two-wave mapping of the keep-4
  * kernel; PO_ERR_UNSUPPORTED unless the library was built with `make SPLIT=1`), "smooth_seq", "smooth_waves", "smooth_nopad", "smooth_debug" (smoothing-QP
- * engine variants), "dp_one_wave" (DP lattice search on one wave per instance whatever the batch size).  Unknown key: PO_ERR_INVALID. */
+ * engine variants), "dp_one_wave" (DP lattice search on one wave per instance whatever the batch size), "queue_policy" (chained refinement rounds: 0 = a workgroup takes a
+ * fresh path before a hand-back, k >= 1 = hand-backs of round >= k first; scheduling only).  Unknown key: PO_ERR_INVALID. */
 int po_debug_set(po_handle h, const char *key, int value);
+/* Developer tool: with po_debug_set(h, "queue_trace", 1), the item timeline of the last chained-rounds solve — records of 4 int64: path | round << 32 |
+ * speculative << 40 | outcome << 48 (0 final, 1 handed back, 2 failed attempt handed to its continuation, 3 / 4 continuation cancelled), start, end
+ * (100 MHz device wall clock), workgroup index.  Returns the number of records copied (synchronises the stream). */
+int po_debug_trace_read(po_handle h, long long *out, int max_records);
 
 /* Host-pointer entry: H2D, solve, D2H, synchronous. */
 int po_solve_batch(po_handle h, const po_batch_in *in, const po_batch_out *out);

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PO_LIB") or os.path.join(_HERE, "libpo_hip.so")  # PO_LIB: dev builds (make dev), A/B experiments
 _LIB = None
 
-EXPORTS = ["po_default_params", "po_problem_dims", "po_keep_control_steps", "po_create", "po_destroy", "po_set_stream", "po_debug_set", "po_device_count",
+EXPORTS = ["po_default_params", "po_problem_dims", "po_keep_control_steps", "po_create", "po_destroy", "po_set_stream", "po_debug_set", "po_debug_trace_read", "po_device_count",
            "po_solve_batch", "po_solve_batch_device", "po_assemble_batch", "po_scaling_batch", "po_last_kernel_ms", "po_strerror",
            "po_last_hip_error", "po_version", "po_set_map", "po_postcheck_batch", "po_postcheck_batch_device", "po_bounds_batch",
            "po_bounds_batch_device", "po_map_sample", "po_smooth_dims", "po_smooth_batch", "po_smooth_batch_device",
@@ -31,7 +31,7 @@ class PoError(RuntimeError):
 
 
 _ENV_DEBUG = {"PO_IDENTITY_ORDER": "identity_order", "PO_DEBUG_CYCLES": "debug_cycles", "PO_SPLIT": "split", "PO_SMOOTH_SEQ": "smooth_seq",
-              "PO_SMOOTH_WAVES": "smooth_waves", "PO_SMOOTH_NOPAD": "smooth_nopad", "PO_SMOOTH_DEBUG": "smooth_debug", "PO_DP_ONE_WAVE": "dp_one_wave"}
+              "PO_SMOOTH_WAVES": "smooth_waves", "PO_SMOOTH_NOPAD": "smooth_nopad", "PO_SMOOTH_DEBUG": "smooth_debug", "PO_DP_ONE_WAVE": "dp_one_wave", "PO_QUEUE_POLICY": "queue_policy"}
 
 
 def lib():
@@ -128,6 +128,14 @@ class Engine:
     def debug_set(self, key: str, value: int):
         """po_debug_set: developer A/B switches (identity_order, debug_cycles, split, smooth_seq, smooth_waves, smooth_nopad, smooth_debug, dp_one_wave)."""
         _check(lib().po_debug_set(self._h, key.encode(), int(value)))
+
+    def debug_trace_read(self, max_records: int = 65000):
+        """po_debug_trace_read: [n, 4] int64 records of the last chained-rounds solve (after debug_set("queue_trace", 1))."""
+        out = np.zeros((max_records, 4), dtype=np.int64)
+        n = lib().po_debug_trace_read(self._h, out.ctypes.data_as(C.c_void_p), max_records)
+        if n < 0:
+            _check(n)
+        return out[:n]
 
     def close(self):
         if self._h:

@@ -85,7 +85,9 @@ struct po_handle_s {
     // developer switches (po_debug_set; the library reads no environment variable): identity_order (block i solves path i), debug_cycles (per-phase shader
     // clocks of path 0 on stderr; synchronises), split (experimental stage-split mapping, only in builds made with `make SPLIT=1`), smoothing / DP-search A/B switches
     bool env_identity = false, env_cycles = false, env_split = false, env_smooth_seq = false, env_smooth_nopad = false, env_smooth_debug = false, env_dp_one_wave = false;
-    int env_smooth_waves = 0;
+    int env_smooth_waves = 0, env_queue_policy = 0;
+    bool env_queue_trace = false;
+    DevBuf trace_buf;
     DevBuf in_buf, out_buf, asm_buf, scale_buf, dbg_buf, map_buf, post_buf, coef_buf, bnd_buf, smooth_buf, smooth_io, plan_coef, plan_io, plan_arena, plan_host;
     po::DevMap map{};  // obstacle-distance layer (po_set_map); map.d == nullptr until set
     std::mutex mu;
@@ -125,7 +127,7 @@ void po_default_params(po_params *p) {
     p->enable_raw_output = 1; p->output_spacing = 0.3; /* planning_flags.cpp:127-129 */
     p->polish = 0; p->polish_delta = 1e-6; p->polish_refine_iter = 3; p->polish_passes = 1;  /* OSQP defaults (polish off) */
     p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-7; p->refine_rounds = 1; p->probe_iters = 0;
-    p->refine_chain = 1; p->refine_extra_rounds = 0; p->refine_adapt = 1;
+    p->refine_chain = 1; p->refine_extra_rounds = 0; p->refine_adapt = 1; p->refine_speculate = 1;
 }
 
 int po_problem_dims(int form, int N, int keep, int *n, int *m, int *C) {
@@ -193,6 +195,7 @@ int po_destroy(po_handle h) {
     h->pol_buf.release();
     h->ord_buf.release();
     h->rq_buf.release();
+    h->trace_buf.release();
     h->in_buf.release(); h->out_buf.release(); h->asm_buf.release(); h->scale_buf.release(); h->dbg_buf.release(); h->map_buf.release(); h->post_buf.release(); h->coef_buf.release(); h->bnd_buf.release(); h->smooth_buf.release(); h->smooth_io.release(); h->plan_coef.release(); h->plan_io.release(); h->plan_arena.release(); h->plan_host.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -219,8 +222,23 @@ int po_debug_set(po_handle h, const char *key, int value) {
     else if (k == "smooth_nopad") h->env_smooth_nopad = value != 0;
     else if (k == "smooth_debug") h->env_smooth_debug = value != 0;
     else if (k == "dp_one_wave") h->env_dp_one_wave = value != 0;
+    else if (k == "queue_trace") h->env_queue_trace = value != 0;
+    else if (k == "queue_policy") h->env_queue_policy = value < 0 ? 0 : (value > 31 ? 31 : value);
     else return PO_ERR_INVALID;
     return PO_OK;
+}
+
+int po_debug_trace_read(po_handle h, long long *out, int max_records) {
+    if (!h || !out || max_records < 0) return PO_ERR_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->trace_buf.p) return 0;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    long long hdr[4];
+    HIP_TRY(hipMemcpy(hdr, h->trace_buf.p, sizeof(hdr), hipMemcpyDeviceToHost));
+    int n = (int)std::min<long long>(std::min<long long>(hdr[0], 65000), max_records);
+    HIP_TRY(hipMemcpy(out, static_cast<long long *>(h->trace_buf.p) + 4, sizeof(long long) * 4 * (size_t)n, hipMemcpyDeviceToHost));
+    return n;
 }
 
 int po_set_stream(po_handle h, void *hip_stream) {
@@ -253,7 +271,7 @@ static int make_dev_params(const po_handle_s *h, int form, int keep, po::DevPara
     D->pol_passes = p.polish_passes;
     D->refine = p.refine; D->ref_every = p.refine_every > 0 ? p.refine_every : 10; D->ref_max_iter = p.refine_max_iter; D->ref_max_refactor = p.refine_max_refactor;
     D->ref_rho = p.refine_rho; D->ref_eps = p.refine_eps; D->ref_rounds = p.refine_rounds;
-    D->ref_extra = (p.refine && p.refine_extra_rounds > 0) ? p.refine_extra_rounds : 0; D->ref_adapt = p.refine_adapt;
+    D->ref_extra = (p.refine && p.refine_extra_rounds > 0) ? p.refine_extra_rounds : 0; D->ref_adapt = p.refine_adapt; D->ref_spec = p.refine_speculate;
     D->slice = (!p.refine && p.probe_iters > 0) ? p.probe_iters : 0;
     return PO_OK;
 }
@@ -287,7 +305,7 @@ static void fill_dev_batch(const po_handle_s *h, po::DevBatch *D, const po_batch
     D->pol_state = nullptr; D->pol_stride = 0;
     D->use_split = 0;
     D->round = 0;
-    D->rq = nullptr; D->rq_rounds = 1;
+    D->rq = nullptr; D->rq_cap = 0; D->spec_words = nullptr; D->rq_policy = h->env_queue_policy; D->dbg_trace = nullptr;
     D->n = n; D->m = m;
 }
 
@@ -315,7 +333,7 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     if (h->params.polish || h->params.refine || h->params.probe_iters > 0) {  // OSQP's polish, opt-in (the refinement and the sliced solve use the same block): the solve kernels leave their ADMM state in pol_buf, polish_kernel picks it up
         const int sd = po_polish_state_doubles(in->formulation, in->N, C, in->keep);
         if (sd > 0) {  // (shapes on the single-level mapping have no polish kernel: status_polish stays 0 = not attempted)
-            if ((rc = h->pol_buf.ensure(sizeof(double) * (size_t)sd * (size_t)in->B))) return rc;
+            if ((rc = h->pol_buf.ensure(sizeof(double) * (size_t)sd * (size_t)in->B * 2))) return rc;  // (two state blocks per path: speculative continuations)
             D.pol_state = static_cast<double *>(h->pol_buf.p);
             D.pol_stride = sd;
             polish = true;
@@ -327,11 +345,17 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     }
     po::DevBatch DS = D;  // what the solve launches see (the polish launch keeps D: B workgroups, no queue)
     const int rounds_total = (h->params.refine_rounds > 1 ? h->params.refine_rounds : 1) + P.ref_extra;
-    if (h->params.refine && rounds_total > 1 && rounds_total < 64 && h->params.refine_chain && D.pol_state != nullptr && in->B < (1 << 24)) {
-        const size_t qints = 4 + (size_t)(rounds_total - 1) * (size_t)in->B;
-        if ((rc = h->rq_buf.ensure(sizeof(int) * 2 * qints))) return rc;
+    if (h->params.refine && rounds_total > 1 && rounds_total < 32 && h->params.refine_chain && D.pol_state != nullptr && in->B < (1 << 24)) {
+        // chained rounds: hand-backs and speculative continuations, at most one of each per path and round
+        const size_t cap = 2 * (size_t)(rounds_total - 1) * (size_t)in->B, qints = 8 + cap;  // (po_fast.inc: kRqHdr)
+        if ((rc = h->rq_buf.ensure(sizeof(int) * (2 * qints + 3 * (size_t)in->B)))) return rc;
         DS.rq = static_cast<int *>(h->rq_buf.p);
-        DS.rq_rounds = rounds_total;
+        DS.rq_cap = (int)cap;
+    }
+    if (h->env_queue_trace && DS.rq != nullptr) {  // dev: item timeline (po_debug_trace_read)
+        if ((rc = h->trace_buf.ensure(sizeof(long long) * (4 + 4 * 65000)))) return rc;
+        HIP_TRY(hipMemsetAsync(h->trace_buf.p, 0, sizeof(long long) * 4, h->stream));
+        DS.dbg_trace = static_cast<long long *>(h->trace_buf.p);
     }
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     // per-path equilibration (h->params.scaling class-level Ruiz passes; 0 -> identity), then the fused solve

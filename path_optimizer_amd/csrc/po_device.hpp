@@ -35,7 +35,7 @@ struct DevParams {
     int max_iter, check_every, adapt_every, end_heading;
     double pol_delta;           // OSQP delta
     int polish, pol_refine, pol_passes;
-    int refine, ref_every, ref_max_iter, ref_max_refactor, ref_rounds, ref_extra, ref_adapt;  // po_params.refine*
+    int refine, ref_every, ref_max_iter, ref_max_refactor, ref_rounds, ref_extra, ref_adapt, ref_spec;  // po_params.refine*
     int slice;              // po_params.probe_iters (0 with refine): iterations of the first launch pair
     double ref_rho, ref_eps;
 };
@@ -58,8 +58,11 @@ struct DevBatch {
     int use_split;          // launcher hint: take the stage-split two-wave mapping where it exists (keep 4, one-wave shapes; not with polish)
     double *pol_state;      // polish only: [B][pol_stride] per-lane ADMM state left by the solve kernels for polish_kernel (or nullptr)
     int pol_stride;
-    int rq_rounds;          // chained refinement rounds: the grid holds B * rq_rounds workgroups (see rq_wait in po_fast.inc)
-    int *rq;                // ... and this launch's device-side queue [4 + (rq_rounds - 1) * B] (nullptr: one launch pair per round)
+    long long *dbg_trace;   // dev: per-item timeline of the chained rounds (po_debug_set "queue_trace"), or nullptr
+    int rq_policy;          // chained refinement rounds: which item a workgroup prefers (rq_take)
+    int rq_cap;             // chained refinement rounds: entries of the queue; the grid holds B + rq_cap workgroups (see rq_take in po_fast.inc)
+    int *rq;                // ... and this launch's device-side queue [8 + rq_cap] (nullptr: one launch pair per round)
+    int *spec_words;        // ... and the verdict words of the speculative continuations [B][3] (po_fast.inc, spec_post)
 };
 
 template <int F> struct FormTraits;

@@ -64,12 +64,13 @@ PO_DECL(po_launch_solve_kp_ref); PO_DECL(po_launch_solve_kpc_ref); PO_DECL(po_la
 // then the general variant (po_fast.inc, solve_kernel_fast).
 extern "C" hipError_t po_launch_solve_round(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
 namespace po {
-// the two queues of a chained-rounds solve: tail = 0, pending = B, error = 0, entries = -1
+// the two queues of a chained-rounds solve (po_fast.inc, rq_take): tail = 0, pending = B, error = head = fresh = 0, entries = -1
 __global__ void rq_init_kernel(int *rq, int qints, int B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 2 * qints) return;
+    if (i >= 2 * qints + 3 * B) return;
+    if (i >= 2 * qints) { rq[i] = 0; return; }  // the verdict words of the speculative continuations
     const int k = i % qints;
-    rq[i] = k == 1 ? B : (k < 4 ? 0 : -1);
+    rq[i] = k == 1 ? B : (k < kRqHdr ? 0 : -1);
 }
 // After the launches of a solve that hands paths from launch to launch (refinement rounds, probe): no internal "in flight" status may reach the caller
 // (a path that a malformed caller-side order skipped, a chained follow-up block that gave up waiting): anything at or below kStatusDeferred becomes UNSOLVED.
@@ -94,12 +95,12 @@ extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po
     DevBatch rb = *in;
     if (P->refine && rounds > 1 && in->rq != nullptr) {
         // chained rounds (po_params.refine_chain): ONE launch pair, rounds * B workgroups each; in->rq = the two queues ([0]: uniform-variant launch, [1]: general
-        // one), in->rq_rounds = rounds.  See rq_wait in po_fast.inc.
-        const int qints = 4 + (rounds - 1) * in->B;
-        hipLaunchKernelGGL(rq_init_kernel, dim3((2 * qints + 255) / 256), dim3(256), 0, st, in->rq, qints, in->B);
+        // one) followed by the verdict words, in->rq_cap = entries per queue.  See rq_take in po_fast.inc.
+        const int qints = kRqHdr + in->rq_cap;
+        hipLaunchKernelGGL(rq_init_kernel, dim3((2 * qints + 3 * in->B + 255) / 256), dim3(256), 0, st, in->rq, qints, in->B);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
-        rb.round = 0; rb.rq_rounds = rounds;
+        rb.round = 0; rb.spec_words = in->rq + 2 * qints;
         if (form == F_KP) { e = po_launch_solve_kp_uni_ref(&rb, P, st, nullptr); rb.rq = in->rq + qints; if (e == hipSuccess) e = po_launch_solve_kp_ref(&rb, P, st, nullptr); }
         else if (form == F_KPC) { e = po_launch_solve_kpc_uni_ref(&rb, P, st, nullptr); rb.rq = in->rq + qints; if (e == hipSuccess) e = po_launch_solve_kpc_ref(&rb, P, st, nullptr); }
         else { e = po_launch_solve_k_uni_ref(&rb, P, st, nullptr); rb.rq = in->rq + qints; if (e == hipSuccess) e = po_launch_solve_k_ref(&rb, P, st, nullptr); }

@@ -94,7 +94,7 @@ namespace po {
 template <class K> hipError_t launch1(K kern, const DevBatch *in, const DevParams *P, int nt, size_t lds, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(in->rq != nullptr ? in->B * in->rq_rounds : in->B), dim3(nt), lds, st, *in, *P);
+    hipLaunchKernelGGL(kern, dim3(in->rq != nullptr ? in->B + in->rq_cap : in->B), dim3(nt), lds, st, *in, *P);
     return hipGetLastError();
 }
 // thread-block shape: NT threads x SPL stages per thread must cover N, and NT >= C (one control per thread).

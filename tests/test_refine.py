@@ -345,7 +345,8 @@ def test_device_probe_then_longest_first_is_bit_identical(form, cfg, B, probe_it
                                                   (0, 3, 64, 3, {"N": 231, "ds": 0.3})])
 def test_device_chained_rounds_are_bit_identical_to_one_launch_per_round(form, cfg, B, rounds, kw):
     """po_params.refine_chain (default 1): all refinement rounds inside ONE launch pair — a workgroup that does not certify its path pushes it onto a
-    device-side queue and a follow-up workgroup of the same launch resumes it (csrc/po_fast.inc: rq_wait / rq_push).  Scheduling only: every output — raw
+    device-side queue and another workgroup of the same launch resumes it (csrc/po_fast.inc: rq_take / rq_push); po_params.refine_speculate: the next
+    round's type-based iteration already runs beside a refinement and takes the path over when that one fails.  Scheduling only: every output — raw
     solution, states, every po_info field — is bit-identical to the version with one launch pair per round, also with a caller-supplied order and on a
     ragged batch with paths the uniform-variant launch defers to the general one."""
     from path_optimizer_amd import binding
@@ -355,10 +356,17 @@ def test_device_chained_rounds_are_bit_identical_to_one_launch_per_round(form, c
         b.n_points = np.full(B, b.N, dtype=np.int32); b.n_points[1::5] = b.N - 7; b.n_points[2::7] = b.N // 2
         b.bounds[3::4, 30:45, 0, :] = (-1e30, 1e30)
     res = {}
-    for chain in (0, 1):
+    for chain in (0, 1, "no-speculation", "speculate-from-0", "extra-rounds-reference", "extra-rounds"):
         p = binding.default_params()
-        assert p.refine_chain == 1
-        p.refine, p.refine_rounds, p.refine_chain = 1, rounds, chain
+        assert p.refine_chain == 1 and p.refine_speculate == 1
+        p.refine, p.refine_rounds, p.refine_chain = 1, rounds, 0 if chain in (0, "extra-rounds-reference") else 1
+        if chain == "no-speculation":
+            p.refine_speculate = -1
+        if chain == "speculate-from-0":
+            p.refine_speculate = 0
+        if chain in ("extra-rounds-reference", "extra-rounds"):  # with rounds below eps (the headline setting's shape): more hand-overs per path
+            p.refine_extra_rounds = 2
+            p.refine_speculate = 0
         eng = binding.Engine(0, p)
         res[chain] = eng.solve_batch(b, want_x=True)
         if chain == 1 and B > 2:
@@ -370,10 +378,11 @@ def test_device_chained_rounds_are_bit_identical_to_one_launch_per_round(form, c
     # (the half-length ragged paths of this batch include one whose end-heading window makes it infeasible-in-practice: it runs to max_iter in every
     # round structure, on the device and in the oracle alike — kept: the hand-over of a path that ends at max_iter is part of what is compared)
     assert (i0["status"] == 1).mean() >= 0.9 and set(np.unique(i0["status_refine"][i0["status"] == 1])) <= {1, -1}
-    for key in [k for k in res if k != 0]:
+    for key in [k for k in res if k not in (0, "extra-rounds-reference")]:
+        ref = res["extra-rounds-reference"] if key == "extra-rounds" else res[0]
         st1, i1, x1 = res[key]
-        assert i0.tobytes() == i1.tobytes(), (key, np.where(i0["iters"] != i1["iters"])[0])
-        assert np.array_equal(x0, x1) and np.array_equal(st0, st1), key
+        assert ref[1].tobytes() == i1.tobytes(), (key, np.where(ref[1]["iters"] != i1["iters"])[0], ref[1][ref[1]["iters"] != i1["iters"]], i1[ref[1]["iters"] != i1["iters"]])
+        assert np.array_equal(ref[2], x1) and np.array_equal(ref[0], st1), key
 
 
 @pytest.mark.gpu
