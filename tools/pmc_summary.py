@@ -10,7 +10,7 @@ for f in glob.glob(os.path.join(src, "trace", "*kernel_stats.csv")):
 if os.path.exists(os.path.join(src, "bench_trace.json")):
     shutil.copy(os.path.join(src, "bench_trace.json"), os.path.join(dst, "bench_under_rocprof.json"))
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, set()]))
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_f64"):
     for f in glob.glob(os.path.join(src, sub, "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0][:70]
@@ -18,7 +18,8 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
             a[0] += float(r["Counter_Value"]); a[1].add(r["Dispatch_Id"])
 out = {k: {c: {"sum": v[0], "dispatches": len(v[1]), "per_dispatch": v[0] / max(len(v[1]), 1)} for c, v in d.items()} for k, d in agg.items()}
 json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
-solve = (next((v for k, v in out.items() if "solve_kernel_fast<0, 4, 64, true, true" in k), None)  # uniform-row-class launch: the one that does the work
+solve = (next((v for k, v in out.items() if "solve_kernel_fast<0, 4, 64, true, true, true" in k), None)  # the headline: uniform-row-class launch with the refinement phase (chained rounds)
+         or next((v for k, v in out.items() if "solve_kernel_fast<0, 4, 64, true, true" in k), None)  # uniform-row-class launch: the one that does the work
          or next((v for k, v in out.items() if "solve_kernel_fast<0, 4, 64" in k), None) or next((v for k, v in out.items() if "solve_kernel" in k), None))  # the headline kernel (KP, SPL 4, one wave), not the pipeline legs' <0, 3, 128>
 if solve and "FETCH_SIZE" in solve and "WRITE_SIZE" in solve:
     fetch = solve["FETCH_SIZE"]["per_dispatch"] * 1024.0
@@ -33,9 +34,13 @@ if solve and "FETCH_SIZE" in solve and "WRITE_SIZE" in solve:
 if solve and "SQ_INSTS_VALU" in solve:
     # VALU wave-instructions per path-iteration: BASELINE config 3 = 4096 paths x 339.734 iterations per launch (po_info.iters, deterministic).
     # fp64 wave-instructions per path-iteration: static count of one plain iteration of the headline kernel (tools/isa_phase_hist.py; argv[3] if given).
-    it_sum = 4096 * 339.73388671875
+    ref = any("solve_kernel_fast<0, 4, 64, true, true, true" in k for k in out)
+    it_sum = 4096 * (171.25 if ref else 339.73388671875)  # headline setting (3 + 2 refinement rounds): 171.25 iterations per path, refinement iterations included
+    f64 = {c: solve[c]["per_dispatch"] for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64") if c in solve}
     v = {"valu_wave_instr_per_path_iter": solve["SQ_INSTS_VALU"]["per_dispatch"] / it_sum,
-         "fp64_wave_instr_per_path_iter": float(sys.argv[3]) if len(sys.argv) > 3 else None,
+         "fp64_wave_instr_per_path_iter": (sum(f64.values()) / it_sum) if f64 else (float(sys.argv[3]) if len(sys.argv) > 3 else None),
+         "fp64_flop_per_launch": 64.0 * (f64["SQ_INSTS_VALU_ADD_F64"] + f64["SQ_INSTS_VALU_MUL_F64"] + 2 * f64["SQ_INSTS_VALU_FMA_F64"] + f64["SQ_INSTS_VALU_TRANS_F64"]) if len(f64) == 4 else None,
+         "kernel": "solve_kernel_fast<0, 4, 64, true, true, " + ("true>" if ref else "false>"),
          "occupancy_waves_per_simd": 1,
          "sq_wave_cycles_per_path_iter": solve.get("SQ_WAVE_CYCLES", {}).get("per_dispatch", 0) * 4 / it_sum,
          "source": f"{dst}/pmc_summary.json (rocprofv3 --pmc SQ_INSTS_VALU ...) and the ISA histogram of the same tree (profiles/<tag>/phase_breakdown.txt)"}
