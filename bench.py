@@ -317,7 +317,7 @@ def stage_legs_gpu(torch, binding, synth, eng, stream, dbatch, B):
     st["full_pipeline"] = {"ms": ms_p, "instances_per_s": B / (ms_p * 1e-3), "ok_frac": float(po_["ok"].double().mean().item()),
                            "states_mean": float(po_["n_states"].double().mean().item()), "qp_iters_mean": float(pinf["iters"].mean()),
                            "workload": f"{B} planning instances (24 waypoints over ~70 m, 60-disc map 700 x 700 cells): bSpline -> TENSION2 QP -> DP search -> post QP -> "
-                                       "re-sampling (0.15..0.3 m) -> bounds -> KP QP -> collision check"}
+                                       "re-sampling (0.15..0.3 m) -> bounds -> KP QP -> collision check; engine at the HEADLINE setting (the path QP runs the chained refinement rounds)"}
     p3 = binding.default_params(); p3.eps_abs = p3.eps_rel = 1e-3  # the reference's own stopping point: it never touches OSQP's eps (default 1e-3)
     e4 = binding.Engine(torch.cuda.current_device(), p3); e4.set_map(*scn["map"])
     e4.plan_batch_device(tp, po_, Np, way_len); torch.cuda.synchronize()
@@ -582,7 +582,7 @@ def main():
     ap.add_argument("--no-stages", action="store_true", help="skip the legs for the stages around the QP (SURVEY.md §8f)")
     ap.add_argument("--no-configs", action="store_true", help="skip the quick legs for BASELINE configs 1, 2, 5 and the K formulation")
     ap.add_argument("--no-parity", action="store_true", help="skip the accuracy / parity legs")
-    ap.add_argument("--cpu-sample", type=int, default=2048, help="paths timed on the CPU oracle (rank 0, N=1 only; 0 = no CPU legs)")
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="paths timed on the CPU oracle (rank 0, N=1 only; 0 = no CPU legs)")
     ap.add_argument("--gather", action="store_true", help="N>1: gather every rank's states and info on rank 0 (SURVEY §8e collective 1) and report its time")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 PMC child passes that measure `roofline.traffic` in this run")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
