@@ -245,7 +245,7 @@ int po_set_stream(po_handle h, void *hip_stream);
  * "debug_cycles" (per-phase shader clocks of path 0 on stderr; makes the solve entry synchronous), "split" (stage-split two-wave mapping of the keep-4
  * kernel; PO_ERR_UNSUPPORTED unless the library was built with `make SPLIT=1`), "smooth_seq", "smooth_waves", "smooth_nopad", "smooth_debug" (smoothing-QP
  * engine variants), "dp_one_wave" (DP lattice search on one wave per instance whatever the batch size), "queue_policy" (chained refinement rounds: 0 = a workgroup takes a
- * fresh path before a hand-back, k >= 1 = hand-backs of round >= k first; scheduling only).  Unknown key: PO_ERR_INVALID. */
+ * fresh path before a hand-back, k >= 1 = hand-backs of round >= k first, -1 = automatic: 0, or 1 when the caller supplies po_batch_in.order; scheduling only).  Unknown key: PO_ERR_INVALID. */
 int po_debug_set(po_handle h, const char *key, int value);
 /* Developer tool: with po_debug_set(h, "queue_trace", 1), the item timeline of the last chained-rounds solve — records of 4 int64: path | round << 32 |
  * speculative << 40 | outcome << 48 (0 final, 1 handed back, 2 failed attempt handed to its continuation, 3 / 4 continuation cancelled), start, end

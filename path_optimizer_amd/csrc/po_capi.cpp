@@ -85,7 +85,7 @@ struct po_handle_s {
     // developer switches (po_debug_set; the library reads no environment variable): identity_order (block i solves path i), debug_cycles (per-phase shader
     // clocks of path 0 on stderr; synchronises), split (experimental stage-split mapping, only in builds made with `make SPLIT=1`), smoothing / DP-search A/B switches
     bool env_identity = false, env_cycles = false, env_split = false, env_smooth_seq = false, env_smooth_nopad = false, env_smooth_debug = false, env_dp_one_wave = false;
-    int env_smooth_waves = 0, env_queue_policy = 0;
+    int env_smooth_waves = 0, env_queue_policy = -1;  // queue_policy -1: automatic (fresh paths first; hand-backs first when the caller supplies an order)
     bool env_queue_trace = false;
     DevBuf trace_buf;
     DevBuf in_buf, out_buf, asm_buf, scale_buf, dbg_buf, map_buf, post_buf, coef_buf, bnd_buf, smooth_buf, smooth_io, plan_coef, plan_io, plan_arena, plan_host;
@@ -223,7 +223,7 @@ int po_debug_set(po_handle h, const char *key, int value) {
     else if (k == "smooth_debug") h->env_smooth_debug = value != 0;
     else if (k == "dp_one_wave") h->env_dp_one_wave = value != 0;
     else if (k == "queue_trace") h->env_queue_trace = value != 0;
-    else if (k == "queue_policy") h->env_queue_policy = value < 0 ? 0 : (value > 31 ? 31 : value);
+    else if (k == "queue_policy") h->env_queue_policy = value < 0 ? -1 : (value > 31 ? 31 : value);
     else return PO_ERR_INVALID;
     return PO_OK;
 }
@@ -305,7 +305,8 @@ static void fill_dev_batch(const po_handle_s *h, po::DevBatch *D, const po_batch
     D->pol_state = nullptr; D->pol_stride = 0;
     D->use_split = 0;
     D->round = 0;
-    D->rq = nullptr; D->rq_cap = 0; D->spec_words = nullptr; D->rq_policy = h->env_queue_policy; D->dbg_trace = nullptr;
+    D->rq = nullptr; D->rq_cap = 0; D->spec_words = nullptr; D->rq_policy = h->env_queue_policy >= 0 ? h->env_queue_policy : (in->order != nullptr ? 1 : 0);  // auto: with the caller's longest-first order, hand-backs first
+    D->dbg_trace = nullptr;
     D->n = n; D->m = m;
 }
 
