@@ -358,6 +358,8 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
         HIP_TRY(hipMemsetAsync(h->trace_buf.p, 0, sizeof(long long) * 4, h->stream));
         DS.dbg_trace = static_cast<long long *>(h->trace_buf.p);
     }
+    if (P.slice > 0 && D.pol_state != nullptr && D.order == nullptr)  // (before anything is enqueued: a failed allocation leaves no half-run batch behind)
+        if ((rc = h->ord_buf.ensure(sizeof(int) * (size_t)in->B))) return rc;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     // per-path equilibration (h->params.scaling class-level Ruiz passes; 0 -> identity), then the fused solve
     HIP_TRY(po_launch_scale(in->formulation, &D, &P, h->params.scaling, static_cast<double *>(h->scale_buf.p), h->stream));
@@ -379,7 +381,6 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
                 key[(size_t)b] = o.status == po::kStatusDeferred - 1 ? ((o.r_dual == o.r_dual && o.r_dual > 0) ? o.r_dual : 0.0) : -1.0;
             }
             std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return key[(size_t)a] > key[(size_t)b]; });  // largest dual residual first
-            if (int rc2 = h->ord_buf.ensure(sizeof(int) * (size_t)in->B)) return rc2;
             HIP_TRY(hipMemcpyAsync(h->ord_buf.p, ord.data(), sizeof(int) * ord.size(), hipMemcpyHostToDevice, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));  // (ord is a local)
             rb.order = static_cast<const int *>(h->ord_buf.p);

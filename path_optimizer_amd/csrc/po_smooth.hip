@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <utility>
 
 #include "../../include/po_hip.h"
 #define PO_MAP_DEVICE_CODE
@@ -48,6 +49,14 @@ constexpr int kKT = 4;  // a variable appears in at most 4 rows in all three QPs
 
 template <int W> __host__ __device__ constexpr int col_stride() { return (W + 2) & ~1; }  // dinv + W entries, padded to 16 bytes
 template <int W> __host__ __device__ constexpr int col_pad() { return 4 * W; }            // zero columns past n: the sweeps need no guards
+// Wide bands (W >= 8, TENSION): the factor is kept BLOCK-wise, W columns per block of blk_stride doubles — during the factorisation the W columns (LS doubles
+// each) at the head of their block, afterwards the two dense W x W matrices of the blocked substitution (band_solve_blocks) in their place.
+template <int W> __host__ __device__ constexpr int blk_stride() { return W >= 8 ? 2 * W * W : 0; }
+template <int W> __host__ __device__ constexpr size_t factor_doubles(size_t np, bool blocked) {  // LDS doubles of the factor storage for np columns (natural layout: np columns of col_stride)
+    const size_t nat = np * col_stride<W>();
+    if constexpr (W >= 8) { const size_t blk = (np + W - 1) / W * blk_stride<W>(); return blocked && blk > nat ? blk : nat; }
+    else return nat;
+}
 constexpr int kChunkPad = 72;  // doubles: one per chunk of the partitioned substitution (at most 64 chunks own rows, the zero padding columns reach a few further)
 // Rows per lane of the partitioned substitution (narrow bands, W <= 4): a multiple of W; 0 when the QP is too small to give every chunk W rows inside the
 // zero padding (the single-lane window then).  From 6 rows per lane on, the chunks are laid out bank-conflict-free (see Prob::cch); below that the natural
@@ -63,9 +72,9 @@ __host__ __device__ constexpr bool scan_padded(int c) { return c >= 6; }
 template <int KIND> struct Lds {
     using T = ST<KIND>;
     static constexpr int LS = col_stride<T::W>();
-    static __host__ __device__ size_t bytes(int P) {
+    static __host__ __device__ size_t bytes(int P, bool blocked) {  // blocked: wide bands in the block layout (band_solve_blocks), see po_smooth_blocked
         const size_t n = (size_t)T::n(P), m = (size_t)T::m(P), np = n + col_pad<T::W>();
-        size_t d = np * LS + (size_t)T::KA * m + n + np + 3 * m;  // Lb, Av, x, wk, v, l, u  (q and the dy / scaling scratch tm live in the HBM block)
+        size_t d = factor_doubles<T::W>(np, blocked) + (size_t)T::KA * m + n + np + 3 * m;  // Lb, Av, x, wk, v, l, u  (q and the dy / scaling scratch tm live in the HBM block)
         if constexpr (T::W <= 4) {
             if (scan_padded(scan_chunk<T::W>((int)n))) d += kChunkPad + np + kChunkPad;  // chunk-padded factor, wkp (the partitioned substitution's right-hand side)
         }
@@ -93,12 +102,13 @@ template <int KIND> struct Prob {  // views into LDS + scratch for one QP
     // cycles).  So the factor carries one dead double per chunk (lane stride cch LS + 1: odd) and the substitution works on wkp, a copy of wk with one dead
     // double per chunk when cch is even.  cch == 0: natural layout (single-lane substitution).
     int cch, wpad;
+    int bst;  // wide bands: block stride of the factor storage (blk_stride), 0 = natural layout (developer A/B: band_solve_lanes)
     float rcch;
     double *wkp;
     __device__ __forceinline__ int chunk_of(int j) const { return (int)(((float)j + 0.5f) * rcch); }  // j / cch, exact for j < 2^16
     __device__ __forceinline__ int lcol(int j) const {  // offset of factor column j in Lb
         if constexpr (W <= 4) return j * LS + (cch ? chunk_of(j) : 0);
-        else return j * LS;
+        else return bst ? (j / W) * bst + (j % W) * LS : j * LS;
     }
     __device__ __forceinline__ int pidx(int j) const { return j + chunk_of(j) * wpad; }  // offset of row j in wkp (cch != 0)
     __device__ __forceinline__ void setA(int r, int s, int col, double val) { Av[s * m + r] = val; Ac[s * m + r] = (uint16_t)col; }
@@ -207,6 +217,7 @@ template <int NWV> __device__ __forceinline__ void band_sync() {
     else { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 }
 
+template <int KIND, int NWV> __device__ void convert_blocks(Prob<KIND> &pb, int tid);
 template <int KIND, int NWV = 1> __device__ void factorise(Prob<KIND> &pb, double rho, double sigma, int tid, int lane) {  // tid: thread of the block; lane: lane of the block's serial wave (outside 0 .. 63 on the others) — the pivot loop works on lanes 0 .. W (W + 1) / 2 - 1
     using T = ST<KIND>;
     constexpr int W = T::W, KA = T::KA, WP = T::WP;
@@ -327,6 +338,7 @@ template <int KIND, int NWV = 1> __device__ void factorise(Prob<KIND> &pb, doubl
         for (int d = 0; d <= W; ++d) pb.Lb[pb.lcol(j) + d] = 0;
     }
     __syncthreads();
+    if constexpr (W >= 8) { if (pb.bst) convert_blocks<KIND, NWV>(pb, tid); }
 }
 
 // L D L' x = wk, in place, one lane.  Forward: column sweep with the W pending right-hand sides in registers; backward: row sweep.
@@ -395,71 +407,256 @@ template <int KIND> __device__ __forceinline__ void band_solve(Prob<KIND> &pb) {
     }
 }
 
-// L D L' x = wk, in place, on W + 0 cooperating lanes (lanes 0..W-1; the other lanes of the wave mirror lane 0 and store the same values).
-// The W pending right-hand sides of the sliding window live one per LANE instead of one per register of a single lane: at column j the owner lane
-// (j mod W) holds the finished y_j, every lane takes it with a v_readlane broadcast (the lane index is a compile-time constant after unrolling by W)
-// and applies ITS entry of factor column j — one FMA per lane per column instead of W on one lane; the owner then picks up the row that enters
-// the window.  The backward sweep is the same recursion on L' run column-wise from the far end (pending sums of the W rows below the current one).
-// Factor entries and the entering right-hand sides of the NEXT block of W columns are requested before the current block is processed.
 __device__ __forceinline__ double lane_bcast(double v, int k) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), k), hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
     return __hiloint2double(hi, lo);
 }
+
+// L D L' x = wk, in place, on W cooperating lanes, column by column (wide bands; natural factor layout).  Since round 3 the DEVELOPER A/B path of TENSION
+// (po_debug_set "smooth_seq" with one wave per QP; the product path is band_solve_blocks below) — the reference the blocked substitution is tested against.
+// Lane l holds the pending sum of one row; at column j the owner lane's value is final, every lane takes it with a v_readlane broadcast and applies its entry
+// of factor column j.  Round 2's form of this routine picked the entering row up in the same register — a v_cndmask pair between every two dependent FMAs —
+// and guarded every load of the backward sweep: 81 k cycles per solve at P = 100 (136 per column and sweep).  This form: 32.6 k (54 per column):
+//   * two registers per lane: wa = the row of the CURRENT block of W columns this lane owns (row j0 + l), wb = its row of the NEXT block (j0 + W + l).  At
+//     in-block column uu a lane updates exactly one of them (wa if its row is still ahead of the column, wb otherwise): two FMAs on every lane, the lane mask
+//     applied to the coefficient (see lane_fma2), no select between dependent FMAs; chain per column = v_readlane -> v_fma;
+//   * one coefficient per lane and column at a per-lane offset (loop-invariant) from the block base, 1/d and the entering right-hand side once per block:
+//     11 loads per block instead of 27, requested one whole block ahead into the other register set (ping-pong, no copies: the s_waitcnt counts);
+//   * a lane's finished value stays in wa until the end of the block: one store per block;
+//   * only the W working lanes run: an LDS access costs a quarter of the full-wave one.
+// Arithmetic: the same FMAs in the same order as round 2's routine (bit-identical to it when it was replaced).
+template <bool HASA> __device__ __forceinline__ void lane_fma2(double &wa, double &wb, double c, double y, bool ina) {
+    // wa <- wa - c y on the lanes with `ina`, wb <- wb - c y on the others: the lane mask goes into the COEFFICIENT (off the chain; c - ca is exact), both FMAs run
+    // on every lane.  (EXEC-masked FMAs — s_mov exec, v_fma, s_mov exec, v_fma, s_mov exec — measured 68 cycles per column: every instruction of the column
+    // waits for the one before it.)  The empty assembler statement keeps the compiler from turning the zero coefficient back into a select of the result.
+    if constexpr (HASA) {
+        double ca = ina ? c : 0.0;
+        asm volatile("" : "+v"(ca));
+        const double cb = c - ca;
+        wa = __builtin_fma(-ca, y, wa);
+        wb = __builtin_fma(-cb, y, wb);
+    } else {
+        wb = __builtin_fma(-c, y, wb);
+    }
+}
+template <int W> struct LaneSet { double c[W], dinv, bn; };
+template <int W, int UU> __device__ __forceinline__ void lanes_fwd_step(double &wa, double &wb, const LaneSet<W> &s, int l) {
+    lane_fma2<(UU < W - 1)>(wa, wb, s.c[UU], lane_bcast(wa, UU), l > UU);  // wa: lanes l > uu; wb: lanes l <= uu
+}
+template <int W, int UU> __device__ __forceinline__ void lanes_bwd_step(double &wa, double &wb, const LaneSet<W> &s, int l) {
+    lane_fma2<(UU > 0)>(wa, wb, s.c[UU], lane_bcast(wa, UU), l < UU);  // wa: lanes l < uu; wb: lanes l >= uu
+}
+template <int W, int... U> __device__ __forceinline__ void lanes_fwd_block(double &wa, double &wb, const LaneSet<W> &s, int l, std::integer_sequence<int, U...>) {
+    (lanes_fwd_step<W, U>(wa, wb, s, l), ...);
+}
+template <int W, int... U> __device__ __forceinline__ void lanes_bwd_block(double &wa, double &wb, const LaneSet<W> &s, int l, std::integer_sequence<int, U...>) {
+    (lanes_bwd_step<W, W - 1 - U>(wa, wb, s, l), ...);
+}
 template <int KIND> __device__ __forceinline__ void band_solve_lanes(Prob<KIND> &pb, int lane) {
     using T = ST<KIND>;
     constexpr int W = T::W, LS = Prob<KIND>::LS;
-    const int l = lane < W ? lane : 0;
-    const int nsteps = (pb.n + W - 1) / W * W;  // whole blocks of W columns; the zero padding (col_pad) covers the over-run
-    const double *__restrict__ Lb = pb.Lb;
-    double *__restrict__ wk = pb.wk;
-    int ent[W];  // this lane's entry of the factor column at in-block position uu: row offset d = (l - uu) mod W, d == 0 -> the entering row (offset W)
+    static_assert(W <= 16, "lane masks");
+    if (lane >= W) return;
+    const int l = lane;
+    const int nblk = (pb.n + W - 1) / W;  // whole blocks of W columns; the zero padding (col_pad) covers the over-run of the look-ahead
+    const double *Lb = pb.Lb;
+    double *wk = pb.wk;
+    constexpr auto seq = std::make_integer_sequence<int, W>{};
+    LaneSet<W> A, B;
+    // ---- forward: L y = b, stored as z = D^-1 y.  Column j0 + uu: row j0 + l takes L[j0 + l][j0 + uu] (l > uu), row j0 + W + l takes L[j0 + W + l][j0 + uu] (l <= uu) ----
+    {
+        int off[W];
 #pragma unroll
-    for (int uu = 0; uu < W; ++uu) { const int d = (l - uu + W) % W; ent[uu] = d == 0 ? W : d; }
-    // ---- forward: L y = b, then y <- D^-1 y (stored) ----
-    double w = wk[l];
-    double cf[W], bn[W], dn[W], cf2[W], bn2[W], dn2[W];
+        for (int uu = 0; uu < W; ++uu) off[uu] = uu * LS + (l - uu) + (l <= uu ? W : 0);
+        auto load = [&](LaneSet<W> &s, int j0) {
 #pragma unroll
-    for (int uu = 0; uu < W; ++uu) { cf[uu] = Lb[uu * LS + ent[uu]]; bn[uu] = wk[uu + W]; dn[uu] = Lb[uu * LS]; }
-    for (int j0 = 0; j0 < nsteps; j0 += W) {
-#pragma unroll
-        for (int uu = 0; uu < W; ++uu) { const int j = j0 + W + uu; cf2[uu] = Lb[j * LS + ent[uu]]; bn2[uu] = wk[j + W]; dn2[uu] = Lb[j * LS]; }
-#pragma unroll
-        for (int uu = 0; uu < W; ++uu) {
-            const double yj = lane_bcast(w, uu);
-            wk[j0 + uu] = yj * dn[uu];
-            w = (l == uu ? bn[uu] : w) - cf[uu] * yj;
+            for (int uu = 0; uu < W; ++uu) s.c[uu] = Lb[j0 * LS + off[uu]];
+            s.dinv = Lb[(j0 + l) * LS];
+            s.bn = wk[j0 + 2 * W + l];
+        };
+        double wa = wk[l], wb = wk[W + l];
+        load(A, 0);
+        int k = 0;
+        for (; k + 1 < nblk; k += 2) {
+            load(B, (k + 1) * W);
+            lanes_fwd_block<W>(wa, wb, A, l, seq);
+            wk[k * W + l] = wa * A.dinv; wa = wb; wb = A.bn;
+            load(A, (k + 2) * W);
+            lanes_fwd_block<W>(wa, wb, B, l, seq);
+            wk[(k + 1) * W + l] = wa * B.dinv; wa = wb; wb = B.bn;
         }
-#pragma unroll
-        for (int uu = 0; uu < W; ++uu) { cf[uu] = cf2[uu]; bn[uu] = bn2[uu]; dn[uu] = dn2[uu]; }
+        if (k < nblk) {
+            lanes_fwd_block<W>(wa, wb, A, l, seq);
+            wk[k * W + l] = wa * A.dinv;
+        }
     }
-    // ---- backward: L' x = y, column-wise from the end: lane (r mod W) holds z_r minus the contributions of the solved rows below r ----
-    // at row j the owner lane (j mod W) is final; lane l holds row j - d, d = (uu - l) mod W, and subtracts L[j][j - d] x_j = Lb[(j - d) LS + d] x_j;
-    // the owner (d == 0) then takes the row that enters the window, j - W, with its entry Lb[(j - W) LS + W].
-    int entb[W];
+    // ---- backward: L' x = z, column-wise from the end.  Column j0 + uu: row j0 + l takes L[j0 + uu][j0 + l] (l < uu), row j0 - W + l takes L[j0 + uu][j0 - W + l] (l >= uu) ----
+    {
+        int off[W];
 #pragma unroll
-    for (int uu = 0; uu < W; ++uu) { const int d = (uu - l + W) % W; entb[uu] = d == 0 ? W : d; }
-    w = wk[nsteps - W + l];
-    auto loadb = [&](int j0, double (&c)[W], double (&zn)[W]) {
+        for (int uu = 0; uu < W; ++uu) off[uu] = l < uu ? l * LS + (uu - l) : (l - W) * LS + (uu - l + W);
+        auto load = [&]<bool CL>(LaneSet<W> &s, int j0) {  // CL: the blocks at the start of the band have no rows below them — clamped into the array, never used
 #pragma unroll
-        for (int uu = 0; uu < W; ++uu) {
-            const int j = j0 + uu, r = j - entb[uu];
-            const bool ok = r >= 0;
-            const double cv = Lb[(ok ? r : 0) * LS + entb[uu]], zv = wk[j - W >= 0 ? j - W : 0];
-            c[uu] = ok ? cv : 0.0;
-            zn[uu] = j - W >= 0 ? zv : 0.0;
+            for (int uu = 0; uu < W; ++uu) { const int i = j0 * LS + off[uu]; s.c[uu] = Lb[CL ? (i > 0 ? i : 0) : i]; }
+            const int r = j0 - 2 * W + l;
+            s.bn = wk[CL ? (r > 0 ? r : 0) : r];
+        };
+        int j0 = (nblk - 1) * W;
+        double wa = wk[j0 + l], wb = wk[j0 - W + l > 0 ? j0 - W + l : 0];
+        load.template operator()<true>(A, j0);
+        int k = nblk - 1;
+        auto pair = [&]<bool CL>() {
+            load.template operator()<CL>(B, (k - 1) * W);
+            lanes_bwd_block<W>(wa, wb, A, l, seq);
+            wk[k * W + l] = wa; wa = wb; wb = A.bn;
+            load.template operator()<CL>(A, k >= 2 ? (k - 2) * W : 0);
+            lanes_bwd_block<W>(wa, wb, B, l, seq);
+            wk[(k - 1) * W + l] = wa; wa = wb; wb = B.bn;
+        };
+        for (; k >= 4; k -= 2) pair.template operator()<false>();  // (blocks k - 1 >= 3 and k - 2 >= 2: every index positive)
+        for (; k >= 1; k -= 2) pair.template operator()<true>();
+        if (k == 0) {
+            lanes_bwd_block<W>(wa, wb, A, l, seq);
+            wk[l] = wa;
         }
-    };
-    loadb(nsteps - W, cf, bn);
-    for (int j0 = nsteps - W; j0 >= 0; j0 -= W) {
-        loadb(j0 - W >= 0 ? j0 - W : 0, cf2, bn2);
+    }
+}
+
+
+// ---- wide bands, product path: BLOCKED substitution (round 3) ---------------------------------------------------------------------------------------------
+// With the columns taken W at a time the factor is block bidiagonal: L = [T_0; C_0 T_1; C_1 T_2; ...], T_k unit lower triangular (the band inside block k),
+// C_k upper triangular (rows of block k + 1 against the columns of block k), D = diag(D_k).  With r_k = T_k y_k,
+//     forward   r_0 = b_0,  r_{k+1} = b_{k+1} - M_k r_k,      M_k = C_k T_k^-1                 (dense W x W)
+//     backward  x_k = S_k r_k - M_k' x_{k+1},                  S_k = T_k^-T D_k^-1 T_k^-1       (dense, symmetric)
+// M_k and S_k depend on the factor only: convert_blocks builds them after every (re-)factorisation, in place of the block's columns.  A block then costs one
+// broadcast of W values (2 W v_readlane) and W FMAs on the chain instead of W dependent {v_readlane, v_readlane, v_fma} steps: a dependent v_fma_f64 ->
+// v_readlane -> v_fma_f64 step is 30 cycles on gfx950 (tools/ubench/chain.hip), a broadcast whose source does not depend on the FMA before it 9 per value.
+// g_k = S_k r_k rides on the forward broadcasts and is parked in wk; the backward sweep is the chain x_k = g_k - M_k' x_{k+1} alone.
+// Numerically this applies explicit inverses of the W x W unit triangles T_k (entries of an SPD band factor: well conditioned) — iterates agree with
+// band_solve_lanes to round-off, not bit for bit (tests/test_smooth.py bounds the difference and checks both against the oracle).
+template <int KIND, int NWV> __device__ void convert_blocks(Prob<KIND> &pb, int tid) {
+    using T = ST<KIND>;
+    constexpr int W = T::W, LS = Prob<KIND>::LS, BS = blk_stride<W>(), nts = 64 * NWV, BPR = nts / W;  // BPR: blocks per round, one thread per (block, column)
+    static_assert(W * LS + W * (W - 1) / 2 <= BS, "the inverse triangle is parked behind the block's columns");
+    const int nblk = (pb.n + W - 1) / W;
+    const int kl = tid / W, c = tid - kl * W;
+    for (int k0 = 0; k0 < nblk; k0 += BPR) {
+        const int k = k0 + kl;
+        const bool act = kl < BPR && k < nblk;
+        double *blk = pb.Lb + (size_t)(act ? k : 0) * BS;
+        double t[W], mc[W], sc[W];
+        // column c of T^-1 (zero above the diagonal): t_c = 1, t_i = - sum_{j < i} T[i][j] t_j
 #pragma unroll
-        for (int uu = W - 1; uu >= 0; --uu) {
-            const double xj = lane_bcast(w, uu);
-            wk[j0 + uu] = xj;
-            w = (l == uu ? bn[uu] : w) - cf[uu] * xj;
+        for (int i = 0; i < W; ++i) {
+            double acc = 0;
+#pragma unroll
+            for (int j = 0; j < i; ++j) acc -= blk[j * LS + (i - j)] * t[j];
+            t[i] = i == c ? 1.0 : (i < c ? 0.0 : acc);
         }
+        if (act) {
 #pragma unroll
-        for (int uu = 0; uu < W; ++uu) { cf[uu] = cf2[uu]; bn[uu] = bn2[uu]; }
+            for (int i = 1; i < W; ++i)
+                if (i > c) blk[W * LS + i * (i - 1) / 2 + c] = t[i];
+        }
+        __syncthreads();
+        // column c of M = C T^-1 (C[i][j] = L[W + i][j], j >= i) and of S = T^-T D^-1 T^-1
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            double acc = 0;
+#pragma unroll
+            for (int j = i; j < W; ++j) acc += blk[j * LS + (W + i - j)] * t[j];
+            mc[i] = acc;
+        }
+        double u[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) u[i] = blk[i * LS] * t[i];
+#pragma unroll
+        for (int a2 = 0; a2 < W; ++a2) {
+            double acc = u[a2];
+#pragma unroll
+            for (int i = a2 + 1; i < W; ++i) acc += blk[W * LS + i * (i - 1) / 2 + a2] * u[i];
+            sc[a2] = acc;
+        }
+        __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < W; ++i) { blk[i * W + c] = mc[i]; blk[W * W + i * W + c] = sc[i]; }
+        }
+        __syncthreads();
+    }
+}
+
+template <int W> struct BlkSet { double m[W], s[W], bn; };
+template <int W, int... U> __device__ __forceinline__ void blk_bcast(double (&y)[W], double v, std::integer_sequence<int, U...>) { ((y[U] = lane_bcast(v, U)), ...); }
+template <int W> __device__ __forceinline__ double blk_dot(const double (&c)[W], const double (&y)[W], double a0) {  // a0 - sum c y, three partial sums (a dependent v_fma_f64 is 10 cycles)
+    double a[3] = {a0, 0.0, 0.0};
+#pragma unroll
+    for (int uu = 0; uu < W; ++uu) a[uu % 3] = __builtin_fma(-c[uu], y[uu], a[uu % 3]);
+    return a[0] + (a[1] + a[2]);
+}
+template <int KIND> __device__ __forceinline__ void band_solve_blocks(Prob<KIND> &pb, int lane) {
+    using T = ST<KIND>;
+    constexpr int W = T::W, BS = blk_stride<W>();
+    if (lane >= W) return;
+    const int l = lane;
+    const int nblk = (pb.n + W - 1) / W;
+    const double *Mb = pb.Lb;
+    double *wk = pb.wk;
+    constexpr auto seq = std::make_integer_sequence<int, W>{};
+    // ---- forward: r_{k+1} = b_{k+1} - M_k r_k on the chain, g_k = S_k r_k beside it (row l of both matrices on lane l) ----
+    {
+        BlkSet<W> A, B;
+        auto load = [&](BlkSet<W> &s, int k) {  // (k == nblk: the look-ahead reads the block behind the last one — inside the padding, never used)
+            const double *mb = Mb + (size_t)k * BS + l * W;
+#pragma unroll
+            for (int uu = 0; uu < W; ++uu) { s.m[uu] = mb[uu]; s.s[uu] = mb[W * W + uu]; }
+            s.bn = wk[(k + 1) * W + l];
+        };
+        auto step = [&](const BlkSet<W> &s, int k, double &r) {
+            double y[W];
+            blk_bcast<W>(y, r, seq);
+            const double rn = blk_dot<W>(s.m, y, s.bn);
+            wk[k * W + l] = -blk_dot<W>(s.s, y, 0.0);
+            r = rn;
+        };
+        double r = wk[l];
+        load(A, 0);
+        int k = 0;
+        for (; k + 1 < nblk; k += 2) {
+            load(B, k + 1);
+            step(A, k, r);
+            load(A, k + 2);
+            step(B, k + 1, r);
+        }
+        if (k < nblk) step(A, k, r);
+    }
+    // ---- backward: x_k = g_k - M_k' x_{k+1} (column l of M_k on lane l); the last block's x is its g ----
+    {
+        struct Bk { double m[W], g; };
+        Bk A, B;
+        auto load = [&](Bk &s, int k) {
+            const int kk = k > 0 ? k : 0;
+            const double *mb = Mb + (size_t)kk * BS + l;
+#pragma unroll
+            for (int uu = 0; uu < W; ++uu) s.m[uu] = mb[uu * W];
+            s.g = wk[kk * W + l];
+        };
+        auto step = [&](const Bk &s, int k, double &x) {
+            double y[W];
+            blk_bcast<W>(y, x, seq);
+            x = blk_dot<W>(s.m, y, s.g);
+            wk[k * W + l] = x;
+        };
+        double x = wk[(nblk - 1) * W + l];
+        int k = nblk - 2;
+        load(A, k);
+        for (; k >= 1; k -= 2) {
+            load(B, k - 1);
+            step(A, k, x);
+            load(A, k - 2);
+            step(B, k - 1, x);
+        }
+        if (k == 0) step(A, 0, x);
     }
 }
 
@@ -796,7 +993,7 @@ template <int KIND, int NWV, int WPE> __global__ __launch_bounds__(64 * NWV, WPE
     // SIMDs by hand, measured 10 % slower: the dispatcher already does it)
     {
         double *dp = reinterpret_cast<double *>(smem_raw);
-        pb.Lb = dp; dp += (size_t)np * LS + (lds_pad ? kChunkPad : 0);
+        pb.Lb = dp; dp += factor_doubles<W>((size_t)np, a.blocked != 0) + (lds_pad ? kChunkPad : 0);
         pb.Av = dp; dp += KA * m;
         pb.x = dp; dp += n;
         pb.wk = dp; dp += np;
@@ -817,12 +1014,13 @@ template <int KIND, int NWV, int WPE> __global__ __launch_bounds__(64 * NWV, WPE
     // narrow bands (W = 3, 4): the substitution is partitioned over the lanes of a wave (chunks of c rows, c a multiple of W, every row's read-ahead inside
     // the zero padding); QPs too small to give every chunk W rows keep the single-lane window
     int cscan = 0;
-    pb.cch = 0; pb.wpad = 0; pb.rcch = 0;
+    pb.cch = 0; pb.wpad = 0; pb.rcch = 0; pb.bst = 0;
+    if constexpr (W >= 8) pb.bst = a.blocked ? blk_stride<W>() : 0;
     if constexpr (W <= 4) {
         cscan = a.seq_band ? 0 : scan_chunk<W>(n);
         if (lds_pad && scan_padded(cscan) && !a.nopad) { pb.cch = cscan; pb.wpad = (cscan & 1) ? 0 : 1; pb.rcch = 1.0f / (float)cscan; }
     }
-    for (int i = lane; i < np * LS + (lds_pad ? kChunkPad : 0); i += NTS) pb.Lb[i] = 0;  // (the P band is parked here in the natural layout until the first factorisation)
+    for (int i = lane; i < (int)factor_doubles<W>((size_t)np, a.blocked != 0) + (lds_pad ? kChunkPad : 0); i += NTS) pb.Lb[i] = 0;  // (the P band is parked here in the natural layout until the first factorisation)
     for (int i = lane; i < np; i += NTS) pb.wk[i] = 0;
     if (pb.wkp) for (int i = lane; i < np + kChunkPad; i += NTS) pb.wkp[i] = 0;
     for (int i = lane; i < n; i += NTS) { pb.x[i] = 0; pb.Tc[i] = 0; }
@@ -997,7 +1195,12 @@ template <int KIND, int NWV, int WPE> __global__ __launch_bounds__(64 * NWV, WPE
         PO_TICK(2);
         // wide bands (TENSION, W = 9): one pending row per lane, one FMA per lane and column (35 instead of 40 ms per 4096 QPs); narrow bands (W = 3, 4): the
         // single-lane window is as fast or faster (measured: TENSION2 14.6 vs 17.2 ms) — the column-to-column latency, not the FMA count, bounds both
-        if constexpr (ST<KIND>::W >= 8) { if (lane < 64) band_solve_lanes<KIND>(pb, lane); }
+        if constexpr (ST<KIND>::W >= 8) {
+            if (lane < 64) {
+                if (pb.bst) band_solve_blocks<KIND>(pb, lane);
+                else band_solve_lanes<KIND>(pb, lane);  // QPs whose block layout does not fit the LDS, and the developer A/B switch "smooth_seq"
+            }
+        }
         else {
             if (cscan) { if (NWV == 1 || lane < 64) band_solve_scan<KIND, NWV>(pb, lane, cscan); }
             else if (lane == 0) band_solve<KIND>(pb);
@@ -1234,11 +1437,16 @@ template <int KIND> static hipError_t launch_kind(const DevSmooth &a, hipStream_
 
 }  // namespace po
 
+// TENSION (W = 9): the block layout of the factor (band_solve_blocks) while two QPs of it fit a CU, the natural layout with the column-by-column
+// substitution beyond (P > 111: one QP per CU up to the 160 KB capacity).
+extern "C" int po_smooth_blocked(int kind, int P) {
+    return kind == PO_SMOOTH_TENSION && po::Lds<PO_SMOOTH_TENSION>::bytes(P, true) <= 80 * 1024 ? 1 : 0;
+}
 extern "C" size_t po_smooth_lds_bytes(int kind, int P) {
     switch (kind) {
-        case PO_SMOOTH_TENSION2: return po::Lds<PO_SMOOTH_TENSION2>::bytes(P);
-        case PO_SMOOTH_TENSION: return po::Lds<PO_SMOOTH_TENSION>::bytes(P);
-        case PO_SMOOTH_POST: return po::Lds<PO_SMOOTH_POST>::bytes(P);
+        case PO_SMOOTH_TENSION2: return po::Lds<PO_SMOOTH_TENSION2>::bytes(P, false);
+        case PO_SMOOTH_TENSION: return po::Lds<PO_SMOOTH_TENSION>::bytes(P, po_smooth_blocked(kind, P) != 0);
+        case PO_SMOOTH_POST: return po::Lds<PO_SMOOTH_POST>::bytes(P, false);
     }
     return 0;
 }
@@ -1250,8 +1458,11 @@ extern "C" size_t po_smooth_scratch_doubles(int kind, int P) {
     }
     return 0;
 }
-extern "C" hipError_t po_launch_smooth(const po::DevSmooth *a, hipStream_t st) {  // (po_smooth_lds_bytes counts the 64 static bytes too: the dynamic part is that minus 64)
-    const size_t lds = po_smooth_lds_bytes(a->kind, a->P);
+extern "C" hipError_t po_launch_smooth(const po::DevSmooth *a0, hipStream_t st) {  // (po_smooth_lds_bytes counts the 64 static bytes too: the dynamic part is that minus 64)
+    po::DevSmooth a1 = *a0;
+    a1.blocked = (po_smooth_blocked(a1.kind, a1.P) && !a1.seq_band) ? 1 : 0;
+    const po::DevSmooth *a = &a1;
+    const size_t lds = a1.kind == PO_SMOOTH_TENSION ? po::Lds<PO_SMOOTH_TENSION>::bytes(a1.P, a1.blocked != 0) : po_smooth_lds_bytes(a1.kind, a1.P);
     switch (a->kind) {
         case PO_SMOOTH_TENSION2: return po::launch_kind<PO_SMOOTH_TENSION2>(*a, st, lds);
         case PO_SMOOTH_TENSION: return po::launch_kind<PO_SMOOTH_TENSION>(*a, st, lds);

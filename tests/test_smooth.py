@@ -161,24 +161,29 @@ def engine(dmap):
     return e
 
 
-def _compare(kind, dev, orc, inp, tol=1e-7, frac=0.9):
+def _compare(kind, dev, orc, inp, tol=1e-7, frac=0.9, blocked=True):
     dx, dy, ds, dinfo, draw = dev
     ox, oy, os_, oinfo, oraw = orc
     assert np.array_equal(dinfo["status"], oinfo["status"]), (dinfo["status"], oinfo["status"])
     same = dinfo["iters"] == oinfo["iters"]
     assert same.mean() >= frac, (dinfo["iters"], oinfo["iters"])  # a residual within round-off of eps may flip one check
     assert np.array_equal(dinfo["n_refactor"][same], oinfo["n_refactor"][same])
-    err = np.abs(draw[same] - oraw[same]).max()
-    assert err < tol, err
-    assert np.abs(dx[same] - ox[same]).max() < tol
+    # kinds 0 and 2: every instance within tol.  Kind 1 (TENSION, W = 9): the device's blocked substitution applies explicit inverses of the 9 x 9 triangles of the
+    # factor (po_smooth.hip band_solve_blocks) — a few ulp more round-off per solve than the oracle's substitution, which the ADMM of a few badly conditioned
+    # instances amplifies over hundreds of iterations (measured on this file's batches: 3 of 40 instances beyond 1e-7, worst 7.4e-7 m on coordinates of 60 m;
+    # the column-by-column device path: worst 5e-8 on the same instance).  At least `frac` of the instances within tol, all within 20 tol (eps is 1e-3).
+    per = np.abs(draw - oraw).reshape(len(draw), -1).max(axis=1)[same]
+    wide = 20 * tol if (kind == 1 and blocked) else tol
+    assert per.max() < wide and (per < tol).mean() >= frac, (per.max(), (per < tol).mean())
+    assert np.abs(dx[same] - ox[same]).max() < wide
     if kind < 2:
-        assert np.abs(dy[same] - oy[same]).max() < tol and np.abs(ds[same] - os_[same]).max() < 10 * tol
+        assert np.abs(dy[same] - oy[same]).max() < wide and np.abs(ds[same] - os_[same]).max() < 10 * wide
     assert np.allclose(dinfo["rho"][same], oinfo["rho"][same], rtol=1e-4)  # the estimate is a ratio of small residuals
     assert np.allclose(dinfo["obj"][same], oinfo["obj"][same], rtol=1e-6, atol=1e-8)
     if (~same).any():  # a residual within round-off of eps flipped one termination check: those instances are compared at 10 x eps, not dropped
         assert (np.abs(dinfo["iters"].astype(int) - oinfo["iters"].astype(int))[~same] == 25).all()
         assert np.abs(dx[~same] - ox[~same]).max() < 1e-2 and np.abs(draw[~same] - oraw[~same]).max() < 1e-2
-    return err
+    return float(per.max())
 
 
 @pytest.mark.gpu
@@ -210,6 +215,12 @@ def test_device_ragged_and_shortest(engine, oracle, omap, kind):
     dev = engine.smooth_batch(kind, inp, want_raw=True)
     orc = oracle.smooth_batch(kind, oracle.default_params(), inp, m_map=omap, want_raw=True)
     _compare(kind, dev, orc, inp)
+    if kind == 1:  # the column-by-column substitution (developer switch) holds the tight bound on every instance
+        try:
+            engine.debug_set("smooth_seq", 1)
+            _compare(kind, engine.smooth_batch(kind, inp, want_raw=True), orc, inp, blocked=False)
+        finally:
+            engine.debug_set("smooth_seq", 0)
     for b in range(40):  # outputs beyond n_points are zero
         n = int(inp["n_points"][b])
         assert not dev[0][b, n:].any() and not dev[1][b, n:].any() and not dev[2][b, n:].any()
@@ -231,13 +242,20 @@ def test_device_matches_reference_fixtures(oracle, dmap, kind):
     inp = _gold_inputs(g, kind)
     dx, dy, ds, info, raw = eng.smooth_batch(kind, inp, want_raw=True)
     assert (info["status"] == PO_STATUS_SOLVED).all()
+    tol = 2e-6 if kind == 1 else 1e-7  # (kind 1: the blocked substitution's round-off, amplified by the ADMM — see _compare; measured worst 1.7e-7 here)
     for b in range(6):
         n_pts = int(inp["n_points"][b])
         n, _ = oracle.smooth_dims(kind, n_pts)
-        assert np.abs(raw[b, :n] - g[f"k{kind}_{b}_x"]).max() < 1e-7
+        assert np.abs(raw[b, :n] - g[f"k{kind}_{b}_x"]).max() < tol
         if kind < 2:
             ref = g[f"k{kind}_{b}_out"]
-            assert np.abs(dx[b, :n_pts] - ref[0]).max() < 1e-7 and np.abs(dy[b, :n_pts] - ref[1]).max() < 1e-7 and np.abs(ds[b, :n_pts] - ref[2]).max() < 1e-6
+            assert np.abs(dx[b, :n_pts] - ref[0]).max() < tol and np.abs(dy[b, :n_pts] - ref[1]).max() < tol and np.abs(ds[b, :n_pts] - ref[2]).max() < 10 * tol
+    if kind == 1:  # the column-by-column substitution (developer switch) at the tight bound
+        eng.debug_set("smooth_seq", 1)
+        raw1 = eng.smooth_batch(kind, inp, want_raw=True)[4]
+        for b in range(6):
+            n, _ = oracle.smooth_dims(kind, int(inp["n_points"][b]))
+            assert np.abs(raw1[b, :n] - g[f"k{kind}_{b}_x"]).max() < 1e-7
 
 
 @pytest.mark.gpu
@@ -312,7 +330,8 @@ def test_device_waves_per_qp_agree(engine, oracle, omap, kind, P):
     res = {}
     try:
         for tag, sw in (("1", {"smooth_waves": 1}), ("4", {"smooth_waves": 4}), ("8", {"smooth_waves": 8}), ("auto", {}),
-                        ("natural", {"smooth_waves": 1, "smooth_nopad": 1}), ("single-lane", {"smooth_waves": 4, "smooth_seq": 1})):
+                        ("natural", {"smooth_waves": 1, "smooth_nopad": 1}), ("single-lane", {"smooth_waves": 4, "smooth_seq": 1}),
+                        ("one-wave-seq", {"smooth_waves": 1, "smooth_seq": 1})):
             for k in ("smooth_waves", "smooth_nopad", "smooth_seq"):
                 engine.debug_set(k, sw.get(k, 0))
             res[tag] = engine.smooth_batch(kind, inp, want_raw=True)
@@ -324,7 +343,9 @@ def test_device_waves_per_qp_agree(engine, oracle, omap, kind, P):
         assert np.array_equal(res[tag][4], ref[4]), tag
         assert np.array_equal(res[tag][3]["iters"], ref[3]["iters"]) and np.array_equal(res[tag][3]["status"], ref[3]["status"]), tag
         assert np.array_equal(res[tag][0], ref[0]) and np.array_equal(res[tag][2], ref[2]), tag
-    for tag in ("natural", "single-lane"):  # same arithmetic per row up to the order of a sum
+    # wide band (kind 1, W = 9): "smooth_seq" runs the column-by-column substitution on the natural factor layout, the product path the blocked one (explicit
+    # inverses of the 9 x 9 triangles): same iterates to round-off
+    for tag in ("natural", "single-lane", "one-wave-seq"):  # same arithmetic per row up to the order of a sum
         assert np.array_equal(res[tag][3]["status"], ref[3]["status"]), tag
         same = res[tag][3]["iters"] == ref[3]["iters"]  # (a residual within round-off of eps may flip one termination check)
         assert same.mean() >= 0.9 and np.abs(res[tag][4][same] - ref[4][same]).max() < 1e-6, tag
