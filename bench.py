@@ -268,7 +268,7 @@ def stage_legs_gpu(torch, binding, synth, eng, stream, dbatch, B):
     from path_optimizer_amd.abi import INFO_BYTES, INFO_DTYPE
     sm = {}
     sm_inputs = {}
-    for name, kind, npts in (("tension2", 0, 100), ("post", 2, 60)):
+    for name, kind, npts in (("tension2", 0, 100), ("tension", 1, 100), ("post", 2, 60)):
         si = synth.make_smooth_inputs(30, 256, P=npts, kind=kind)
         sm_inputs[name] = (kind, si)
         tt = {k: torch.from_numpy(np.ascontiguousarray(np.concatenate([v] * reps, axis=0)[:B])).cuda() for k, v in si.items() if v is not None}
@@ -375,7 +375,7 @@ def stage_legs_cpu(st, ctx):
     st["cpu_port"] = {"bounds_paths_per_s": 64 / (c1 - c0), "post_check_paths_per_s": 64 / (c2 - c1), "cores": 1, "sample": "64 paths each, oracle (C)"}
     for name, (kind, si) in ctx["sm_inputs"].items():
         c3 = time.perf_counter()
-        oracle_py.smooth_batch(kind, p, {k: (None if v is None else v[:64]) for k, v in si.items()})
+        oracle_py.smooth_batch(kind, p, {k: (None if v is None else v[:64]) for k, v in si.items()}, m_map=m)
         st["cpu_port"][f"smoothing_{name}_qps_per_s"] = 64 / (time.perf_counter() - c3)
     spn, length, start, Lc = ctx["spn"], ctx["length"], ctx["start"], ctx["Lc"]
     c4 = time.perf_counter()

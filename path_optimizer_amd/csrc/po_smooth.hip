@@ -612,23 +612,29 @@ template <int KIND> __device__ __forceinline__ void band_solve_blocks(Prob<KIND>
             for (int uu = 0; uu < W; ++uu) { s.m[uu] = mb[uu]; s.s[uu] = mb[W * W + uu]; }
             s.bn = wk[(k + 1) * W + l];
         };
-        auto step = [&](const BlkSet<W> &s, int k, double &r) {
+        // One block: broadcast r, then — once this set's first value is known to have arrived — request the OTHER set (the block after this one), then the
+        // arithmetic.  The compiler's s_waitcnt inside a loop waits for every outstanding LDS request at the first use of a loaded register; placed here, all
+        // that is outstanding is this block's own set, requested a whole block earlier.
+        auto step = [&](const BlkSet<W> &s, BlkSet<W> &other, int k, double &r, bool ahead) {
             double y[W];
             blk_bcast<W>(y, r, seq);
+            asm volatile("" ::"v"(s.m[0]));
+            __builtin_amdgcn_sched_barrier(0);
+            if (ahead) load(other, k + 1);
+            __builtin_amdgcn_sched_barrier(0);
             const double rn = blk_dot<W>(s.m, y, s.bn);
             wk[k * W + l] = -blk_dot<W>(s.s, y, 0.0);
             r = rn;
         };
         double r = wk[l];
+        asm volatile("" : "+v"(r));
         load(A, 0);
         int k = 0;
         for (; k + 1 < nblk; k += 2) {
-            load(B, k + 1);
-            step(A, k, r);
-            load(A, k + 2);
-            step(B, k + 1, r);
+            step(A, B, k, r, true);
+            step(B, A, k + 1, r, true);
         }
-        if (k < nblk) step(A, k, r);
+        if (k < nblk) step(A, B, k, r, false);
     }
     // ---- backward: x_k = g_k - M_k' x_{k+1} (column l of M_k on lane l); the last block's x is its g ----
     {
@@ -641,22 +647,25 @@ template <int KIND> __device__ __forceinline__ void band_solve_blocks(Prob<KIND>
             for (int uu = 0; uu < W; ++uu) s.m[uu] = mb[uu * W];
             s.g = wk[kk * W + l];
         };
-        auto step = [&](const Bk &s, int k, double &x) {
+        auto step = [&](const Bk &s, Bk &other, int k, double &x, bool ahead) {
             double y[W];
             blk_bcast<W>(y, x, seq);
+            asm volatile("" ::"v"(s.m[0]));
+            __builtin_amdgcn_sched_barrier(0);
+            if (ahead) load(other, k - 1);
+            __builtin_amdgcn_sched_barrier(0);
             x = blk_dot<W>(s.m, y, s.g);
             wk[k * W + l] = x;
         };
         double x = wk[(nblk - 1) * W + l];
+        asm volatile("" : "+v"(x));
         int k = nblk - 2;
         load(A, k);
         for (; k >= 1; k -= 2) {
-            load(B, k - 1);
-            step(A, k, x);
-            load(A, k - 2);
-            step(B, k - 1, x);
+            step(A, B, k, x, true);
+            step(B, A, k - 1, x, true);
         }
-        if (k == 0) step(A, 0, x);
+        if (k == 0) step(A, B, 0, x, false);
     }
 }
 
