@@ -22,6 +22,8 @@
 static int g_portable_math = 0;
 void po_oracle_set_portable_math(int on) { g_portable_math = on != 0; }
 int po_oracle_get_portable_math(void) { return g_portable_math; }
+static int g_refine_trace = 0; /* developer aid: one stderr line per refinement block and round (tools/refine_trace.py) */
+void po_oracle_set_refine_trace(int on) { g_refine_trace = on != 0; }
 double po_oracle_psin(double x) { return po_psin(x); }
 double po_oracle_pcos(double x) { return po_pcos(x); }
 double po_oracle_patan2(double y, double x) { return po_patan2(y, x); }
@@ -31,6 +33,7 @@ double po_oracle_patan2(double y, double x) { return po_patan2(y, x); }
 #define MPOW15(x) (g_portable_math ? po_ppow15(x) : pow((x), 1.5))
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1245,6 +1248,7 @@ resume_main:
                 dn = dn > nPx ? dn : nPx;
                 stop = pri_res < prm->refine_eps + prm->refine_eps * (nz > nAx ? nz : nAx) && dua_res < prm->refine_eps + prm->refine_eps * cinv * dn;
             }
+            if (g_refine_trace) fprintf(stderr, "  refine round %d it %d nfac %d changed %d rb %.3g  r_prim %.3e r_dual %.3e%s\n", round, it2, nfac, changed, rb, pri_res, dua_res, stop ? "  CERTIFIED" : "");
             if (stop || it2 >= cap_it) break;
             if (prm->refine_adapt && !changed) {
                 /* refine_adapt: OSQP's rho estimate (compute_rho_estimate's balance of the relative residuals; here on the unscaled ones this test has just
@@ -1259,6 +1263,7 @@ resume_main:
                 if (rn > prm->adapt_tol * rb || rn < rb / prm->adapt_tol) rb_next = rn;
             }
         }
+        if (g_refine_trace) fprintf(stderr, "round %d: type-based iterations so far %d, refinement %d its %d refactorisations -> %s (r_prim %.3e r_dual %.3e; entered at %.3e %.3e)\n", round, iter, it2, nfac, stop ? "certified" : "not certified", pri_res, dua_res, pri0, dua0);
         refine_its += it2;
         refine_fac += nfac;
         info->iters = iter + refine_its;

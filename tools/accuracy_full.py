@@ -22,7 +22,13 @@ SETTINGS = [
     ("refine, rounds 2 + 3 below eps, chained", dict(refine=1, refine_rounds=2, refine_extra_rounds=3)),
     ("refine, rounds 4 + 2 below eps, chained", dict(refine=1, refine_rounds=4, refine_extra_rounds=2)),
     ("refine, 1 round + 2 below eps, chained", dict(refine=1, refine_rounds=1, refine_extra_rounds=2)),
+    ("headline + adapt_tol 3", dict(refine=1, refine_rounds=3, refine_extra_rounds=2, adapt_tol=3.0)),
+    ("headline + adapt_tol 2", dict(refine=1, refine_rounds=3, refine_extra_rounds=2, adapt_tol=2.0)),
+    ("headline + adapt_tol 1.5", dict(refine=1, refine_rounds=3, refine_extra_rounds=2, adapt_tol=1.5)),
+    ("OSQP default + adapt_tol 2", dict(adapt_tol=2.0)),
 ]
+if os.environ.get("PO_ACC_ONLY"):
+    SETTINGS = [s for s in SETTINGS if any(k in s[0] for k in os.environ["PO_ACC_ONLY"].split(","))]
 
 
 def main():
