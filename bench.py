@@ -279,6 +279,18 @@ def stage_legs_gpu(torch, binding, synth, eng, stream, dbatch, B):
         n_q, m_q = binding.smooth_dims(kind, npts)
         sm[name] = {"ms": ms_s, "qps_per_s": B / (ms_s * 1e-3), "qp_iters_per_s": float(inf["iters"].sum()) / (ms_s * 1e-3), "iters_mean": float(inf["iters"].mean()),
                     "iters_max": int(inf["iters"].max()), "unsolved": int((inf["status"] != 1).sum()), "points": npts, "n": n_q, "m": m_q}
+        if kind == 1:
+            # TENSION reads the clearance of every way point from the map; the 60-disc map of the stage legs puts way points inside discs (unsolved at max_iter above).
+            # Beside it: the map of tests/test_smooth.py and tools/smooth_bench.py, at the reference's own OSQP eps (1e-3, its default) and at the bench's.
+            for eps_s in (1e-3, 1e-4):
+                ps = binding.default_params(); ps.eps_abs = ps.eps_rel = eps_s
+                e2 = binding.Engine(torch.cuda.current_device(), ps); e2.set_stream(stream.cuda_stream)
+                e2.set_map(*synth.make_distance_map(3)[:4])
+                ms2 = timed(lambda: e2.smooth_batch_device(kind, tt, so))
+                inf2 = so["info"].cpu().numpy().view(INFO_DTYPE).reshape(-1)
+                sm[name]["synthetic_map_eps_%g" % eps_s] = {"ms": ms2, "qps_per_s": B / (ms2 * 1e-3), "iters_mean": float(inf2["iters"].mean()), "iters_max": int(inf2["iters"].max()),
+                                                            "unsolved": int((inf2["status"] != 1).sum())}
+                e2.close()
     st["smoothing_qps"] = sm
     spn, length, start = synth.make_search_inputs(9, nb)
     rp = lambda a: torch.from_numpy(np.ascontiguousarray(np.concatenate([a] * reps, axis=0)[:B])).cuda()
