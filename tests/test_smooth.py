@@ -354,6 +354,37 @@ def test_device_waves_per_qp_agree(engine, oracle, omap, kind, P):
 
 
 @pytest.mark.gpu
+def test_device_tension_full_batch_blocked_against_column_by_column(engine):
+    """4096 TENSION QPs of 100 points (the size the stage is measured on; 256 distinct instances): the blocked substitution and the column-by-column one give the
+    same statuses and iteration counts on every instance and the same points to 2e-6; QPs of more points than the block layout's LDS budget allows (P = 160: natural
+    layout, column-by-column substitution on eight waves) agree with one wave per QP bit for bit."""
+    base = synth.make_smooth_inputs(30, 256, P=100, kind=1)
+    inp = {k: (None if v is None else np.concatenate([v] * 16)) for k, v in base.items()}
+    res = {}
+    try:
+        for tag, seq in (("blocked", 0), ("columns", 1)):
+            engine.debug_set("smooth_seq", seq)
+            res[tag] = engine.smooth_batch(1, inp, want_raw=True)
+    finally:
+        engine.debug_set("smooth_seq", 0)
+    a, b = res["blocked"], res["columns"]
+    assert (a[3]["status"] == PO_STATUS_SOLVED).all() and np.array_equal(a[3]["status"], b[3]["status"])
+    assert np.array_equal(a[3]["iters"], b[3]["iters"]) and np.array_equal(a[3]["n_refactor"], b[3]["n_refactor"])
+    assert np.abs(a[4] - b[4]).max() < 2e-6 and np.abs(a[0] - b[0]).max() < 2e-6
+    assert np.array_equal(a[4][:256], a[4][256:512]) and np.array_equal(a[4][:256], a[4][-256:])  # the same instance gives the same bits wherever it sits in the batch
+    from path_optimizer_amd import binding
+    assert binding.lib().po_smooth_blocked(1, 100) == 1 and binding.lib().po_smooth_blocked(1, 160) == 0 and binding.lib().po_smooth_blocked(0, 100) == 0
+    big = synth.make_smooth_inputs(31, 6, P=160, kind=1)
+    try:
+        engine.debug_set("smooth_waves", 1)
+        one = engine.smooth_batch(1, big, want_raw=True)
+    finally:
+        engine.debug_set("smooth_waves", 0)
+    auto = engine.smooth_batch(1, big, want_raw=True)
+    assert (auto[3]["status"] == PO_STATUS_SOLVED).all() and np.array_equal(auto[4], one[4]) and np.array_equal(auto[3]["iters"], one[3]["iters"])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", [0, 2])
 def test_device_chunk_layout_transitions(engine, oracle, omap, kind):
     """Sizes either side of every change in the partitioned substitution: single-lane window (tiny QPs), natural layout (fewer than 6 rows per lane),
