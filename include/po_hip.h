@@ -145,7 +145,9 @@ typedef struct po_params {
                                            round (every round ends with a chip-wide barrier). */
     int    refine_extra_rounds;         /* 0.  E > 0: a path that the last regular round does not certify at refine_eps continues BELOW eps — type-based iteration at
                                            eps / 10, refinement again, eps / 100, ... — for up to E more rounds (full refinement budget each).  A path returned after
-                                           them is certified, or satisfies OSQP's test at eps / 10^E.  For the handful of nearly flat QPs on which the activity-set
+                                           them is certified, or satisfies OSQP's test at eps / 10^E — or ran out of max_iter in one of these rounds on a point that still passes OSQP's
+                                           test at eps: such a path is PO_STATUS_SOLVED with status_refine -1 (it met eps in the last regular round; a round below eps never
+                                           turns a solved path into MAX_ITER).  For the handful of nearly flat QPs on which the activity-set
                                            iteration cycles (BASELINE config 3: 11 of 4096 paths): they are the ones left > 0.1 m from the optimum at eps. */
     int    refine_adapt;                /* 1.  OSQP's adaptive-rho rule (balance of the relative residuals, applied when the estimate leaves [rho / adapt_tol, rho x adapt_tol])
                                            on the refinement's own rho, after a block of refine_every iterations that kept its step vector.  Once the activity set has

@@ -1045,7 +1045,7 @@ int po_oracle_qp_solve_ext(int n, int m, const int *Pp0, const int *Pi0, const d
     /* refine_extra_rounds = E: a path the LAST regular round does not certify goes on below eps — type-based iteration at eps / 10, refinement, eps / 100, ...
      * up to E more rounds (each with the full refinement budget) */
     const int rounds_total = rounds + (prm->refine && prm->refine_extra_rounds > 0 ? prm->refine_extra_rounds : 0);
-    int round = 0, refine_its = 0, refine_fac = 0;
+    int round = 0, refine_its = 0, refine_fac = 0, exhausted = 0;
     double eps_mul = 1.0;
     for (int r_ = 1; r_ < rounds; ++r_) eps_mul *= 10.0;
 resume_main:
@@ -1095,11 +1095,13 @@ resume_main:
         }
         if (can_check || iter == prm->max_iter) {
             double nz = vnorm_inf_scaled(Einv, z, m), nAx = vnorm_inf_scaled(Einv, Axv, m);
-            double eps_prim = eps_mul * (prm->eps_abs + prm->eps_rel * (nz > nAx ? nz : nAx));
+            const double eps_prim_u = prm->eps_abs + prm->eps_rel * (nz > nAx ? nz : nAx); /* at the caller's eps (eps_mul = 1) */
+            double eps_prim = eps_mul * eps_prim_u;
             double nq = vnorm_inf_scaled(Dinv, q, n), nAty = vnorm_inf_scaled(Dinv, Aty, n), nPx = vnorm_inf_scaled(Dinv, Pxv, n);
             double dn = nq > nAty ? nq : nAty;
             dn = dn > nPx ? dn : nPx;
-            double eps_dual = eps_mul * (prm->eps_abs + prm->eps_rel * cinv * dn);
+            const double eps_dual_u = prm->eps_abs + prm->eps_rel * cinv * dn;
+            double eps_dual = eps_mul * eps_dual_u;
             int prim_ok = pri_res < eps_prim, dual_ok = dua_res < eps_dual; /* strict, as OSQP */
             int prim_inf = 0, dual_inf = 0;
             if (!prim_ok) { /* is_primal_infeasible */
@@ -1148,6 +1150,9 @@ resume_main:
             if (prim_ok && dual_ok) { info->status = PO_STATUS_SOLVED; break; }
             if (prim_inf) { info->status = PO_STATUS_PRIMAL_INFEASIBLE; break; }
             if (dual_inf) { info->status = PO_STATUS_DUAL_INFEASIBLE; break; }
+            /* a round BELOW eps (refine_extra_rounds) that runs out of iterations: the path met the caller's eps in the last regular round — if the iterate it ends
+             * on still does, it is solved (not certified: status_refine stays -1), and no further refinement is attempted */
+            if (iter == prm->max_iter && round >= rounds && pri_res < eps_prim_u && dua_res < eps_dual_u) { info->status = PO_STATUS_SOLVED; exhausted = 1; break; }
         }
         if (can_adapt) { /* compute_rho_estimate + adapt_rho (scaled-space quantities) */
             double pr = pri_res_s / (pri_norm_s + 1e-10);
@@ -1178,7 +1183,7 @@ resume_main:
     info->r_dual = dua_res;
     info->rho = rho;
     /* ---- refinement (po_params.refine; extension, not OSQP): the same ADMM iteration continued with the step vector set by activity (see po_hip.h) ---- */
-    if (prm->refine && info->status == PO_STATUS_SOLVED) {
+    if (prm->refine && info->status == PO_STATUS_SOLVED && !exhausted) {
         double rb = prm->refine_rho < OSQP_RHO_MIN ? OSQP_RHO_MIN : (prm->refine_rho > OSQP_RHO_MAX ? OSQP_RHO_MAX : prm->refine_rho);
         double rb_next = rb;
         const int every = prm->refine_every > 0 ? prm->refine_every : 10;

@@ -417,3 +417,45 @@ def test_device_status_refine_says_what_was_certified(oracle):
     assert info["status"][1] == binding.PO_STATUS_NON_FINITE if hasattr(binding, "PO_STATUS_NON_FINITE") else info["status"][1] == -8
     assert info["status_refine"][1] == 0 and (st[1] == 0).all() and (xs[1] == 0).all()  # defined outputs (zeros), never the buffer's previous content
     assert (info["status"][[0, 2, 3]] == 1).all()
+
+
+def _exhausted_case():
+    """Config-3 paths 2400 .. 2415 hold path 2410, whose refinement attempts cycle: with max_iter = 700 it meets eps in the last regular round
+    (575 type-based iterations), fails that round's attempt and runs out of iterations in the first round below eps."""
+    return synth.make_batch(3, B=16, first_path=2400), dict(refine=1, refine_rounds=3, refine_extra_rounds=2, max_iter=700)
+
+
+def test_oracle_round_below_eps_out_of_iterations_keeps_the_path_solved(oracle):
+    """A path that met the caller's eps in the last regular round is SOLVED whatever the rounds below eps do: when one of those runs out of iterations on a point that
+    still passes OSQP's test at eps, the status is solved, status_refine -1 (not certified), and no further attempt runs."""
+    b, kw = _exhausted_case()
+    p = oracle.device_equivalent_params()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    _, info, _ = oracle.solve_batch(b, p, want_x=True)
+    assert (info["status"] == 1).all(), info["status"]
+    i = 10  # path 2410
+    assert info["status_refine"][i] == -1 and info["iters"][i] > 700  # 700 type-based iterations + the failed attempts'
+    eps = 1e-4
+    assert info["r_prim"][i] < eps * 10 and info["r_dual"][i] < eps * 1e3  # OSQP's relative test at eps held (norms of order 1 .. 1e3)
+    # (without the rule this path read MAX_ITER, although a plain solve at the same eps and budget solves it)
+    p0 = oracle.device_equivalent_params(); p0.max_iter = 700
+    _, i0, _ = oracle.solve_batch(b, p0, want_x=True)
+    assert i0["status"][i] == 1 and i0["iters"][i] == 575
+
+
+@pytest.mark.gpu
+def test_device_round_below_eps_out_of_iterations_matches_the_oracle(oracle):
+    from path_optimizer_amd import binding
+
+    b, kw = _exhausted_case()
+    for chain in (1, 0):
+        p = binding.default_params()
+        for k, v in dict(kw, refine_chain=chain).items():
+            setattr(p, k, v)
+        st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
+        ost, oinfo, oxs = oracle.solve_batch(b, oracle.device_equivalent_params(p), want_x=True)
+        assert (info["status"] == 1).all() and np.array_equal(info["status"], oinfo["status"])
+        assert np.array_equal(info["status_refine"], oinfo["status_refine"]) and info["status_refine"][10] == -1
+        same = info["iters"] == oinfo["iters"]
+        assert same[10] and same.mean() >= 0.8 and np.abs(xs[same] - oxs[same]).max() < 1e-6
