@@ -286,9 +286,10 @@ int po_densify_batch_device(po_handle h, int B, int N, const int *n_points, cons
 /* ---- corridor-bounds producer: ReferencePath::updateBounds -> ReferencePathImpl::updateBoundsImproved,
  * src/data_struct/reference_path_impl.cpp:142-201 (+ getApproxState :121-140, getClearanceWithDirectionStrict :283-472 with
  * FLAGS_enable_simple_boundary_decision = true as shipped, tk::spline src/tools/spline.cpp).  Needs po_set_map.
- * UNSUPPORTED FLAG VALUE: FLAGS_enable_simple_boundary_decision = false (the second branch of getClearanceWithDirectionStrict, :317-383, which consults the
- * pre-smoothing spline set by setOriginalSpline — a setter nothing in the reference ever calls) has no device implementation and no po_params field: this entry
- * always computes the shipped default.  A caller that runs the reference with that flag cleared must keep its CPU bounds producer and hand po_batch_in.bounds over.
+ * FLAGS_enable_simple_boundary_decision (src/config/planning_flags.cpp:84): no po_params field, because it has no effect in the reference either — the branch it
+ * selects in getClearanceWithDirectionStrict (:322) also requires is_original_spline_set, and ReferencePath::setOriginalSpline (reference_path.cpp:95) has no caller
+ * anywhere in the reference: the reference-compiled producer returns bit-identical bounds for both values (tests/test_bounds.py).  Only a caller that patches the
+ * reference to CALL setOriginalSpline and clears the flag gets bounds this entry does not produce; such a caller keeps its CPU producer and hands po_batch_in.bounds over.
  * Inputs per path: the N reference states (x, y, heading, s) and the K knots (s, x, y) the path's x(s) / y(s) splines were set
  * from (tk::spline::set_points, natural boundary conditions — what ReferencePath::setSpline receives).
  * Outputs: bounds [B][N][4][2] = (lb, ub) of the four covering circles, directly consumable as po_batch_in.bounds, and

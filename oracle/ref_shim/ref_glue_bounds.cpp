@@ -34,6 +34,13 @@ void po_ref_spline_eval(int K, const double *ks, const double *kv, int n, const 
     for (int i = 0; i < n; ++i) out[i] = s(at[i]);
 }
 
+// FLAGS_enable_simple_boundary_decision of the reference-compiled code (default true, src/config/planning_flags.cpp:84); returns the previous value
+int po_ref_set_simple_boundary_decision(int on) {
+    const int prev = FLAGS_enable_simple_boundary_decision ? 1 : 0;
+    FLAGS_enable_simple_boundary_decision = on != 0;
+    return prev;
+}
+
 // One path: reference states + the knots its x(s), y(s) splines were set from -> bounds [n_valid][4][2] (lb, ub).
 int po_ref_bounds_path(const po_map *m, int N, const double *ref_x, const double *ref_y, const double *ref_z, const double *ref_s, int K,
                        const double *ks, const double *kx, const double *ky, double *bounds /*[N][4][2]*/) {

@@ -68,6 +68,32 @@ def test_oracle_matches_reference_live(oracle, scene):
         assert on == rn and np.abs(ob - rb).max() < 1e-12
 
 
+
+def test_reference_flag_simple_boundary_decision_is_a_no_op(oracle, scene):
+    """FLAGS_enable_simple_boundary_decision = false selects, in getClearanceWithDirectionStrict, a branch that ALSO requires is_original_spline_set
+    (reference_path_impl.cpp:322) — and ReferencePath::setOriginalSpline has no caller anywhere in the reference.  So the flag changes nothing: the reference-compiled
+    producer gives bit-identical bounds for both values, on paths whose covering circles do start inside obstacles (one-sided corridors: lb and ub of the same sign).
+    Which is why po_bounds_batch* has no such switch."""
+    ref_py = pytest.importorskip("oracle.ref_py")
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("reference tree not present")
+    L = ref_py.lib_bounds()
+    P = synth.make_spline_paths(11, 12, 150)
+    one_sided = 0
+    try:
+        for b in range(12):
+            a = [P[k][b] for k in GB.KEYS]
+            assert L.po_ref_set_simple_boundary_decision(1) in (0, 1)
+            rb1, rn1 = ref_py.bounds_path(scene["m"], *a)
+            L.po_ref_set_simple_boundary_decision(0)
+            rb0, rn0 = ref_py.bounds_path(scene["m"], *a)
+            assert rn0 == rn1 and np.array_equal(rb0, rb1)
+            v = rb1[:rn1]
+            one_sided += int(((v[..., 0] > 0) | (v[..., 1] < 0)).sum())
+    finally:
+        L.po_ref_set_simple_boundary_decision(1)
+    assert one_sided > 0  # the in-collision branches were taken
+
 # ------------------------------------------------------------------ GPU ------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def binding():
