@@ -1,4 +1,4 @@
-"""Dev tool (GPU box): latency of the reference-smoothing QP engine on small batches, one, four and eight waves per QP (PO_SMOOTH_WAVES) and the automatic choice."""
+"""Dev tool (GPU box): latency of the reference-smoothing QP engine on small batches, one, four and eight waves per QP (po_debug_set "smooth_waves") and the automatic choice."""
 import os, sys, time
 import numpy as np
 import torch
@@ -17,7 +17,7 @@ for kind, P in ((1, 100), (1, 250)) if os.environ.get("KIND1") else ((0, 100), (
         t = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in rep.items() if v is not None}
         res_ = {}
         for one in ("1", "4", "8", "0", "n1", "n4"):
-            os.environ["PO_SMOOTH_WAVES"] = one.lstrip("n"); os.environ["PO_SMOOTH_NOPAD"] = "1" if one[0] == "n" else "0"
+            eng.debug_set("smooth_waves", int(one.lstrip("n"))); eng.debug_set("smooth_nopad", 1 if one[0] == "n" else 0)
             out = dict(x=torch.zeros((B, P), dtype=torch.float64, device="cuda"), y=torch.zeros((B, P), dtype=torch.float64, device="cuda"),
                        s=torch.zeros((B, P), dtype=torch.float64, device="cuda"), info=torch.zeros((B, INFO_BYTES), dtype=torch.uint8, device="cuda"))
             eng.smooth_batch_device(kind, t, out); torch.cuda.synchronize()
