@@ -158,6 +158,20 @@ typedef struct po_params {
                                            path does anyway when the refinement fails (it then returns to that point).  A refinement that certifies (or improves) the
                                            point cancels the continuation; one that fails hands the path to it.  Takes the failed attempts of the hardest paths — up to
                                            600 refinement iterations each on BASELINE config 3 — off the launch's critical path.  -1: off. */
+    /* refine = 2 (round 4): the refinement phase is a GLOBALISED method instead of the activity-weighted ADMM continuation of refine = 1 — semismooth Newton on
+     * the augmented Lagrangian  phi_y(x) = 1/2 x'Px + sum_i rho_i / 2 dist^2(a_i x + y_i / rho_i, [l_i, u_i])  (rho_i = refine_newton_rho on inequality rows, 1e3 x
+     * that on equality rows, scaled problem) with an EXACT line search on the piecewise-quadratic merit (safeguarded Newton on its piecewise-linear derivative),
+     * and a multiplier update  y <- rho (w - clip(w))  whenever the inner problem is solved to the dual tolerance.  Each Newton step is ONE factorisation of the same
+     * block-tridiagonal matrix the ADMM iteration uses, with the rows outside their bounds at rho_i and the others at OSQP's RHO_MIN (exactly the matrix of
+     * refine = 1), one solve, and a few row passes for the line search.  Without the line search the activity set cycles (that is the failure mode of refine = 1 on
+     * ~0.3 % of BASELINE config 3, and of a repeated polish); with it the method is monotone in phi and terminates finitely.  Certification, status_refine, the
+     * rounds, the chained scheduling and the hand-back rules are those of refine = 1; po_info.iters counts a Newton step as one iteration. */
+    double refine_newton_rho;           /* 1e3 (scaled problem) */
+    double refine_newton_rho_max;       /* 1e5: a multiplier update that does not cut the primal residual by 4 raises the penalty 10 x, up to this (the slow
+                                           case: active rows that are nearly dependent through the heavily weighted curvature-rate variables) */
+    double refine_ls_tol;               /* 1e-4: the line search stops at |psi'(t)| <= tol |psi'(0)| */
+    int    refine_ls_max;               /* 30: evaluations of psi' per line search at most */
+    int    refine_newton_max;           /* 100: Newton steps per attempt (every round) */
 } po_params;
 
 typedef struct po_info {

@@ -100,6 +100,7 @@ void po_oracle_default_params(po_params *p) {
     p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-7; p->refine_rounds = 1; p->probe_iters = 0;  /* (probe_iters: device scheduling only, no effect on results) */
     p->refine_chain = 1; /* device scheduling only */
     p->refine_extra_rounds = 0; p->refine_adapt = 1; p->refine_speculate = 1; /* (device scheduling only) */
+    p->refine_newton_rho = 1e3; p->refine_newton_rho_max = 1e5; p->refine_ls_tol = 1e-4; p->refine_ls_max = 30; p->refine_newton_max = 100; /* refine = 2 */
 }
 
 /* tools.hpp:24-35 — recursive in the reference; same fixed point as this loop */
@@ -1188,12 +1189,103 @@ resume_main:
         double rb_next = rb;
         const int every = prm->refine_every > 0 ? prm->refine_every : 10;
         int nfac = 0, it2 = 0, frozen = 0, stop = 0;
+        (void)frozen;
         const int cap_it = round + 1 < rounds ? (prm->refine_max_iter / 4 > every ? prm->refine_max_iter / 4 : every) : prm->refine_max_iter;
         double *snap = (double *)malloc(sizeof(double) * (size_t)(n + 2 * m)); /* the solved point: kept if the phase does not end at least as well */
         const double pri0 = pri_res, dua0 = dua_res;
         memcpy(snap, x, sizeof(double) * (size_t)n);
         memcpy(snap + n, z, sizeof(double) * (size_t)m);
         memcpy(snap + n + m, y, sizeof(double) * (size_t)m);
+        if (prm->refine == 2) {
+            /* ---- refine = 2: semismooth Newton on the augmented Lagrangian with an exact line search (po_hip.h).  State: x and w_i = a_i x + y_i / rho_i
+             * (one number per row, like the engine's v); implied z = clip(w), y = rho (w - z).  rho_i: rb on inequality rows, 1e3 rb on equality rows. ---- */
+            double rn_ = prm->refine_newton_rho;
+            rn_ = rn_ < OSQP_RHO_MIN ? OSQP_RHO_MIN : (rn_ > OSQP_RHO_MAX ? OSQP_RHO_MAX : rn_);
+            double rb_in = rn_, rb_eq = OSQP_RHO_EQ_OVER_INEQ * rn_, pri_outer = -1.0;
+            const int cap_nw = prm->refine_newton_max > 0 ? prm->refine_newton_max : 100;
+            const int ls_max = prm->refine_ls_max > 0 ? prm->refine_ls_max : 30;
+            double *w = (double *)malloc(sizeof(double) * (size_t)(m + 1)), *sv = (double *)malloc(sizeof(double) * (size_t)(m + 1));
+            double *dv = (double *)malloc(sizeof(double) * (size_t)n), *Pd = (double *)malloc(sizeof(double) * (size_t)n);
+            int first_fac = 1, nouter = 0, fail = 0;
+            csc_mv(n, m, Ap0, Ai0, Ax, x, Axv);
+            for (int i = 0; i < m; ++i) w[i] = Axv[i] + (ctype[i] == 0 ? y[i] / rb_in : (ctype[i] == 1 ? y[i] / rb_eq : 0.0));
+            for (;;) {
+                /* the point (x, z = clip(w), y = rho (w - z)) and OSQP's test on it at refine_eps; the dual residual IS the gradient of the merit */
+                csc_mv(n, m, Ap0, Ai0, Ax, x, Axv);
+                for (int i = 0; i < m; ++i) {
+                    z[i] = w[i] < l[i] ? l[i] : (w[i] > u[i] ? u[i] : w[i]);
+                    y[i] = (ctype[i] == 0 ? rb_in : (ctype[i] == 1 ? rb_eq : 0.0)) * (w[i] - z[i]);
+                }
+                sym_mv(n, Pp0, Pi0, Px, x, Pxv);
+                csc_mtv(n, Ap0, Ai0, Ax, y, Aty);
+                for (int i = 0; i < m; ++i) tm[i] = Axv[i] - z[i];
+                for (int i = 0; i < n; ++i) tn[i] = Pxv[i] + q[i] + Aty[i];
+                pri_res = vnorm_inf_scaled(Einv, tm, m);
+                dua_res = cinv * vnorm_inf_scaled(Dinv, tn, n);
+                const double nz = vnorm_inf_scaled(Einv, z, m), nAx = vnorm_inf_scaled(Einv, Axv, m);
+                const double nAty = vnorm_inf_scaled(Dinv, Aty, n), nPx = vnorm_inf_scaled(Dinv, Pxv, n), nq = vnorm_inf_scaled(Dinv, q, n);
+                double dn = nq > nAty ? nq : nAty;
+                dn = dn > nPx ? dn : nPx;
+                const int dual_ok = dua_res < prm->refine_eps + prm->refine_eps * cinv * dn;
+                stop = dual_ok && pri_res < prm->refine_eps + prm->refine_eps * (nz > nAx ? nz : nAx);
+                if (g_refine_trace) fprintf(stderr, "  newton round %d step %d outer %d nfac %d  r_prim %.3e r_dual %.3e%s\n", round, it2, nouter, nfac, pri_res, dua_res, stop ? "  CERTIFIED" : "");
+                if (stop || it2 >= cap_nw) break;
+                if (dual_ok) { /* the inner problem is solved: multiplier update, w <- A x + (w - clip(w)) */
+                    if (++nouter > 50) break;
+                    /* a multiplier update that did not cut the primal residual by 4: the penalty grows 10 x (the multipliers stay, w is re-expressed) */
+                    double ratio = 1.0;
+                    if (pri_outer >= 0.0 && pri_res > 0.25 * pri_outer && rb_in * 10.0 <= prm->refine_newton_rho_max) { ratio = 0.1; rb_in *= 10.0; rb_eq *= 10.0; first_fac = 1; }
+                    pri_outer = pri_res;
+                    for (int i = 0; i < m; ++i) w[i] = Axv[i] + ratio * (w[i] - z[i]);
+                    continue;
+                }
+                /* Newton step: rows outside their bounds at rho_i, the others at RHO_MIN (the matrix of refine = 1) */
+                int changed = first_fac;
+                for (int i = 0; i < m; ++i) {
+                    const double r = ctype[i] == -1 ? OSQP_RHO_MIN : (ctype[i] == 1 ? rb_eq : ((w[i] < l[i] || w[i] > u[i]) ? rb_in : OSQP_RHO_MIN));
+                    if (r != rho_vec[i]) { rho_vec[i] = r; changed = 1; }
+                }
+                if (changed) {
+                    for (int i = 0; i < m; ++i) { rho_inv[i] = 1.0 / rho_vec[i]; K.Kx[K.rho_pos[i]] = -rho_inv[i]; }
+                    if (ldl_numeric(&F, K.Kp, K.Ki, K.Kx)) { free(w); free(sv); free(dv); free(Pd); free(snap); rc = PO_ERR_INVALID; goto done; }
+                    ++nfac;
+                    first_fac = 0;
+                }
+                for (int i = 0; i < n; ++i) rhs[pinv[i]] = -tn[i];
+                for (int i = 0; i < m; ++i) rhs[pinv[n + i]] = 0.0;
+                ldl_solve(&F, rhs);
+                for (int i = 0; i < n; ++i) dv[i] = rhs[pinv[i]];
+                csc_mv(n, m, Ap0, Ai0, Ax, dv, sv);
+                sym_mv(n, Pp0, Pi0, Px, dv, Pd);
+                /* psi'(t) = c0 + c1 t + sum over inequality rows of rb (w + t s - clip(w + t s)) s: the equality rows are linear in t */
+                double c0 = 0, c1 = 0;
+                for (int i = 0; i < n; ++i) { c0 += dv[i] * (Pxv[i] + q[i]); c1 += dv[i] * Pd[i]; }
+                for (int i = 0; i < m; ++i)
+                    if (ctype[i] == 1) { c0 += rb_eq * (w[i] - z[i]) * sv[i]; c1 += rb_eq * sv[i] * sv[i]; }
+                double t = 1.0, lo = 0.0, hi = -1.0, f0 = 0.0;
+                for (int ev = -1; ev < ls_max; ++ev) { /* ev = -1: psi'(0) */
+                    const double tt = ev < 0 ? 0.0 : t;
+                    double f = c0 + c1 * tt, fp = c1;
+                    for (int i = 0; i < m; ++i)
+                        if (ctype[i] == 0) {
+                            const double ww = w[i] + tt * sv[i];
+                            if (ww < l[i]) { f += rb_in * (ww - l[i]) * sv[i]; fp += rb_in * sv[i] * sv[i]; }
+                            else if (ww > u[i]) { f += rb_in * (ww - u[i]) * sv[i]; fp += rb_in * sv[i] * sv[i]; }
+                        }
+                    if (ev < 0) { f0 = f; if (!(f0 < 0.0)) { fail = 1; break; } continue; }
+                    if (fabs(f) <= prm->refine_ls_tol * fabs(f0)) break;
+                    if (f < 0) lo = t; else hi = t;
+                    double tnx = fp > 0 ? t - f / fp : -1.0;
+                    if (!(tnx > lo && (hi < 0 || tnx < hi))) tnx = hi < 0 ? 2.0 * t : 0.5 * (lo + hi);
+                    t = tnx;
+                }
+                if (fail) break; /* not a descent direction (rounding at the bottom of the merit): the attempt ends uncertified */
+                for (int i = 0; i < n; ++i) x[i] += t * dv[i];
+                for (int i = 0; i < m; ++i) w[i] += t * sv[i];
+                ++it2;
+            }
+            free(w); free(sv); free(dv); free(Pd);
+        } else
         for (;;) {
             /* step vector from the bound type (as set_rho_vec) and, for inequality rows, from activity: z at a bound with a multiplier of the matching sign.
              * Once the refactorisation budget is spent (an active set that keeps flipping) the vector goes back to the type-based one and stays. */

@@ -38,6 +38,8 @@ struct DevParams {
     int refine, ref_every, ref_max_iter, ref_max_refactor, ref_rounds, ref_extra, ref_adapt, ref_spec;  // po_params.refine*
     int slice;              // po_params.probe_iters (0 with refine): iterations of the first launch pair
     double ref_rho, ref_eps;
+    double ref_nw_rho, ref_nw_rho_max, ref_ls_tol;  // po_params.refine = 2 (Newton refinement)
+    int ref_ls_max, ref_nw_max;
 };
 
 struct DevBatch {
@@ -390,7 +392,7 @@ struct RhsFn {
 // Specialised rhs functor of the two-level hot loop.  UNI: every lane's rows have the same class pattern, so the per-row
 // step rho~_r = W_r * {rho, rho_eq, rho_min}[class_r] is a wave-uniform number prepared once per pass (rr[]), instead of a
 // 2-bit decode + two selects per row and stage.  FIRST: compile-time version of the cold-start special case (z^0 = 0).
-template <bool UNI, bool FIRST, int NR> struct RhsFnX {
+template <bool UNI, bool FIRST, int NR, bool NWT = false> struct RhsFnX {  // NWT: Newton refinement (refine = 2), t = rho (clip(v) - v): minus the gradient
     double g[5];
     const double *v;
     int stride;
@@ -405,11 +407,70 @@ template <bool UNI, bool FIRST, int NR> struct RhsFnX {
     template <int MASK, class TL, class TU> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, TL l, TU u) {
         const double rw = UNI ? rr[r] : class_rho(cls, r, W[r], rho, rho_eq);
         const double vv = v[r * stride];
-        const double t = FIRST ? -(rw * vv) : rw * (2.0 * clipd(vv, l, u) - vv);
+        const double t = FIRST ? -(rw * vv) : (NWT ? rw * (clipd(vv, l, u) - vv) : rw * (2.0 * clipd(vv, l, u) - vv));
         const double c[5] = {c0, c1, c2, c3, c4};
 #pragma unroll
         for (int a = 0; a < 5; ++a)
             if (MASK >> a & 1) g[a] += t * c[a];
+    }
+};
+// ---- Newton refinement (po_params.refine = 2): v holds w = a.x + y / rho ----
+// v <- a.x + ratio (v - clip(v)): the multiplier update (ratio = 1), a change of penalty (ratio = rho_old / rho_new), the entry from the ADMM state
+struct NwReexFn {
+    double x[5];
+    double *v;
+    double ratio;
+    template <int MASK, class TL, class TU> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, TL l, TU u) {
+        const double c[5] = {c0, c1, c2, c3, c4};
+        double ax = 0;
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+            if (MASK >> a & 1) ax += c[a] * x[a];
+        const double vv = v[r];
+        v[r] = ax + ratio * (vv - clipd(vv, l, u));
+    }
+};
+// the Newton direction d on one stage's rows, s = a.d.  MODE 0: the part of psi'(t) that is linear in t — rows that are equalities by TYPE:
+// c0 += rho_eq (v - b) s, c1 += rho_eq s^2.  MODE 1: the step, v += t s.
+template <int MODE> struct NwDirFn {
+    double xt[5];
+    double *v;
+    double t, rho_eq, c0, c1;
+    unsigned cls_type;
+    const double *W;
+    template <int MASK, class TL, class TU> __device__ __forceinline__ void row(int r, double k0, double k1, double k2, double k3, double k4, TL l, TU u) {
+        const double c[5] = {k0, k1, k2, k3, k4};
+        double s = 0;
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+            if (MASK >> a & 1) s += c[a] * xt[a];
+        if constexpr (MODE == 0) {
+            if (((cls_type >> (2 * r)) & 3u) == 1u) {
+                const double rw = W[r] * rho_eq, vv = v[r];
+                c0 += rw * (vv - clipd(vv, l, u)) * s;
+                c1 += rw * s * s;
+            }
+        } else v[r] += t * s;
+    }
+};
+// one evaluation of the line search: the inequality rows (by TYPE) at x + t d:  f += rho (w - clip(w)) s,  fp += rho s^2 where w = v + t s is outside its bounds
+struct NwLsFn {
+    double xt[5];
+    const double *v;
+    double t, rho, f, fp;
+    unsigned cls_type;
+    const double *W;
+    template <int MASK, class TL, class TU> __device__ __forceinline__ void row(int r, double k0, double k1, double k2, double k3, double k4, TL l, TU u) {
+        if (((cls_type >> (2 * r)) & 3u) != 0u) return;
+        const double c[5] = {k0, k1, k2, k3, k4};
+        double s = 0;
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+            if (MASK >> a & 1) s += c[a] * xt[a];
+        const double ww = v[r] + t * s, dl = ww - clipd(ww, l, u);
+        const double rw = W[r] * rho;
+        f += rw * dl * s;
+        fp += dl != 0.0 ? rw * s * s : 0.0;
     }
 };
 template <bool FIRST> struct UpdFnX {

@@ -58,7 +58,17 @@ PO_DECL(po_launch_solve_kpc); PO_DECL(po_launch_solve_kpc_uni);
 PO_DECL(po_launch_solve_k); PO_DECL(po_launch_solve_k_uni);
 PO_DECL(po_launch_solve_kp_uni_ref); PO_DECL(po_launch_solve_kpc_uni_ref); PO_DECL(po_launch_solve_k_uni_ref);
 PO_DECL(po_launch_solve_kp_ref); PO_DECL(po_launch_solve_kpc_ref); PO_DECL(po_launch_solve_k_ref);
+PO_DECL(po_launch_solve_kp_uni_nw); PO_DECL(po_launch_solve_kpc_uni_nw); PO_DECL(po_launch_solve_k_uni_nw);
+PO_DECL(po_launch_solve_kp_nw); PO_DECL(po_launch_solve_kpc_nw); PO_DECL(po_launch_solve_k_nw);
 #undef PO_DECL
+// the launch pair (uniform-row-class variant, general variant) of the kernels with a refinement phase: po_params.refine = 2 -> the Newton phase
+typedef hipError_t (*po_launch_fn)(const po::DevBatch *, const po::DevParams *, hipStream_t, size_t *);
+static void po_ref_pair(int form, int refine, po_launch_fn *uni, po_launch_fn *gen) {
+    const bool nw = refine == 2;
+    if (form == po::F_KP) { *uni = nw ? po_launch_solve_kp_uni_nw : po_launch_solve_kp_uni_ref; *gen = nw ? po_launch_solve_kp_nw : po_launch_solve_kp_ref; }
+    else if (form == po::F_KPC) { *uni = nw ? po_launch_solve_kpc_uni_nw : po_launch_solve_kpc_uni_ref; *gen = nw ? po_launch_solve_kpc_nw : po_launch_solve_kpc_ref; }
+    else { *uni = nw ? po_launch_solve_k_uni_nw : po_launch_solve_k_uni_ref; *gen = nw ? po_launch_solve_k_nw : po_launch_solve_k_ref; }
+}
 
 // Two launches on the same stream for the two-level mapping: the uniform-row-class variant first (solves what it can, defers the rest),
 // then the general variant (po_fast.inc, solve_kernel_fast).
@@ -101,9 +111,9 @@ extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         rb.round = 0; rb.spec_words = in->rq + 2 * qints;
-        if (form == F_KP) { e = po_launch_solve_kp_uni_ref(&rb, P, st, nullptr); rb.rq = in->rq + qints; if (e == hipSuccess) e = po_launch_solve_kp_ref(&rb, P, st, nullptr); }
-        else if (form == F_KPC) { e = po_launch_solve_kpc_uni_ref(&rb, P, st, nullptr); rb.rq = in->rq + qints; if (e == hipSuccess) e = po_launch_solve_kpc_ref(&rb, P, st, nullptr); }
-        else { e = po_launch_solve_k_uni_ref(&rb, P, st, nullptr); rb.rq = in->rq + qints; if (e == hipSuccess) e = po_launch_solve_k_ref(&rb, P, st, nullptr); }
+        po_launch_fn uni, gen;
+        po_ref_pair(form, P->refine, &uni, &gen);
+        e = uni(&rb, P, st, nullptr); rb.rq = in->rq + qints; if (e == hipSuccess) e = gen(&rb, P, st, nullptr);
         return e;
     }
     rb.rq = nullptr;
@@ -123,9 +133,9 @@ extern "C" hipError_t po_launch_finalize_status(po_info *info, int B, hipStream_
 extern "C" hipError_t po_launch_solve_round(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st) {
     using namespace po;
     hipError_t e;
-    if (form == F_KP) { e = po_launch_solve_kp_uni_ref(in, P, st, nullptr); if (e == hipSuccess) e = po_launch_solve_kp_ref(in, P, st, nullptr); }
-    else if (form == F_KPC) { e = po_launch_solve_kpc_uni_ref(in, P, st, nullptr); if (e == hipSuccess) e = po_launch_solve_kpc_ref(in, P, st, nullptr); }
-    else { e = po_launch_solve_k_uni_ref(in, P, st, nullptr); if (e == hipSuccess) e = po_launch_solve_k_ref(in, P, st, nullptr); }
+    po_launch_fn uni, gen;
+    po_ref_pair(form, P->refine, &uni, &gen);
+    e = uni(in, P, st, nullptr); if (e == hipSuccess) e = gen(in, P, st, nullptr);
     return e;
 }
 

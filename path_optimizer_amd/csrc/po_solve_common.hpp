@@ -133,7 +133,7 @@ inline bool resolve_shape(int form, int N, int C, int keep, Shape *s) {
 template <int F> inline bool has_uni_variant(const Shape &s) { return s.two && (F != F_K || s.nt == 64); }  // K: one-wave blocks only (Fast::classify)
 // REF: kernels that carry the refinement phase (po_params.refine) around the loop — every variant exists with and without (the phase costs the hot loop
 // a few % even when it is not taken); those with are launched only when po_params.refine is set.
-template <int F, bool UNI, bool REF> hipError_t launch_form(const DevBatch *in_, const DevParams *P, hipStream_t st, size_t *lds_out) {
+template <int F, bool UNI, int REF> hipError_t launch_form(const DevBatch *in_, const DevParams *P, hipStream_t st, size_t *lds_out) {
     Shape s;
     if (!resolve_shape(F, in_->N, in_->C, in_->keep, &s)) return hipErrorInvalidValue;
     const size_t lds = lds_bytes_fast<F>(in_->N, in_->C, s.spl, s.two, s.nt);

@@ -17,7 +17,11 @@
 #ifndef PO_REF
 #define PO_REF 0
 #endif
-#if PO_UNI && PO_REF  // the variants with the refinement phase (po_params.refine): their own objects
+#if PO_UNI && PO_REF == 2  // the variants with the Newton refinement phase (po_params.refine = 2): their own objects
+#define PO_ENTRY PO_CAT(PO_ENTRY_BASE, _uni_nw)
+#elif PO_REF == 2
+#define PO_ENTRY PO_CAT(PO_ENTRY_BASE, _nw)
+#elif PO_UNI && PO_REF  // the variants with the refinement phase (po_params.refine = 1): their own objects
 #define PO_ENTRY PO_CAT(PO_ENTRY_BASE, _uni_ref)
 #elif PO_UNI
 #define PO_ENTRY PO_CAT(PO_ENTRY_BASE, _uni)
@@ -28,7 +32,7 @@
 #endif
 
 extern "C" hipError_t PO_ENTRY(const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out) {
-    return po::launch_form<PO_FORM, PO_UNI != 0, PO_REF != 0>(in, P, st, lds_out);
+    return po::launch_form<PO_FORM, PO_UNI != 0, PO_REF>(in, P, st, lds_out);
 }
 
 #if !PO_UNI && !PO_REF  // the polish kernels of this formulation build with the general-variant object

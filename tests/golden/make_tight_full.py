@@ -4,9 +4,9 @@ yardstick of the accuracy clause "<= 1e-4 m lateral-offset RMS per path" (BASELI
     set     batch                                                                  paths
     c3      BASELINE config 3: KP, N = 200, per-path random obstacle clearances    4096  (the batch `value` is measured on)
     c2      BASELINE config 2: KP, N = 120, fixed corridor                         1024
-    c5      BASELINE config 5: KPC, N = 400, curvature / curvature-rate limits      256
-    k       config-3 corridors, K formulation, N = 200                              256
-    keep3   config-3 generator at N = 231, ds = 0.3 m -> keep_control_steps_ = 3    256  (the shape the reference's own pipeline hands the QP)
+    c5      BASELINE config 5: KPC, N = 400, curvature / curvature-rate limits     4096  (round 4: the whole batch, was 256)
+    k       config-3 corridors, K formulation, N = 200                             4096  (round 4: the whole batch, was 256)
+    keep3   config-3 generator at N = 231, ds = 0.3 m -> keep_control_steps_ = 3   1024  (the shape the reference's own pipeline hands the QP)
 
 Method (test infrastructure, CPU only; the same as make_tight_c3.py): oracle ADMM to eps 1e-6, then primal-dual active-set iteration on the full KKT system
 with scipy's sparse LU (an algorithm independent of both ADMM implementations), accepted only when the active set reproduces itself, i.e. the point satisfies
@@ -31,9 +31,9 @@ SETS = {
     # name: (config, kwargs of synth.make_batch, paths)
     "c3": (3, {}, 4096),
     "c2": (2, {}, 1024),
-    "c5": (5, {}, 256),
-    "k": (3, {"formulation": 2}, 256),
-    "keep3": (3, {"N": 231, "ds": 0.3}, 256),
+    "c5": (5, {}, 4096),
+    "k": (3, {"formulation": 2}, 4096),
+    "keep3": (3, {"N": 231, "ds": 0.3}, 1024),
 }
 
 
@@ -90,7 +90,7 @@ def _work(arg):
 
 def main():
     names = sys.argv[1:] or list(SETS)
-    nproc = os.cpu_count() or 1
+    nproc = int(os.environ.get("PO_GOLDEN_PROCS", os.cpu_count() or 1))
     for name in names:
         nb = SETS[name][2]
         step = max(8, -(-nb // (4 * nproc)))
