@@ -167,6 +167,8 @@ typedef struct po_params {
      * ~0.3 % of BASELINE config 3, and of a repeated polish); with it the method is monotone in phi and terminates finitely.  Certification, status_refine, the
      * rounds, the chained scheduling and the hand-back rules are those of refine = 1; po_info.iters counts a Newton step as one iteration. */
     double refine_newton_rho;           /* 1e3 (scaled problem) */
+    double refine_newton_rho_eq;        /* 1e4: penalty of the equality rows, fixed (NOT 1e3 x the inequality one as in OSQP's step vector: the merit's gradient carries
+                                           rho_eq x (a.x - b), a difference of O(1) numbers, whose rounding at rho_eq >= 1e6 alone sits above the dual tolerance) */
     double refine_newton_rho_max;       /* 1e5: a multiplier update that does not cut the primal residual by 4 raises the penalty 10 x, up to this (the slow
                                            case: active rows that are nearly dependent through the heavily weighted curvature-rate variables) */
     double refine_ls_tol;               /* 1e-4: the line search stops at |psi'(t)| <= tol |psi'(0)| */

@@ -100,7 +100,7 @@ void po_oracle_default_params(po_params *p) {
     p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-7; p->refine_rounds = 1; p->probe_iters = 0;  /* (probe_iters: device scheduling only, no effect on results) */
     p->refine_chain = 1; /* device scheduling only */
     p->refine_extra_rounds = 0; p->refine_adapt = 1; p->refine_speculate = 1; /* (device scheduling only) */
-    p->refine_newton_rho = 1e3; p->refine_newton_rho_max = 1e5; p->refine_ls_tol = 1e-4; p->refine_ls_max = 30; p->refine_newton_max = 100; /* refine = 2 */
+    p->refine_newton_rho = 1e3; p->refine_newton_rho_eq = 1e4; p->refine_newton_rho_max = 1e5; p->refine_ls_tol = 1e-4; p->refine_ls_max = 30; p->refine_newton_max = 100; /* refine = 2 */
 }
 
 /* tools.hpp:24-35 — recursive in the reference; same fixed point as this loop */
@@ -1201,7 +1201,10 @@ resume_main:
              * (one number per row, like the engine's v); implied z = clip(w), y = rho (w - z).  rho_i: rb on inequality rows, 1e3 rb on equality rows. ---- */
             double rn_ = prm->refine_newton_rho;
             rn_ = rn_ < OSQP_RHO_MIN ? OSQP_RHO_MIN : (rn_ > OSQP_RHO_MAX ? OSQP_RHO_MAX : rn_);
-            double rb_in = rn_, rb_eq = OSQP_RHO_EQ_OVER_INEQ * rn_, pri_outer = -1.0;
+            /* equality rows: a FIXED penalty (not 1e3 x the inequality one): the gradient carries rho_eq x (a.x - b), a difference of O(1) numbers — at 1e6 and more
+             * its rounding alone (1e-16 x 1e6 x the unscaling) sits above the dual tolerance */
+            double rb_in = rn_, pri_outer = -1.0;
+            const double rb_eq = prm->refine_newton_rho_eq > 0 ? prm->refine_newton_rho_eq : 1e4;
             const int cap_nw = prm->refine_newton_max > 0 ? prm->refine_newton_max : 100;
             const int ls_max = prm->refine_ls_max > 0 ? prm->refine_ls_max : 30;
             double *w = (double *)malloc(sizeof(double) * (size_t)(m + 1)), *sv = (double *)malloc(sizeof(double) * (size_t)(m + 1));
@@ -1234,15 +1237,17 @@ resume_main:
                     if (++nouter > 50) break;
                     /* a multiplier update that did not cut the primal residual by 4: the penalty grows 10 x (the multipliers stay, w is re-expressed) */
                     double ratio = 1.0;
-                    if (pri_outer >= 0.0 && pri_res > 0.25 * pri_outer && rb_in * 10.0 <= prm->refine_newton_rho_max) { ratio = 0.1; rb_in *= 10.0; rb_eq *= 10.0; first_fac = 1; }
+                    if (pri_outer >= 0.0 && pri_res > 0.25 * pri_outer && rb_in * 10.0 <= prm->refine_newton_rho_max) { ratio = 0.1; rb_in *= 10.0; first_fac = 1; }
                     pri_outer = pri_res;
-                    for (int i = 0; i < m; ++i) w[i] = Axv[i] + ratio * (w[i] - z[i]);
+                    for (int i = 0; i < m; ++i) w[i] = Axv[i] + (ctype[i] == 1 ? 1.0 : ratio) * (w[i] - z[i]);
                     continue;
                 }
                 /* Newton step: rows outside their bounds at rho_i, the others at RHO_MIN (the matrix of refine = 1) */
                 int changed = first_fac;
                 for (int i = 0; i < m; ++i) {
-                    const double r = ctype[i] == -1 ? OSQP_RHO_MIN : (ctype[i] == 1 ? rb_eq : ((w[i] < l[i] || w[i] > u[i]) ? rb_in : OSQP_RHO_MIN));
+                    /* outside by more than rounding noise (a slack that sits on its bound comes out as +-1e-19: whether such a row counts as active must not
+                     * depend on the last bit — it changes the Newton matrix, not the gradient) */
+                    const double r = ctype[i] == -1 ? OSQP_RHO_MIN : (ctype[i] == 1 ? rb_eq : (fabs(w[i] - z[i]) > 1e-15 * (1.0 + fabs(z[i])) ? rb_in : OSQP_RHO_MIN));
                     if (r != rho_vec[i]) { rho_vec[i] = r; changed = 1; }
                 }
                 if (changed) {
@@ -1278,6 +1283,14 @@ resume_main:
                     double tnx = fp > 0 ? t - f / fp : -1.0;
                     if (!(tnx > lo && (hi < 0 || tnx < hi))) tnx = hi < 0 ? 2.0 * t : 0.5 * (lo + hi);
                     t = tnx;
+                }
+                if (g_refine_trace) {
+                    int na = 0, nb = 0;
+                    for (int i = 0; i < m; ++i) { if (ctype[i] == 0) { if (rho_vec[i] == rb_in) ++na; else ++nb; } }
+                    double sx = 0, sd = 0;
+                    for (int i = 0; i < n; ++i) { sx += (D[i] * x[i]) * (D[i] * x[i]); sd += (D[i] * dv[i]) * (D[i] * dv[i]); }
+                    fprintf(stderr, "      nact0 %d ninact %d |x|^2 %.9e |d|^2(all) %.9e\n", na, nb, sx, sd);
+                    fprintf(stderr, "      c0 %.6e c1 %.6e f0 %.6e t %.9f\n", c0 / cscale, c1 / cscale, f0 / cscale, t);
                 }
                 if (fail) break; /* not a descent direction (rounding at the bottom of the merit): the attempt ends uncertified */
                 for (int i = 0; i < n; ++i) x[i] += t * dv[i];

@@ -38,7 +38,7 @@ struct DevParams {
     int refine, ref_every, ref_max_iter, ref_max_refactor, ref_rounds, ref_extra, ref_adapt, ref_spec;  // po_params.refine*
     int slice;              // po_params.probe_iters (0 with refine): iterations of the first launch pair
     double ref_rho, ref_eps;
-    double ref_nw_rho, ref_nw_rho_max, ref_ls_tol;  // po_params.refine = 2 (Newton refinement)
+    double ref_nw_rho, ref_nw_rho_eq, ref_nw_rho_max, ref_ls_tol;  // po_params.refine = 2 (Newton refinement)
     int ref_ls_max, ref_nw_max;
 };
 
@@ -419,7 +419,8 @@ template <bool UNI, bool FIRST, int NR, bool NWT = false> struct RhsFnX {  // NW
 struct NwReexFn {
     double x[5];
     double *v;
-    double ratio;
+    double ratio, ratio_eq;  // inequality rows / rows that are equalities by TYPE (their penalty is fixed, po_params.refine_newton_rho_eq)
+    unsigned cls_type;
     template <int MASK, class TL, class TU> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, TL l, TU u) {
         const double c[5] = {c0, c1, c2, c3, c4};
         double ax = 0;
@@ -427,7 +428,7 @@ struct NwReexFn {
         for (int a = 0; a < 5; ++a)
             if (MASK >> a & 1) ax += c[a] * x[a];
         const double vv = v[r];
-        v[r] = ax + ratio * (vv - clipd(vv, l, u));
+        v[r] = ax + (((cls_type >> (2 * r)) & 3u) == 1u ? ratio_eq : ratio) * (vv - clipd(vv, l, u));
     }
 };
 // the Newton direction d on one stage's rows, s = a.d.  MODE 0: the part of psi'(t) that is linear in t — rows that are equalities by TYPE:

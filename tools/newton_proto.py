@@ -112,7 +112,7 @@ def newton_al(Ps, As, l, u, x, y, rho_in, rho_eq, sigma=1e-6, tol=1e-9, max_newt
                     t = tn
             x = x + t * d
             if verbose:
-                print(f"   outer {outer} newton {k} |g| {gn:.2e} nact {int(J.sum())} t {t:.3g}")
+                print(f"   outer {outer} newton {k} |g| {gn:.2e} nact {int(J.sum())} t {t:.9f} f0 {(g @ d):.6e}")
         # multiplier update
         w, pw, r = parts(x, y)
         y = r.copy()
