@@ -139,7 +139,9 @@ typedef struct po_params {
                                            arbitrary order ends with a long tail of half-empty CUs; longest-first packs it.  150 is a good value there.
                                            NOTE: with probe_iters > 0 the device-pointer entry is NOT asynchronous (the host reads po_info between the two launch
                                            pairs and sorts): it blocks, cannot be stream-captured, and po_last_kernel_ms then includes that host time. */
-    int    refine_chain;                /* 1 (default).  refine_rounds > 1 only; scheduling only, results bit-identical.  1: all rounds run inside ONE launch pair —
+    int    refine_chain;                /* 1 (default).  refine_rounds > 1 only; scheduling only, results bit-identical.  (2, with refine = 2 only: "split" — the short type-based
+                                           warm start runs in the plain solve kernels, the Newton refinement of round 0 as a launch of its own, and the paths it does not
+                                           certify, if any, go through one launch pair per later round: each kernel keeps its own register allocation, nothing waits on a queue.)  1: all rounds run inside ONE launch pair —
                                            a workgroup that does not certify its path pushes it onto a device-side queue and a follow-up workgroup of the same launch
                                            resumes it, so a later round fills the tail of the one before instead of waiting for its slowest path.  0: one launch pair per
                                            round (every round ends with a chip-wide barrier). */

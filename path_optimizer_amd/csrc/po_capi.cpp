@@ -22,6 +22,7 @@ extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po
 extern "C" hipError_t po_launch_solve_round(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
 extern "C" hipError_t po_launch_finalize_status(po_info *info, int B, hipStream_t st);
 extern "C" hipError_t po_launch_polish(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
+extern "C" hipError_t po_launch_newton(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
 extern "C" int po_polish_state_doubles(int form, int N, int C, int keep);
 extern "C" hipError_t po_launch_scale(int form, const po::DevBatch *in, const po::DevParams *P, int passes, double *sc, hipStream_t st);
 extern "C" hipError_t po_launch_assemble(int form, const po::DevBatch *in, const po::DevParams *P, double *l, double *u, double *dyn, hipStream_t st);
@@ -276,6 +277,7 @@ static int make_dev_params(const po_handle_s *h, int form, int keep, po::DevPara
     D->slice = (!p.refine && p.probe_iters > 0) ? p.probe_iters : 0;
     D->ref_nw_rho = p.refine_newton_rho > 0 ? p.refine_newton_rho : 1e3; D->ref_nw_rho_max = p.refine_newton_rho_max; D->ref_nw_rho_eq = p.refine_newton_rho_eq > 0 ? p.refine_newton_rho_eq : 1e4; D->ref_ls_tol = p.refine_ls_tol > 0 ? p.refine_ls_tol : 1e-4;
     D->ref_ls_max = p.refine_ls_max > 0 ? p.refine_ls_max : 30; D->ref_nw_max = p.refine_newton_max > 0 ? p.refine_newton_max : 100;
+    D->ref_split_warm = 0;
     return PO_OK;
 }
 
@@ -349,7 +351,9 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     }
     po::DevBatch DS = D;  // what the solve launches see (the polish launch keeps D: B workgroups, no queue)
     const int rounds_total = (h->params.refine_rounds > 1 ? h->params.refine_rounds : 1) + P.ref_extra;
-    if (h->params.refine && rounds_total > 1 && rounds_total < 32 && h->params.refine_chain && D.pol_state != nullptr && in->B < (1 << 24)) {
+    // refine = 2, refine_chain = 2: "split" scheduling — plain warm-start launch, the Newton refinement as its own launch, then the (nearly always empty) per-round launches
+    const bool split = h->params.refine == 2 && h->params.refine_chain == 2 && D.pol_state != nullptr && rounds_total < 32;
+    if (!split && h->params.refine && rounds_total > 1 && rounds_total < 32 && h->params.refine_chain && D.pol_state != nullptr && in->B < (1 << 24)) {
         // chained rounds: hand-backs and speculative continuations, at most one of each per path and round
         const size_t cap = 2 * (size_t)(rounds_total - 1) * (size_t)in->B, qints = 8 + cap;  // (po_fast.inc: kRqHdr)
         if ((rc = h->rq_buf.ensure(sizeof(int) * (2 * qints + 3 * (size_t)in->B)))) return rc;
@@ -390,6 +394,17 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
         }
         rb.round = 1;
         HIP_TRY(po_launch_solve_round(in->formulation, &rb, &P, h->stream));
+    } else if (split) {
+        po::DevParams P1 = P;  // the warm start: the plain solve kernels, stopped where round 0 of the rounds stops (10^(R-1) x eps)
+        for (int r = 1; r < (h->params.refine_rounds > 1 ? h->params.refine_rounds : 1); ++r) { P1.eps_abs *= 10.0; P1.eps_rel *= 10.0; }
+        P1.ref_split_warm = 1;
+        HIP_TRY(po_launch_solve(in->formulation, &D, &P1, h->stream, nullptr));
+        HIP_TRY(po_launch_newton(in->formulation, &D, &P, h->stream));
+        for (int r = 1; r < rounds_total; ++r) {  // what the Newton launch did not certify (rare): the later rounds, one launch pair each
+            po::DevBatch rb = D;
+            rb.round = r;
+            HIP_TRY(po_launch_solve_round(in->formulation, &rb, &P, h->stream));
+        }
     } else {
         HIP_TRY(po_launch_solve(in->formulation, &DS, &P, h->stream, nullptr));
     }

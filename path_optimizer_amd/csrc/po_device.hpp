@@ -40,6 +40,7 @@ struct DevParams {
     double ref_rho, ref_eps;
     double ref_nw_rho, ref_nw_rho_eq, ref_nw_rho_max, ref_ls_tol;  // po_params.refine = 2 (Newton refinement)
     int ref_ls_max, ref_nw_max;
+    int ref_split_warm;  // launcher only: this is the warm-start launch of the split scheduling (plain kernels although refine = 2)
 };
 
 struct DevBatch {
@@ -416,9 +417,9 @@ template <bool UNI, bool FIRST, int NR, bool NWT = false> struct RhsFnX {  // NW
 };
 // ---- Newton refinement (po_params.refine = 2): v holds w = a.x + y / rho ----
 // v <- a.x + ratio (v - clip(v)): the multiplier update (ratio = 1), a change of penalty (ratio = rho_old / rho_new), the entry from the ADMM state
-struct NwReexFn {
+struct NwReexFn {  // (v: a COPY of the row group's values, copied in and out by the pass — see ReclassFn in po_fast.inc for why not a pointer into the lane state)
     double x[5];
-    double *v;
+    double v[9];
     double ratio, ratio_eq;  // inequality rows / rows that are equalities by TYPE (their penalty is fixed, po_params.refine_newton_rho_eq)
     unsigned cls_type;
     template <int MASK, class TL, class TU> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, TL l, TU u) {
@@ -435,8 +436,8 @@ struct NwReexFn {
 // c0 += rho_eq (v - b) s, c1 += rho_eq s^2.  MODE 1: the step, v += t s.
 template <int MODE> struct NwDirFn {
     double xt[5];
-    double *v;
-    double t, rho_eq, c0, c1;
+    double v[9];
+    double t, rho, rho_eq, c0, c1, f0;
     unsigned cls_type;
     const double *W;
     template <int MASK, class TL, class TU> __device__ __forceinline__ void row(int r, double k0, double k1, double k2, double k3, double k4, TL l, TU u) {
@@ -446,18 +447,20 @@ template <int MODE> struct NwDirFn {
         for (int a = 0; a < 5; ++a)
             if (MASK >> a & 1) s += c[a] * xt[a];
         if constexpr (MODE == 0) {
-            if (((cls_type >> (2 * r)) & 3u) == 1u) {
-                const double rw = W[r] * rho_eq, vv = v[r];
-                c0 += rw * (vv - clipd(vv, l, u)) * s;
+            const unsigned k = (cls_type >> (2 * r)) & 3u;
+            const double vv = v[r], dl = vv - clipd(vv, l, u);
+            if (k == 1u) {
+                const double rw = W[r] * rho_eq;
+                c0 += rw * dl * s;
                 c1 += rw * s * s;
-            }
+            } else if (k == 0u) f0 += W[r] * rho * dl * s;  // the inequality rows' part of psi'(0): saves the line search one evaluation
         } else v[r] += t * s;
     }
 };
 // one evaluation of the line search: the inequality rows (by TYPE) at x + t d:  f += rho (w - clip(w)) s,  fp += rho s^2 where w = v + t s is outside its bounds
 struct NwLsFn {
     double xt[5];
-    const double *v;
+    double v[9];
     double t, rho, f, fp;
     unsigned cls_type;
     const double *W;

@@ -92,7 +92,7 @@ __global__ void finalize_status_kernel(po_info *info, int B) {
 extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out) {
     using namespace po;
     hipError_t e;
-    const bool ref = (P->refine != 0 || P->slice > 0) && in->pol_state != nullptr;  // the kernels that carry the refinement phase / hand paths back (two-level shapes; they need the state block)
+    const bool ref = (P->refine != 0 || P->slice > 0) && in->pol_state != nullptr && !(P->refine == 2 && P->ref_split_warm);  // the kernels that carry the refinement phase / hand paths back (two-level shapes; they need the state block)
     if (!ref) {
         if (form == F_KP) { e = po_launch_solve_kp_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kp(in, P, st, lds_out); }
         if (form == F_KPC) { e = po_launch_solve_kpc_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kpc(in, P, st, lds_out); }
@@ -142,6 +142,14 @@ extern "C" hipError_t po_launch_solve_round(int form, const po::DevBatch *in, co
 #define PO_DECLP(name) extern "C" hipError_t name(const po::DevBatch *in, const po::DevParams *P, hipStream_t st)
 PO_DECLP(po_launch_polish_kp); PO_DECLP(po_launch_polish_kpc); PO_DECLP(po_launch_polish_k);
 #undef PO_DECLP
+#define PO_DECLP(name) extern "C" hipError_t name(const po::DevBatch *in, const po::DevParams *P, hipStream_t st)
+PO_DECLP(po_launch_newton_kp); PO_DECLP(po_launch_newton_kpc); PO_DECLP(po_launch_newton_k);
+#undef PO_DECLP
+// the Newton refinement of round 0 as its own launch (po_params.refine = 2, refine_chain = 2)
+extern "C" hipError_t po_launch_newton(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st) {
+    using namespace po;
+    return form == F_KP ? po_launch_newton_kp(in, P, st) : (form == F_KPC ? po_launch_newton_kpc(in, P, st) : po_launch_newton_k(in, P, st));
+}
 extern "C" int po_polish_state_doubles_kp(int N, int C, int keep);
 extern "C" int po_polish_state_doubles_kpc(int N, int C, int keep);
 extern "C" int po_polish_state_doubles_k(int N, int C, int keep);

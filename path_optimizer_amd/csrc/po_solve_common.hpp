@@ -214,6 +214,22 @@ template <int F> inline int polish_state_doubles(int N, int C, int keep) {
     return 0;
 #endif
 }
+// the Newton refinement of round 0 as its own launch (po_params.refine = 2, refine_chain = 2): same shapes as the polish
+template <int F> hipError_t launch_newton(const DevBatch *in, const DevParams *P, hipStream_t st) {
+    Shape s;
+    if (!resolve_shape(F, in->N, in->C, in->keep, &s) || !s.two) return hipErrorInvalidValue;
+    const size_t lds = lds_bytes_fast<F>(in->N, in->C, s.spl, s.two, s.nt);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+#ifdef PO_DEV_HEADLINE
+    if (s.spl == 4 && s.nt == 64) return launch1(&newton_kernel<F, 4, 64>, in, P, 64, lds, st);
+    return hipErrorInvalidValue;
+#else
+#define PO_X(SPL_, NT_) return launch1(&newton_kernel<F, SPL_, NT_>, in, P, NT_, lds, st)
+    PO_POLISH_SHAPES(PO_X)
+#undef PO_X
+    return hipErrorInvalidValue;
+#endif
+}
 template <int F> hipError_t launch_polish(const DevBatch *in, const DevParams *P, hipStream_t st) {
     Shape s;
     if (!resolve_shape(F, in->N, in->C, in->keep, &s) || !s.two) return hipErrorInvalidValue;

@@ -31,9 +31,20 @@
 #define PO_ENTRY PO_ENTRY_BASE
 #endif
 
+#if PO_REF == 3  // the Newton refinement as its own kernels (po_params.refine = 2, refine_chain = 2): one object per formulation, nothing else in it
+#if PO_FORM == 0
+#define PO_NEWTON_ENTRY po_launch_newton_kp
+#elif PO_FORM == 1
+#define PO_NEWTON_ENTRY po_launch_newton_kpc
+#else
+#define PO_NEWTON_ENTRY po_launch_newton_k
+#endif
+extern "C" hipError_t PO_NEWTON_ENTRY(const po::DevBatch *in, const po::DevParams *P, hipStream_t st) { return po::launch_newton<PO_FORM>(in, P, st); }
+#else
 extern "C" hipError_t PO_ENTRY(const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out) {
     return po::launch_form<PO_FORM, PO_UNI != 0, PO_REF>(in, P, st, lds_out);
 }
+#endif
 
 #if !PO_UNI && !PO_REF  // the polish kernels of this formulation build with the general-variant object
 #if PO_FORM == 0

@@ -2,7 +2,8 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
 from make_tight_full import batch_of
 from path_optimizer_amd import binding
-b = batch_of(sys.argv[1], 1, int(sys.argv[2]))
-p = binding.default_params(); p.refine=2; p.refine_rounds=5; p.refine_extra_rounds=2; p.refine_eps=1e-8; p.refine_chain=0
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+b = batch_of(sys.argv[1], B, int(sys.argv[2]))
+p = binding.default_params(); p.refine=2; p.refine_rounds=5; p.refine_extra_rounds=2; p.refine_eps=1e-8; p.refine_chain=2
 st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
-print(info)
+print(info[:1])
