@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("PO_LIB") or os.path.join(_HERE, "libpo_hip.so")  # PO
 _LIB = None
 
 EXPORTS = ["po_default_params", "po_problem_dims", "po_keep_control_steps", "po_create", "po_destroy", "po_set_stream", "po_debug_set", "po_debug_trace_read", "po_device_count",
-           "po_solve_batch", "po_solve_batch_device", "po_assemble_batch", "po_scaling_batch", "po_last_kernel_ms", "po_strerror",
+           "po_solve_batch", "po_solve_batch_device", "po_assemble_batch", "po_scaling_batch", "po_last_kernel_ms", "po_last_phase_ms", "po_strerror",
            "po_last_hip_error", "po_version", "po_set_map", "po_postcheck_batch", "po_postcheck_batch_device", "po_bounds_batch",
            "po_bounds_batch_device", "po_map_sample", "po_smooth_dims", "po_smooth_batch", "po_smooth_batch_device",
            "po_resample_batch", "po_resample_batch_device", "po_limits_batch", "po_limits_batch_device", "po_dp_search_batch",
@@ -56,6 +56,7 @@ def lib():
         L.po_assemble_batch.argtypes = [C.c_void_p, C.POINTER(PoBatchIn), C.c_void_p, C.c_void_p, C.c_void_p]
         L.po_scaling_batch.argtypes = [C.c_void_p, C.POINTER(PoBatchIn), C.c_void_p]
         L.po_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.po_last_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         _LIB = L
     return _LIB
 
@@ -366,6 +367,13 @@ class Engine:
         ms = C.c_float()
         _check(lib().po_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
+
+    def last_phase_ms(self) -> dict:
+        """po_last_phase_ms: where the last solve spent its time (host-pointer entry: pack + H2D / solve / D2H / host pack / host unpack; split scheduling: the solve's own phases)."""
+        ms = (C.c_float * 8)()
+        _check(lib().po_last_phase_ms(self._h, ms))
+        keys = ("pack_h2d", "solve", "d2h", "host_pack", "host_unpack", "warm_start", "newton", "fallback")
+        return {k: float(ms[i]) for i, k in enumerate(keys)}
 
 
 class DeviceBatch:

@@ -3,6 +3,7 @@
 // kernels or returns an error code.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <algorithm>
@@ -11,6 +12,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/po_hip.h"
@@ -72,6 +74,43 @@ struct DevBuf {  // grow-only device buffer
         cap = 0;
     }
 };
+struct HostBuf {  // grow-only PINNED host buffer (hipHostMalloc): the staging area of the host-pointer entry — DMA engines read / write it directly,
+                  // so the H2D / D2H copies run at PCIe speed and asynchronously (a copy from pageable memory is staged by the runtime, synchronously)
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return PO_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        if (!hip_ok(hipHostMalloc(&p, bytes, hipHostMallocDefault), "hipHostMalloc")) return PO_ERR_NOMEM;
+        cap = bytes;
+        return PO_OK;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+struct CopySeg { char *dst; const char *src; size_t bytes; };
+// memcpy of a list of segments on `nthr` host threads (pieces of <= 2 MB handed out round-robin: every thread streams through every array)
+void parallel_copy(const std::vector<CopySeg> &segs, int nthr) {
+    std::vector<CopySeg> pieces;
+    const size_t kPiece = (size_t)2 << 20;
+    for (const CopySeg &sg : segs)
+        for (size_t o = 0; o < sg.bytes; o += kPiece) pieces.push_back({sg.dst + o, sg.src + o, std::min(kPiece, sg.bytes - o)});
+    if (nthr <= 1 || pieces.size() <= 1) {
+        for (const CopySeg &pc : pieces) std::memcpy(pc.dst, pc.src, pc.bytes);
+        return;
+    }
+    nthr = (int)std::min<size_t>((size_t)nthr, pieces.size());
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthr; ++t)
+        th.emplace_back([&pieces, t, nthr] { for (size_t i = (size_t)t; i < pieces.size(); i += (size_t)nthr) std::memcpy(pieces[i].dst, pieces[i].src, pieces[i].bytes); });
+    for (size_t i = 0; i < pieces.size(); i += (size_t)nthr) std::memcpy(pieces[i].dst, pieces[i].src, pieces[i].bytes);
+    for (std::thread &t : th) t.join();
+}
 }  // namespace
 
 struct po_handle_s {
@@ -79,7 +118,12 @@ struct po_handle_s {
     po_params params{};
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
+    hipEvent_t evh[4] = {nullptr, nullptr, nullptr, nullptr};  // host-pointer entry: start, H2D done, (ev0 .. ev1 = the solve), D2H done; evh[3]: solve phase mark (po_last_phase_ms)
+    hipEvent_t evp[2] = {nullptr, nullptr};                    // split scheduling (refine = 2): end of the warm-start launches, end of the Newton launch
+    bool timed = false, timed_host = false, timed_phases = false;
+    double host_pack_ms = 0.0, host_unpack_ms = 0.0;
+    HostBuf pin_in, pin_out;   // pinned staging of the host-pointer entry
+    int host_threads = 0;      // pack / unpack threads (0: min(8, hardware threads); po_debug_set "host_threads")
     DevBuf pol_buf;  // per-lane ADMM state handed from the solve kernels to the polish kernel (po_params.polish)
     DevBuf ord_buf;  // po_params.probe_iters: the launch order of the second round
     DevBuf rq_buf;   // po_params.refine_chain: the two device-side queues of a chained-rounds solve
@@ -185,6 +229,8 @@ int po_create(int device, const po_params *params, po_handle *out) {
         delete h;
         return PO_ERR_HIP;
     }
+    for (hipEvent_t &e : h->evh) if (!hip_ok(hipEventCreate(&e), "hipEventCreate")) { delete h; return PO_ERR_HIP; }
+    for (hipEvent_t &e : h->evp) if (!hip_ok(hipEventCreate(&e), "hipEventCreate")) { delete h; return PO_ERR_HIP; }
     h->stream = h->own_stream;
     *out = h;
     return PO_OK;
@@ -199,8 +245,11 @@ int po_destroy(po_handle h) {
     h->rq_buf.release();
     h->trace_buf.release();
     h->in_buf.release(); h->out_buf.release(); h->asm_buf.release(); h->scale_buf.release(); h->dbg_buf.release(); h->map_buf.release(); h->post_buf.release(); h->coef_buf.release(); h->bnd_buf.release(); h->smooth_buf.release(); h->smooth_io.release(); h->plan_coef.release(); h->plan_io.release(); h->plan_arena.release(); h->plan_host.release();
+    h->pin_in.release(); h->pin_out.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (hipEvent_t e : h->evh) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->evp) if (e) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return PO_OK;
@@ -211,6 +260,7 @@ int po_debug_set(po_handle h, const char *key, int value) {
     std::lock_guard<std::mutex> g(h->mu);
     const std::string k(key);
     if (k == "identity_order") h->env_identity = value != 0;
+    else if (k == "host_threads") h->host_threads = value < 0 ? 0 : value;
     else if (k == "debug_cycles") h->env_cycles = value != 0;
     else if (k == "split") {
 #ifdef PO_WITH_SPLIT
@@ -368,6 +418,7 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     if (P.slice > 0 && D.pol_state != nullptr && D.order == nullptr)  // (before anything is enqueued: a failed allocation leaves no half-run batch behind)
         if ((rc = h->ord_buf.ensure(sizeof(int) * (size_t)in->B))) return rc;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    h->timed_phases = false;
     // per-path equilibration (h->params.scaling class-level Ruiz passes; 0 -> identity), then the fused solve
     HIP_TRY(po_launch_scale(in->formulation, &D, &P, h->params.scaling, static_cast<double *>(h->scale_buf.p), h->stream));
     if (P.slice > 0 && D.pol_state != nullptr) {
@@ -399,12 +450,11 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
         for (int r = 1; r < (h->params.refine_rounds > 1 ? h->params.refine_rounds : 1); ++r) { P1.eps_abs *= 10.0; P1.eps_rel *= 10.0; }
         P1.ref_split_warm = 1;
         HIP_TRY(po_launch_solve(in->formulation, &D, &P1, h->stream, nullptr));
+        HIP_TRY(hipEventRecord(h->evp[0], h->stream));
         HIP_TRY(po_launch_newton(in->formulation, &D, &P, h->stream));
-        for (int r = 1; r < rounds_total; ++r) {  // what the Newton launch did not certify (rare): the later rounds, one launch pair each
-            po::DevBatch rb = D;
-            rb.round = r;
-            HIP_TRY(po_launch_solve_round(in->formulation, &rb, &P, h->stream));
-        }
+        HIP_TRY(hipEventRecord(h->evp[1], h->stream));
+        h->timed_phases = true;
+        // (po_launch_newton = newton_kernel + newton_fallback_kernel: the rare path the first does not certify runs its later rounds in the second)
     } else {
         HIP_TRY(po_launch_solve(in->formulation, &DS, &P, h->stream, nullptr));
     }
@@ -442,36 +492,11 @@ int po_solve_batch(po_handle h, const po_batch_in *in, const po_batch_out *out) 
     HIP_TRY(hipSetDevice(h->device));
     const size_t B = in->B, N = in->N;
     const bool kpc = in->formulation == PO_KPC;
-    // one staging buffer: 5 ref arrays + bounds(8) + (max_k, max_kp) per point, x0(3) + goal per path
+    // one staging block: 5 ref arrays + bounds(8) + (max_k, max_kp) per point, x0(3) + goal per path, then n_points / order (ints)
     const size_t per_pt = 13 + (kpc ? 2 : 0);
     if (in->n_points)
         for (size_t b = 0; b < B; ++b)
             if (in->n_points[b] < 2 || in->n_points[b] > in->N) return PO_ERR_INVALID;
-    const size_t in_bytes = sizeof(double) * (B * N * per_pt + B * 4 + 2 * ((B + 1) / 2 + 1));
-    const size_t out_bytes = sizeof(double) * (B * N * 5 + (out->x ? B * (size_t)n : 0)) + sizeof(po_info) * B;
-    {
-        std::lock_guard<std::mutex> g(h->mu);
-        if ((rc = h->in_buf.ensure(in_bytes)) || (rc = h->out_buf.ensure(out_bytes))) return rc;
-    }
-    double *d = static_cast<double *>(h->in_buf.p);
-    po_batch_in din = *in;
-    size_t o = 0;
-    auto up = [&](const double *src, size_t cnt, const double **dst) -> int {
-        *dst = d + o;
-        if (!hip_ok(hipMemcpyAsync(d + o, src, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream), "H2D")) return PO_ERR_HIP;
-        o += cnt;
-        return PO_OK;
-    };
-    if ((rc = up(in->ref_x, B * N, &din.ref_x)) || (rc = up(in->ref_y, B * N, &din.ref_y)) || (rc = up(in->ref_z, B * N, &din.ref_z)) ||
-        (rc = up(in->ref_k, B * N, &din.ref_k)) || (rc = up(in->ref_s, B * N, &din.ref_s)) || (rc = up(in->bounds, B * N * 8, &din.bounds)) ||
-        (rc = up(in->x0, B * 3, &din.x0)) || (rc = up(in->goal_z, B, &din.goal_z)))
-        return rc;
-    if (kpc && ((rc = up(in->max_k, B * N, &din.max_k)) || (rc = up(in->max_kp, B * N, &din.max_kp)))) return rc;
-    if (in->n_points) {
-        int *dn = reinterpret_cast<int *>(d + o);
-        HIP_TRY(hipMemcpyAsync(dn, in->n_points, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
-        din.n_points = dn;
-    }
     if (in->order) {  // scheduling hint: must be a permutation (checked here; the device-pointer entry trusts its caller)
         std::vector<char> seen(B, 0);
         for (size_t b = 0; b < B; ++b) {
@@ -479,10 +504,59 @@ int po_solve_batch(po_handle h, const po_batch_in *in, const po_batch_out *out) 
             if (v < 0 || (size_t)v >= B || seen[(size_t)v]) return PO_ERR_INVALID;
             seen[(size_t)v] = 1;
         }
-        int *dord = reinterpret_cast<int *>(d + o) + ((B + 1) / 2) * 2;
-        HIP_TRY(hipMemcpyAsync(dord, in->order, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
-        din.order = dord;
     }
+    const size_t in_bytes = sizeof(double) * (B * N * per_pt + B * 4 + 2 * ((B + 1) / 2 + 1));
+    const size_t out_bytes = sizeof(double) * (B * N * 5 + (out->x ? B * (size_t)n : 0)) + sizeof(po_info) * B;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        if ((rc = h->in_buf.ensure(in_bytes)) || (rc = h->out_buf.ensure(out_bytes)) || (rc = h->pin_in.ensure(in_bytes)) || (rc = h->pin_out.ensure(out_bytes))) return rc;
+    }
+    // ---- pack: caller's (pageable) arrays -> the pinned block, on several host threads; the block goes to the device in slices as they fill ----
+    double *d = static_cast<double *>(h->in_buf.p);
+    char *pin = static_cast<char *>(h->pin_in.p);
+    po_batch_in din = *in;
+    std::vector<CopySeg> segs;
+    size_t o = 0;
+    auto up = [&](const double *src, size_t cnt, const double **dst) {
+        *dst = d + o;
+        segs.push_back({pin + o * sizeof(double), reinterpret_cast<const char *>(src), cnt * sizeof(double)});
+        o += cnt;
+    };
+    up(in->ref_x, B * N, &din.ref_x); up(in->ref_y, B * N, &din.ref_y); up(in->ref_z, B * N, &din.ref_z); up(in->ref_k, B * N, &din.ref_k); up(in->ref_s, B * N, &din.ref_s);
+    up(in->bounds, B * N * 8, &din.bounds); up(in->x0, B * 3, &din.x0); up(in->goal_z, B, &din.goal_z);
+    if (kpc) { up(in->max_k, B * N, &din.max_k); up(in->max_kp, B * N, &din.max_kp); }
+    size_t used = o * sizeof(double);
+    if (in->n_points) {
+        segs.push_back({pin + o * sizeof(double), reinterpret_cast<const char *>(in->n_points), sizeof(int) * B});
+        din.n_points = reinterpret_cast<const int *>(d + o);
+        used = o * sizeof(double) + sizeof(int) * B;
+    }
+    if (in->order) {
+        const size_t oo = o * sizeof(double) + sizeof(int) * ((B + 1) / 2) * 2;
+        segs.push_back({pin + oo, reinterpret_cast<const char *>(in->order), sizeof(int) * B});
+        din.order = reinterpret_cast<const int *>(reinterpret_cast<char *>(d) + oo);
+        used = oo + sizeof(int) * B;
+    }
+    const int nthr = h->host_threads > 0 ? h->host_threads : (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    HIP_TRY(hipEventRecord(h->evh[0], h->stream));
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        // the block in slices of 32 MB: slice k is on its way over PCIe while slice k + 1 is being packed (gaps between the int arrays travel as they are)
+        const size_t kSlice = (size_t)32 << 20;
+        for (size_t lo = 0; lo < used; lo += kSlice) {
+            const size_t hi = std::min(used, lo + kSlice);
+            std::vector<CopySeg> cur;
+            for (const CopySeg &sg : segs) {
+                const size_t s0 = (size_t)(sg.dst - pin), s1 = s0 + sg.bytes;
+                const size_t a0 = std::max(s0, lo), a1 = std::min(s1, hi);
+                if (a0 < a1) cur.push_back({pin + a0, sg.src + (a0 - s0), a1 - a0});
+            }
+            parallel_copy(cur, nthr);
+            HIP_TRY(hipMemcpyAsync(reinterpret_cast<char *>(d) + lo, pin + lo, hi - lo, hipMemcpyHostToDevice, h->stream));
+        }
+        h->host_pack_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    HIP_TRY(hipEventRecord(h->evh[1], h->stream));
     po_batch_out dout;
     char *ob = static_cast<char *>(h->out_buf.p);
     dout.states = reinterpret_cast<double *>(ob);
@@ -490,10 +564,43 @@ int po_solve_batch(po_handle h, const po_batch_in *in, const po_batch_out *out) 
     dout.info = reinterpret_cast<po_info *>(ob + sizeof(double) * (B * N * 5 + (out->x ? B * (size_t)n : 0)));
     rc = po_solve_batch_device(h, &din, &dout);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out->states, dout.states, sizeof(double) * B * N * 5, hipMemcpyDeviceToHost, h->stream));
-    if (out->x) HIP_TRY(hipMemcpyAsync(out->x, dout.x, sizeof(double) * B * (size_t)n, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(out->info, dout.info, sizeof(po_info) * B, hipMemcpyDeviceToHost, h->stream));
+    // ---- D2H into the pinned block (one copy), then unpack on the host threads ----
+    char *pout = static_cast<char *>(h->pin_out.p);
+    HIP_TRY(hipMemcpyAsync(pout, ob, out_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipEventRecord(h->evh[2], h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<CopySeg> us;
+        us.push_back({reinterpret_cast<char *>(out->states), pout, sizeof(double) * B * N * 5});
+        if (out->x) us.push_back({reinterpret_cast<char *>(out->x), pout + sizeof(double) * B * N * 5, sizeof(double) * B * (size_t)n});
+        us.push_back({reinterpret_cast<char *>(out->info), pout + sizeof(double) * (B * N * 5 + (out->x ? B * (size_t)n : 0)), sizeof(po_info) * B});
+        parallel_copy(us, nthr);
+        h->host_unpack_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    h->timed_host = true;
+    return PO_OK;
+}
+
+// What the last po_solve_batch (host pointers) spent where, ms: [0] pack + H2D (stream time from the start of the call to the last H2D slice: the pack runs
+// under the copies), [1] the solve (= po_last_kernel_ms), [2] D2H, [3] host pack alone (wall), [4] host unpack (wall).  And, for the split scheduling of
+// refine = 2, the solve's own phases: [5] equilibration + warm-start launches, [6] the Newton launch, [7] the per-round fallback launches + status sweep (0 otherwise).
+int po_last_phase_ms(po_handle h, float *ms8) {
+    if (!h || !ms8 || !h->timed) return PO_ERR_INVALID;
+    for (int i = 0; i < 8; ++i) ms8[i] = 0.0f;
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    HIP_TRY(hipEventElapsedTime(&ms8[1], h->ev0, h->ev1));
+    if (h->timed_host) {
+        HIP_TRY(hipEventSynchronize(h->evh[2]));
+        HIP_TRY(hipEventElapsedTime(&ms8[0], h->evh[0], h->evh[1]));
+        HIP_TRY(hipEventElapsedTime(&ms8[2], h->ev1, h->evh[2]));
+        ms8[3] = (float)h->host_pack_ms; ms8[4] = (float)h->host_unpack_ms;
+    }
+    if (h->timed_phases) {
+        HIP_TRY(hipEventElapsedTime(&ms8[5], h->ev0, h->evp[0]));
+        HIP_TRY(hipEventElapsedTime(&ms8[6], h->evp[0], h->evp[1]));
+        HIP_TRY(hipEventElapsedTime(&ms8[7], h->evp[1], h->ev1));
+    }
     return PO_OK;
 }
 

@@ -221,10 +221,10 @@ template <int F> hipError_t launch_newton(const DevBatch *in, const DevParams *P
     const size_t lds = lds_bytes_fast<F>(in->N, in->C, s.spl, s.two, s.nt);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
 #ifdef PO_DEV_HEADLINE
-    if (s.spl == 4 && s.nt == 64) return launch1(&newton_kernel<F, 4, 64>, in, P, 64, lds, st);
+    if (s.spl == 4 && s.nt == 64) { hipError_t e_ = launch1(&newton_kernel<F, 4, 64>, in, P, 64, lds, st); return e_ != hipSuccess ? e_ : launch1(&newton_fallback_kernel<F, 4, 64>, in, P, 64, lds, st); }
     return hipErrorInvalidValue;
 #else
-#define PO_X(SPL_, NT_) return launch1(&newton_kernel<F, SPL_, NT_>, in, P, NT_, lds, st)
+#define PO_X(SPL_, NT_) { hipError_t e_ = launch1(&newton_kernel<F, SPL_, NT_>, in, P, NT_, lds, st); return e_ != hipSuccess ? e_ : launch1(&newton_fallback_kernel<F, SPL_, NT_>, in, P, NT_, lds, st); }
     PO_POLISH_SHAPES(PO_X)
 #undef PO_X
     return hipErrorInvalidValue;

@@ -175,7 +175,7 @@ def test_device_pipeline_bounds_solve_check(binding, oracle, scene):
     ost, oinfo, _ = oracle.solve_batch(batch, oracle.device_equivalent_params(), want_x=False)
     assert np.array_equal(info["status"], oinfo["status"]) and (info["status"] == 1).mean() > 0.5  # (corridors squeezed by the random discs can be infeasible: -3 on both)
     same = info["iters"] == oinfo["iters"]
-    assert same.mean() >= 0.9 and np.abs(states - ost)[same].max() < 1e-6
+    assert same.mean() >= 0.98 and np.abs(states - ost)[same].max() < 1e-6
     if (~same).any():  # one termination check earlier / later: compared at 10 x eps instead of dropped
         assert np.abs(states - ost)[~same].max() < 1e-3
     onk, ook = oracle.postcheck_batch(oracle.default_params(), scene["m"], states, info, batch.n_points)

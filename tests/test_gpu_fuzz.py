@@ -97,7 +97,7 @@ def test_random_case_refinement_matches_oracle(oracle, seed):
     assert np.array_equal(info["status"], oinfo["status"]), (seed, info["status"], oinfo["status"])
     ok = info["status"] == 1
     same = ok & (info["iters"] == oinfo["iters"])  # (refactorisation counts may differ where a row sits on its bound with a multiplier at noise level)
-    assert same.sum() >= 0.6 * ok.sum(), (seed, form, b.N, b.keep, info["iters"], oinfo["iters"])
+    assert same.sum() >= 0.98 * ok.sum() - 1, (seed, form, b.N, b.keep, info["iters"], oinfo["iters"])
     if same.any():
         assert np.abs(xs - oxs)[same].max() < 1e-5, (seed, np.abs(xs - oxs)[same].max())
     conv = ok & (info["r_prim"] < 2e-6) & (info["r_dual"] < 2e-6) & (oinfo["r_prim"] < 2e-6) & (oinfo["r_dual"] < 2e-6)

@@ -97,7 +97,10 @@ def test_device_refine_rounds_match_oracle(oracle, form, cfg, B, rounds):
     ost, oinfo, oxs = oracle.solve_batch(b, oracle.device_equivalent_params(p))
     assert np.array_equal(info["status"], oinfo["status"]) and (info["status_polish"] == 0).all()
     same = info["iters"] == oinfo["iters"]
-    assert same.mean() >= 0.7, (info["iters"], oinfo["iters"])
+    # measured (round 4): 95 / 96 and 48 / 48 (KP), 6 / 8 (KPC, two paths one refinement block apart), 16 / 16 (K)
+    assert same.mean() >= 0.98 or (~same).sum() <= 2, (same.mean(), info["iters"][~same], oinfo["iters"][~same])
+    # (the rest: one refinement block (10 it) or one check interval (25 it) earlier / later on one side, per round)
+    assert (np.abs(info["iters"].astype(int) - oinfo["iters"].astype(int))[~same] <= 25 * rounds).all()
     dn = np.abs(info["n_refactor"].astype(int) - oinfo["n_refactor"].astype(int))[same]
     assert (dn == 0).mean() >= 0.9 and dn.max() <= 2  # (an activity test decided by the last bits can cost / save one refactorisation without changing the count)
     ident = same & (info["n_refactor"] == oinfo["n_refactor"])
@@ -107,7 +110,7 @@ def test_device_refine_rounds_match_oracle(oracle, form, cfg, B, rounds):
     assert dx[ident].max() < 1e-5 and np.median(dx[ident]) < 1e-8 and np.abs(st[ident] - ost[ident]).max() < 1e-5
     assert dx[same].max() < 1e-4
     conv = (info["r_prim"] < 2e-6) & (info["r_dual"] < 2e-6) & (oinfo["r_prim"] < 2e-6) & (oinfo["r_dual"] < 2e-6)
-    assert conv.mean() >= 0.7 and np.abs(st[conv] - ost[conv])[..., :3].max() < 2e-4
+    assert conv.mean() >= 0.9 and np.abs(st[conv] - ost[conv])[..., :3].max() < 2e-4
     assert abs(info["iters"].mean() - oinfo["iters"].mean()) < 0.1 * oinfo["iters"].mean()
     if form == 0:
         gold = np.load(GOLD)["e_y"]
@@ -131,7 +134,8 @@ def test_device_refine_matches_oracle_and_optimum(oracle):
     assert (extra >= 10).all() and (extra <= 400).all() and (extra % 10 == 0).all()
     # same algorithm on the same iterates (they differ in the last bits: FMA contraction, block elimination vs sparse LDL'): the same iteration
     # counts except where an activity test or the termination test is decided by those bits
-    assert (extra == oextra).mean() >= 0.8, (extra == oextra).mean()
+    assert (extra == oextra).mean() >= 0.98, (extra == oextra).mean()
+    assert (np.abs(extra - oextra) <= 10).all()  # the rest: one refinement block
     assert abs(np.mean(extra) - np.mean(oextra)) < 5
     r, ro = _rms(xs, gold, b.N), _rms(oxs, gold, b.N)
     assert (r <= 1e-4).mean() >= 0.985 and abs((r <= 1e-4).mean() - (ro <= 1e-4).mean()) <= 0.02
