@@ -147,9 +147,9 @@ typedef struct po_params {
                                            round (every round ends with a chip-wide barrier). */
     int    refine_extra_rounds;         /* 0.  E > 0: a path that the last regular round does not certify at refine_eps continues BELOW eps — type-based iteration at
                                            eps / 10, refinement again, eps / 100, ... — for up to E more rounds (full refinement budget each).  A path returned after
-                                           them is certified, or satisfies OSQP's test at eps / 10^E — or ran out of max_iter in one of these rounds on a point that still passes OSQP's
-                                           test at eps: such a path is PO_STATUS_SOLVED with status_refine -1 (it met eps in the last regular round; a round below eps never
-                                           turns a solved path into MAX_ITER).  For the handful of nearly flat QPs on which the activity-set
+                                           them is certified, or satisfies OSQP's test at eps / 10^E — or ran out of max_iter in one of these rounds: then the point it ends on is tested
+                                           against OSQP's criteria at the caller's eps once more — passes: PO_STATUS_SOLVED with status_refine -1; fails (ADMM residuals are
+                                           not monotone): PO_STATUS_MAX_ITER with that iterate, like any other path that runs out of iterations (po_plan_batch: ok = 0).  For the handful of nearly flat QPs on which the activity-set
                                            iteration cycles (BASELINE config 3: 11 of 4096 paths): they are the ones left > 0.1 m from the optimum at eps. */
     int    refine_adapt;                /* 1.  OSQP's adaptive-rho rule (balance of the relative residuals, applied when the estimate leaves [rho / adapt_tol, rho x adapt_tol])
                                            on the refinement's own rho, after a block of refine_every iterations that kept its step vector.  Once the activity set has
@@ -188,7 +188,7 @@ typedef struct po_info {
     double rho;         /* final rho                                    */
     double obj;         /* 0.5 x'Px at exit                             */
     int    status_refine; /* po_params.refine: 0 the refinement did not run on this path (refine off, or the path was not solved); 1 CERTIFIED: OSQP's
-                             termination test holds on the returned point at refine_eps (1e-6), i.e. the point is the QP's optimum to that tolerance; -1 the
+                             termination test holds on the returned point at refine_eps (default 1e-7), i.e. the point is the QP's optimum to that tolerance; -1 the
                              refinement ran out of its budget before that: the returned point satisfies OSQP's test at eps_abs / eps_rel only (it is the refined
                              point when its residuals are no worse than the solved point's, else the solved point) — a caller that needs the <= 1e-4 m accuracy
                              clause per path treats -1 as "not certified" */
@@ -276,6 +276,10 @@ int po_debug_trace_read(po_handle h, long long *out, int max_records);
 int po_solve_batch(po_handle h, const po_batch_in *in, const po_batch_out *out);
 /* Device-pointer entry: all pointers in `in`/`out` are device pointers; asynchronous on the stream. */
 int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out *out);
+/* Synchronises the handle's stream and reports whether the last solve ran to its end: PO_OK, or PO_ERR_HIP when a workgroup of a chained-rounds launch
+ * (po_params.refine_chain = 1) gave up waiting for a hand-back — a protocol time-out (5 s, or longer in proportion to max_iter / refine_max_iter / the rounds); every
+ * other waiter then leaves at once and the affected paths are reported PO_STATUS_UNSOLVED.  po_solve_batch (host pointers) performs this check itself. */
+int po_solve_status(po_handle h);
 
 /* ---- post-solve step: PathOptimizer::optimizePath, src/path_optimizer/path_optimizer.cpp:183-200 ----
  * Upload the obstacle-distance layer (host pointer in `map->distance`) to the handle's device; kept until replaced. */

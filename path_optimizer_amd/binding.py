@@ -8,17 +8,18 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
-from .abi import (INFO_BYTES, INFO_DTYPE, PO_ERR_HIP, PO_OK, PoBatchIn, PoBatchOut, PoParams)
+from .abi import (INFO_BYTES, INFO_DTYPE, PO_ERR_HIP, PO_ERR_UNSUPPORTED, PO_OK, PoBatchIn, PoBatchOut, PoParams)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PO_LIB") or os.path.join(_HERE, "libpo_hip.so")  # PO_LIB: dev builds (make dev), A/B experiments
 _LIB = None
 
 EXPORTS = ["po_default_params", "po_problem_dims", "po_keep_control_steps", "po_create", "po_destroy", "po_set_stream", "po_debug_set", "po_debug_trace_read", "po_device_count",
-           "po_solve_batch", "po_solve_batch_device", "po_assemble_batch", "po_scaling_batch", "po_last_kernel_ms", "po_last_phase_ms", "po_strerror",
+           "po_solve_batch", "po_solve_batch_device", "po_assemble_batch", "po_scaling_batch", "po_last_kernel_ms", "po_last_phase_ms", "po_solve_status", "po_strerror",
            "po_last_hip_error", "po_version", "po_set_map", "po_postcheck_batch", "po_postcheck_batch_device", "po_bounds_batch",
            "po_bounds_batch_device", "po_map_sample", "po_smooth_dims", "po_smooth_batch", "po_smooth_batch_device",
            "po_resample_batch", "po_resample_batch_device", "po_limits_batch", "po_limits_batch_device", "po_dp_search_batch",
@@ -57,6 +58,7 @@ def lib():
         L.po_scaling_batch.argtypes = [C.c_void_p, C.POINTER(PoBatchIn), C.c_void_p]
         L.po_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.po_last_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.po_solve_status.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -120,11 +122,20 @@ class Engine:
         self._h = C.c_void_p()
         _check(lib().po_create(device, C.byref(self.params), C.byref(self._h)))
         # developer conveniences of THIS Python plumbing (tools/*.py, A/B runs): PO_* environment variables are translated into po_debug_set calls
-        # here; the C library itself reads no environment variable
-        for env, key in _ENV_DEBUG.items():
-            v = os.environ.get(env)
-            if v not in (None, "", "0"):
-                self.debug_set(key, int(v) if v.lstrip("-").isdigit() else 1)
+        # here; the C library itself reads no environment variable.  A switch this build does not have (PO_SPLIT on a build without `make SPLIT=1`) is
+        # reported and ignored; any other failure destroys the handle before it propagates.
+        try:
+            for env, key in _ENV_DEBUG.items():
+                v = os.environ.get(env)
+                if v not in (None, "", "0"):
+                    rc = lib().po_debug_set(self._h, key.encode(), int(v) if v.lstrip("-").isdigit() else 1)
+                    if rc == PO_ERR_UNSUPPORTED:
+                        sys.stderr.write(f"[path_optimizer_amd] {env} ignored: this build of libpo_hip.so has no '{key}' switch\n")
+                    else:
+                        _check(rc)
+        except Exception:
+            self.close()
+            raise
 
     def debug_set(self, key: str, value: int):
         """po_debug_set: developer A/B switches (identity_order, debug_cycles, split, smooth_seq, smooth_waves, smooth_nopad, smooth_debug, dp_one_wave)."""

@@ -121,6 +121,8 @@ struct po_handle_s {
     hipEvent_t evh[4] = {nullptr, nullptr, nullptr, nullptr};  // host-pointer entry: start, H2D done, (ev0 .. ev1 = the solve), D2H done; evh[3]: solve phase mark (po_last_phase_ms)
     hipEvent_t evp[2] = {nullptr, nullptr};                    // split scheduling (refine = 2): end of the warm-start launches, end of the Newton launch
     bool timed = false, timed_host = false, timed_phases = false;
+    size_t rq_qints = 0;
+    bool rq_used = false;      // the last solve ran the chained rounds: its queues' error flags are worth a look (po_solve_status)
     double host_pack_ms = 0.0, host_unpack_ms = 0.0;
     HostBuf pin_in, pin_out;   // pinned staging of the host-pointer entry
     int host_threads = 0;      // pack / unpack threads (0: min(8, hardware threads); po_debug_set "host_threads")
@@ -353,14 +355,14 @@ static void fill_dev_batch(const po_handle_s *h, po::DevBatch *D, const po_batch
     D->out_x = out ? out->x : nullptr;
     D->dbg_cycles = nullptr;
     D->only_deferred = 0;
-    D->perm_bits = 0;  // block -> path permutation (PO_IDENTITY_ORDER=1: blockIdx order, dev tool)
+    D->perm_bits = 0;  // block -> path permutation (po_debug_set "identity_order": blockIdx order, dev tool)
     if (!h->env_identity && in->B > 8)
         while ((1 << D->perm_bits) < in->B) ++D->perm_bits;
     D->scale = nullptr;
     D->pol_state = nullptr; D->pol_stride = 0;
     D->use_split = 0;
     D->round = 0;
-    D->rq = nullptr; D->rq_cap = 0; D->spec_words = nullptr; D->rq_policy = h->env_queue_policy >= 0 ? h->env_queue_policy : (in->order != nullptr ? 1 : 0);  // auto: with the caller's longest-first order, hand-backs first
+    D->rq = nullptr; D->rq_cap = 0; D->spec_words = nullptr; D->rq_timeout = 0; D->rq_policy = h->env_queue_policy >= 0 ? h->env_queue_policy : (in->order != nullptr ? 1 : 0);  // auto: with the caller's longest-first order, hand-backs first
     D->dbg_trace = nullptr;
     D->n = n; D->m = m;
 }
@@ -396,7 +398,7 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
         }
     }
     {   // EXPERIMENTAL, off by default: the stage-split two-wave mapping of the keep-4 kernel (two waves per SIMD; DESIGN.md §9: correct, but measured 30 % slower
-        // than the one-wave mapping — seven LDS hand-offs per iteration).  PO_SPLIT=1 selects it (A/B runs, tests); never together with the polish (state layout).
+        // than the one-wave mapping — seven LDS hand-offs per iteration).  po_debug_set "split" selects it (A/B runs, tests); never together with the polish (state layout).
         D.use_split = (h->env_split && !polish) ? 1 : 0;
     }
     po::DevBatch DS = D;  // what the solve launches see (the polish launch keeps D: B workgroups, no queue)
@@ -406,9 +408,13 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     if (!split && h->params.refine && rounds_total > 1 && rounds_total < 32 && h->params.refine_chain && D.pol_state != nullptr && in->B < (1 << 24)) {
         // chained rounds: hand-backs and speculative continuations, at most one of each per path and round
         const size_t cap = 2 * (size_t)(rounds_total - 1) * (size_t)in->B, qints = 8 + cap;  // (po_fast.inc: kRqHdr)
+        h->rq_qints = qints;
         if ((rc = h->rq_buf.ensure(sizeof(int) * (2 * qints + 3 * (size_t)in->B)))) return rc;
         DS.rq = static_cast<int *>(h->rq_buf.p);
         DS.rq_cap = (int)cap;
+        // time-out of a waiter: 5 s, or what the slowest legitimate producer could take — every round's iteration budget at a generous 50 us per iteration, x 4 for a shared / preempted GPU
+        const double per_round_it = (double)h->params.max_iter + (double)(h->params.refine == 2 ? 20 * h->params.refine_newton_max : h->params.refine_max_iter);
+        DS.rq_timeout = (long long)std::max(5.0e8, 4.0 * 50e-6 * 1e8 * per_round_it * (double)rounds_total);
     }
     if (h->env_queue_trace && DS.rq != nullptr) {  // dev: item timeline (po_debug_trace_read)
         if ((rc = h->trace_buf.ensure(sizeof(long long) * (4 + 4 * 65000)))) return rc;
@@ -419,6 +425,7 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
         if ((rc = h->ord_buf.ensure(sizeof(int) * (size_t)in->B))) return rc;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     h->timed_phases = false;
+    h->rq_used = DS.rq != nullptr;
     // per-path equilibration (h->params.scaling class-level Ruiz passes; 0 -> identity), then the fused solve
     HIP_TRY(po_launch_scale(in->formulation, &D, &P, h->params.scaling, static_cast<double *>(h->scale_buf.p), h->stream));
     if (P.slice > 0 && D.pol_state != nullptr) {
@@ -569,6 +576,7 @@ int po_solve_batch(po_handle h, const po_batch_in *in, const po_batch_out *out) 
     HIP_TRY(hipMemcpyAsync(pout, ob, out_bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipEventRecord(h->evh[2], h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if ((rc = po_solve_status(h))) return rc;
     {
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<CopySeg> us;
@@ -579,6 +587,21 @@ int po_solve_batch(po_handle h, const po_batch_in *in, const po_batch_out *out) 
         h->host_unpack_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     h->timed_host = true;
+    return PO_OK;
+}
+
+// Did the last solve on this handle run to its end?  Synchronises the stream.  PO_OK, or PO_ERR_HIP when a workgroup of a chained-rounds launch (refine_chain = 1) gave up
+// waiting for a hand-back (a protocol time-out: the affected paths are reported PO_STATUS_UNSOLVED).  The host-pointer entry checks this itself.
+int po_solve_status(po_handle h) {
+    if (!h) return PO_ERR_INVALID;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (!h->rq_used || !h->rq_buf.p) return PO_OK;
+    int hdr[2][8];
+    const int *rq = static_cast<const int *>(h->rq_buf.p);
+    HIP_TRY(hipMemcpy(hdr[0], rq, sizeof(int) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hdr[1], rq + h->rq_qints, sizeof(int) * 8, hipMemcpyDeviceToHost));
+    if (hdr[0][2] != 0 || hdr[1][2] != 0) { g_hip_err = "chained refinement rounds: a workgroup timed out waiting for a hand-back (affected paths are PO_STATUS_UNSOLVED)"; return PO_ERR_HIP; }
     return PO_OK;
 }
 

@@ -66,6 +66,7 @@ struct DevBatch {
     int rq_cap;             // chained refinement rounds: entries of the queue; the grid holds B + rq_cap workgroups (see rq_take in po_fast.inc)
     int *rq;                // ... and this launch's device-side queue [8 + rq_cap] (nullptr: one launch pair per round)
     int *spec_words;        // ... and the verdict words of the speculative continuations [B][3] (po_fast.inc, spec_post)
+    long long rq_timeout;   // ... and how long a waiter waits for a hand-back before it flags the launch as failed (100 MHz ticks; 0: the 5 s floor)
 };
 
 template <int F> struct FormTraits;
@@ -294,11 +295,38 @@ __device__ __forceinline__ int perm_index(unsigned i, int bits, int B) {
     return (int)i;
 }
 
+// Wave-wide reductions on DPP row shifts (VALU latency) instead of __shfl_xor (= ds_bpermute: an LDS round trip per level and value): Kogge-Stone inside the four
+// rows of 16 lanes (row_shr 1, 2, 4, 8: lane 15 of a row ends up with the row's total), then the four row totals through v_readlane.  Every lane returns the same bits.
+// Measured per kernel (A/B in one run, BASELINE config 3): newton_kernel 6.60 -> 5.92 ms per launch with the DPP form, the ADMM hot kernel 1.04 -> 1.10 ms (its
+// residual passes run every 25 iterations only, and the allocation at the 512-register limit does not like the change): the DPP form in the Newton objects only.
+#if defined(PO_REF) && PO_REF == 3 && !defined(PO_SHFL_REDUCE)
+#define PO_DPP_REDUCE 1
+#endif
+#ifdef PO_DPP_REDUCE
+template <int CTRL> __device__ __forceinline__ double dpp_shr_keep(double v) {  // lane t <- lane t - n of its row; lanes without a source keep their own value
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL> __device__ __forceinline__ double dpp_shr_zero(double v) {  // ... lanes without a source read 0
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_of(double v, int k) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), k), __builtin_amdgcn_readlane(__double2loint(v), k));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_shr_zero<0x111>(v); v += dpp_shr_zero<0x112>(v); v += dpp_shr_zero<0x114>(v); v += dpp_shr_zero<0x118>(v);
+    return (lane_of(v, 15) + lane_of(v, 31)) + (lane_of(v, 47) + lane_of(v, 63));
+}
+#else
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+#endif
 // exponent all ones: Inf or NaN.  An integer test on purpose: the build uses -fno-honor-nans, under which `v != v` folds to false, and the
 // residual norms are fmax-accumulated (fmax drops a NaN operand), so a non-finite iterate would otherwise read as "converged".
 // The high word goes through an empty asm: otherwise the optimiser recognises the mask-and-compare as is.fpclass(v, inf | nan) and, the producing
@@ -315,11 +343,18 @@ __device__ __forceinline__ int nan_bits(double v) {  // NaN only (an infinite cl
     return (hi & 0x7ff00000) == 0x7ff00000 && ((hi & 0x000fffff) | lo) != 0;
 }
 
+#ifdef PO_DPP_REDUCE
+__device__ __forceinline__ double wave_max(double v) {
+    v = fmax(v, dpp_shr_keep<0x111>(v)); v = fmax(v, dpp_shr_keep<0x112>(v)); v = fmax(v, dpp_shr_keep<0x114>(v)); v = fmax(v, dpp_shr_keep<0x118>(v));
+    return fmax(fmax(lane_of(v, 15), lane_of(v, 31)), fmax(lane_of(v, 47), lane_of(v, 63)));
+}
+#else
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
     return v;
 }
+#endif
 
 // -------------------------------------------------------------------------------------------------------
 // row functors
@@ -417,9 +452,9 @@ template <bool UNI, bool FIRST, int NR, bool NWT = false> struct RhsFnX {  // NW
 };
 // ---- Newton refinement (po_params.refine = 2): v holds w = a.x + y / rho ----
 // v <- a.x + ratio (v - clip(v)): the multiplier update (ratio = 1), a change of penalty (ratio = rho_old / rho_new), the entry from the ADMM state
-struct NwReexFn {  // (v: a COPY of the row group's values, copied in and out by the pass — see ReclassFn in po_fast.inc for why not a pointer into the lane state)
+struct NwReexFn {  // (v points into the lane state: copies in and out of the functor — ReclassFn's way — measured 9 % slower on the whole Newton launch)
     double x[5];
-    double v[9];
+    double *v;
     double ratio, ratio_eq;  // inequality rows / rows that are equalities by TYPE (their penalty is fixed, po_params.refine_newton_rho_eq)
     unsigned cls_type;
     template <int MASK, class TL, class TU> __device__ __forceinline__ void row(int r, double c0, double c1, double c2, double c3, double c4, TL l, TU u) {
@@ -436,7 +471,7 @@ struct NwReexFn {  // (v: a COPY of the row group's values, copied in and out by
 // c0 += rho_eq (v - b) s, c1 += rho_eq s^2.  MODE 1: the step, v += t s.
 template <int MODE> struct NwDirFn {
     double xt[5];
-    double v[9];
+    double *v;
     double t, rho, rho_eq, c0, c1, f0;
     unsigned cls_type;
     const double *W;
@@ -453,14 +488,17 @@ template <int MODE> struct NwDirFn {
                 const double rw = W[r] * rho_eq;
                 c0 += rw * dl * s;
                 c1 += rw * s * s;
-            } else if (k == 0u) f0 += W[r] * rho * dl * s;  // the inequality rows' part of psi'(0): saves the line search one evaluation
+            }
+#ifdef PO_NW_F0_MERGE
+            else if (k == 0u) f0 += W[r] * rho * dl * s;  // the inequality rows' part of psi'(0): saves the line search one evaluation
+#endif
         } else v[r] += t * s;
     }
 };
 // one evaluation of the line search: the inequality rows (by TYPE) at x + t d:  f += rho (w - clip(w)) s,  fp += rho s^2 where w = v + t s is outside its bounds
 struct NwLsFn {
     double xt[5];
-    double v[9];
+    const double *v;
     double t, rho, f, fp;
     unsigned cls_type;
     const double *W;

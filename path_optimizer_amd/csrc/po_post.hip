@@ -899,7 +899,7 @@ extern "C" hipError_t po_launch_limits(int B, int N, const int *n_points, const 
 extern "C" hipError_t po_launch_dp_search(const po::DevMap *m, const po::DevSpline *in, const po::DevSearch *q, int one_wave, hipStream_t st) {
     const size_t lds1 = po_dp_lds_bytes(in->K, q->L), lds4 = lds1 + kDpEightWaveScratch;
     // few instances (a planner's own call: B = 1): eight waves per instance share the edge evaluations of a layer; a full batch keeps one wave per instance
-    // (one_wave: the caller's A/B switch, read once at po_create)
+    // (one_wave: the caller's A/B switch, po_debug_set "dp_one_wave")
     if (in->B <= 512 && !one_wave && lds4 <= 160 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&po::dp_search_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
         if (e != hipSuccess) return e;

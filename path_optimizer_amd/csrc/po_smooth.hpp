@@ -22,7 +22,7 @@ struct DevSmooth {
     DevMap map;             // TENSION only
     int perm_bits;          // block -> instance mixing (po_device.hpp perm_index), 0 = blockIdx order
     long long *dbg_cycles;  // optional [B][8] per-phase shader-clock totals (dev tool: PO_SMOOTH_DEBUG=1), or nullptr
-    int seq_band;           // dev (PO_SMOOTH_SEQ=1): narrow-band substitutions on one lane (the round-1 path) instead of partitioned over the wave
+    int seq_band;           // dev (po_debug_set "smooth_seq"): narrow-band substitutions on one lane (the round-1 path) instead of partitioned over the wave
     int waves;              // dev (PO_SMOOTH_WAVES=1|4|8): waves per QP of the narrow-band kinds (0: chosen from the LDS footprint and the batch size)
     int blocked;            // set by po_launch_smooth: TENSION in the block layout of the factor (po_smooth_blocked; off with seq_band)
     int nopad;              // dev (PO_SMOOTH_NOPAD=1): the partitioned substitution on the natural LDS layout (bank conflicts) for A/B

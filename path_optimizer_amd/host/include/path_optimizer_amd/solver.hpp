@@ -49,14 +49,18 @@ class PoEngine {
     const po_params &params() const { return params_; }
     static PoEngine &instance() { static PoEngine e; return e; }
     // One engine per visible HIP device (device 0 first), created once per process with the default parameters: what the multi-device solveBatch takes.
-    static std::vector<PoEngine *> allDevices() {
-        static std::vector<std::unique_ptr<PoEngine>> own;
-        static std::vector<PoEngine *> view;
-        if (view.empty()) {
-            const int n = po_device_count();
-            for (int d = 0; d < n; ++d) { own.emplace_back(new PoEngine(d)); view.push_back(own.back().get()); }
-        }
-        return view;
+    // Thread-safe (function-local static, initialised exactly once); an EMPTY vector means no HIP device is visible — solveBatch reports that as its own error.
+    static const std::vector<PoEngine *> &allDevices() {
+        struct All {
+            std::vector<std::unique_ptr<PoEngine>> own;
+            std::vector<PoEngine *> view;
+            All() {
+                const int n = po_device_count();
+                for (int d = 0; d < n; ++d) { own.emplace_back(new PoEngine(d)); view.push_back(own.back().get()); }
+            }
+        };
+        static const All all;
+        return all.view;
     }
  private:
     po_handle h_{};
@@ -117,7 +121,8 @@ class OsqpSolver {
     // One batch = one (horizon, keep_control_steps_): PO_ERR_INVALID otherwise, as for one engine.  The first error of any shard is returned.
     static int solveBatch(int formulation, const PlanningInstance *inst, size_t B, size_t horizon, std::vector<std::vector<State>> *paths,
                           std::vector<po_info> *info, const std::vector<PoEngine *> &engines, std::vector<double> *device_ms = nullptr) {
-        if (!inst || !paths || !info || horizon < 2 || engines.empty()) return PO_ERR_INVALID;
+        if (engines.empty()) return PO_ERR_HIP;  // (PoEngine::allDevices() with no HIP device visible: not a malformed call)
+        if (!inst || !paths || !info || horizon < 2) return PO_ERR_INVALID;
         for (PoEngine *e : engines) if (!e) return PO_ERR_INVALID;
         const size_t G = engines.size();
         paths->assign(B, {});
