@@ -165,8 +165,8 @@ def config_legs(torch, binding, synth, dev, stream, steps=3):
 
 # The setting `value` is quoted at — ONE setting for every shape (round 4): a short OSQP-faithful ADMM run (to the first termination check) as the warm start, then
 # the Newton refinement (po_params.refine = 2: semismooth Newton on the augmented Lagrangian with an exact line search) until OSQP's termination test holds at refine_eps.
-HEADLINE = {"label": "ADMM warm start (25 it) + Newton refinement (refine = 2, refine_eps 3e-9), split launches",
-            "params": dict(refine=2, refine_rounds=5, refine_extra_rounds=2, refine_eps=3e-9, refine_chain=2),
+HEADLINE = {"label": "ADMM warm start (25 it) + Newton refinement (refine = 2, refine_eps 1e-8 + one final correction step), split launches",
+            "params": dict(refine=2, refine_rounds=5, refine_extra_rounds=2, refine_eps=1e-8, refine_chain=2),
             "algorithm": "EXTENSION (closer to the QP's optimum than the reference's OSQP run): certified per path, po_info.status_refine"}
 HEADLINE_R3 = {"label": "round-3 headline: eps 1e-4 + activity-weighted ADMM refinement (refine = 1; 3 rounds + 2 below eps, chained; refine_eps 1e-7)",
                "params": dict(refine=1, refine_rounds=3, refine_extra_rounds=2)}
@@ -242,10 +242,12 @@ def settings_table(torch, binding, batch, dev, stream, gold):
                       ("eps 1e-4 + refine, 3 rounds + 2 below eps, one launch pair per round", dict(refine=1, refine_rounds=3, refine_extra_rounds=2, refine_chain=0)),
                       (HEADLINE_R3["label"], HEADLINE_R3["params"]),
                       (HEADLINE["label"], HEADLINE["params"]),
+                      ("Newton refinement, fallback launch always issued: fully asynchronous (refine_chain = 3)", dict(HEADLINE["params"], refine_chain=3)),
                       ("Newton refinement, chained in one launch pair (refine_chain = 1)", dict(HEADLINE["params"], refine_chain=1)),
                       ("Newton refinement, entered at 1e3 x eps (refine_rounds = 4)", dict(HEADLINE["params"], refine_rounds=4)),
                       ("Newton refinement, entered at 1e2 x eps (refine_rounds = 3)", dict(HEADLINE["params"], refine_rounds=3)),
-                      ("Newton refinement, refine_eps 1e-8", dict(HEADLINE["params"], refine_eps=1e-8)),
+                      ("Newton refinement, without the final correction step", dict(HEADLINE["params"], refine_newton_final=0)),
+                      ("Newton refinement, refine_eps 3e-9", dict(HEADLINE["params"], refine_eps=3e-9)),
                       ("eps 1e-4 + refine, 3 + 2 rounds, refine_adapt off", dict(refine=1, refine_rounds=3, refine_extra_rounds=2, refine_adapt=0)),
                       ("eps 1e-4 + refine, 3 + 2 rounds, refine_eps 1e-6", dict(refine=1, refine_rounds=3, refine_extra_rounds=2, refine_eps=1e-6)),
                       ("eps 1e-3 (OSQP's own default, what the reference runs) + refine 3 + 3 rounds", dict(refine=1, refine_rounds=3, refine_extra_rounds=3, eps_abs=1e-3, eps_rel=1e-3)),
@@ -846,8 +848,15 @@ def main():
         time_serial(torch, engs[0], streams[0], dbatch, 1, barrier)  # (dbatch holds the headline outputs again for the stage legs below)
         info = dbatch.info_numpy()
         if args.streams > 1:
-            time_pipelined(torch, engs, streams, dbs, min(args.steps, 3), barrier)
-            pel, pms = time_pipelined(torch, engs, streams, dbs, args.steps, barrier)
+            # (the fully asynchronous variant of the split scheduling, refine_chain = 3: one host thread feeds all the streams, so no call may block)
+            pengs = []
+            for i in range(S):
+                e_ = binding.Engine(local_rank, make_params(binding, dict(HEADLINE["params"], refine_chain=3)))
+                e_.set_stream(streams[i].cuda_stream)
+                pengs.append(e_)
+            time_pipelined(torch, pengs, streams, dbs, min(args.steps, 3), barrier)
+            pel, pms = time_pipelined(torch, pengs, streams, dbs, args.steps, barrier)
+            [e_.close() for e_ in pengs]
             details["pipelined_3_streams" if S == 3 else f"pipelined_{S}_streams"] = {
                 "paths_per_s": B * args.steps / pel, "ms_per_step": pel / args.steps * 1e3, "launch_ms_mean": float(np.mean(pms)),
                 "note": f"the same K steps issued round-robin on {S} handles/streams (independent batches overlap: the stragglers of one drain under the next); NOT `value`"}

@@ -139,9 +139,11 @@ typedef struct po_params {
                                            arbitrary order ends with a long tail of half-empty CUs; longest-first packs it.  150 is a good value there.
                                            NOTE: with probe_iters > 0 the device-pointer entry is NOT asynchronous (the host reads po_info between the two launch
                                            pairs and sorts): it blocks, cannot be stream-captured, and po_last_kernel_ms then includes that host time. */
-    int    refine_chain;                /* 1 (default).  refine_rounds > 1 only; scheduling only, results bit-identical.  (2, with refine = 2 only: "split" — the short type-based
+    int    refine_chain;                /* 1 (default).  refine_rounds > 1 only; scheduling only, results bit-identical.  (2 / 3, with refine = 2 only: "split" — the short type-based
                                            warm start runs in the plain solve kernels, the Newton refinement of round 0 as a launch of its own, and the paths it does not
-                                           certify, if any, go through one launch pair per later round: each kernel keeps its own register allocation, nothing waits on a queue.)  1: all rounds run inside ONE launch pair —
+                                           certify (rare) go through their later rounds in a fallback launch: each kernel keeps its own register allocation, nothing waits on
+                                           a queue.  2: the fallback launch is issued only when a path needs it — the engine reads a 4-byte count back, so the device-pointer
+                                           entry returns when the Newton launch has FINISHED (it blocks; the launch it saves costs 0.5 ms); 3: always issued, fully asynchronous.)  1: all rounds run inside ONE launch pair —
                                            a workgroup that does not certify its path pushes it onto a device-side queue and a follow-up workgroup of the same launch
                                            resumes it, so a later round fills the tail of the one before instead of waiting for its slowest path.  0: one launch pair per
                                            round (every round ends with a chip-wide barrier). */
@@ -175,7 +177,12 @@ typedef struct po_params {
                                            case: active rows that are nearly dependent through the heavily weighted curvature-rate variables) */
     double refine_ls_tol;               /* 1e-4: the line search stops at |psi'(t)| <= tol |psi'(0)| */
     int    refine_ls_max;               /* 30: evaluations of psi' per line search at most */
-    int    refine_newton_max;           /* 100: Newton steps per attempt (every round) */
+    int    refine_newton_max;           /* 300: Newton steps per attempt (every round).  BASELINE config 3: mean 16, max 60; config 5 (KPC): mean 28, max ~210 */
+    int    refine_newton_final;         /* 1: once the point is certified at refine_eps, ONE more Newton step is taken from it (Newton converges quadratically once the
+                                           active set is right: the residuals drop to the rounding floor) — the accuracy a tighter refine_eps would buy without asking the
+                                           termination test for tolerances below what fp64 delivers on the KPC rows weighted 1e5 (measured: refine_eps 3e-9 leaves
+                                           93 of 4096 KPC paths stalling at r_dual 5e-9 until the step budget is spent).  0: stop at the certified point. */
+    int    reserved_newton;
 } po_params;
 
 typedef struct po_info {
@@ -267,6 +274,9 @@ int po_set_stream(po_handle h, void *hip_stream);
  * engine variants), "dp_one_wave" (DP lattice search on one wave per instance whatever the batch size), "queue_policy" (chained refinement rounds: 0 = a workgroup takes a
  * fresh path before a hand-back, k >= 1 = hand-backs of round >= k first, -1 = automatic: 0, or 1 when the caller supplies po_batch_in.order; scheduling only).  Unknown key: PO_ERR_INVALID. */
 int po_debug_set(po_handle h, const char *key, int value);
+/* Developer read-back (synchronises the stream): "fallback_paths" = how many paths the Newton launch of the last split-scheduled solve (refine = 2, refine_chain 2 / 3)
+ * did not certify and handed to the fallback launch. */
+int po_debug_get(po_handle h, const char *key, long long *value);
 /* Developer tool: with po_debug_set(h, "queue_trace", 1), the item timeline of the last chained-rounds solve — records of 4 int64: path | round << 32 |
  * speculative << 40 | outcome << 48 (0 final, 1 handed back, 2 failed attempt handed to its continuation, 3 / 4 continuation cancelled), start, end
  * (100 MHz device wall clock), workgroup index.  Returns the number of records copied (synchronises the stream). */

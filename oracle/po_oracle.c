@@ -100,7 +100,7 @@ void po_oracle_default_params(po_params *p) {
     p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-7; p->refine_rounds = 1; p->probe_iters = 0;  /* (probe_iters: device scheduling only, no effect on results) */
     p->refine_chain = 1; /* device scheduling only */
     p->refine_extra_rounds = 0; p->refine_adapt = 1; p->refine_speculate = 1; /* (device scheduling only) */
-    p->refine_newton_rho = 1e3; p->refine_newton_rho_eq = 1e4; p->refine_newton_rho_max = 1e5; p->refine_ls_tol = 1e-4; p->refine_ls_max = 30; p->refine_newton_max = 100; /* refine = 2 */
+    p->refine_newton_rho = 1e3; p->refine_newton_rho_eq = 1e4; p->refine_newton_rho_max = 1e5; p->refine_ls_tol = 1e-4; p->refine_ls_max = 30; p->refine_newton_max = 300; p->refine_newton_final = 1; /* refine = 2 */
 }
 
 /* tools.hpp:24-35 — recursive in the reference; same fixed point as this loop */
@@ -1205,11 +1205,11 @@ resume_main:
              * its rounding alone (1e-16 x 1e6 x the unscaling) sits above the dual tolerance */
             double rb_in = rn_, pri_outer = -1.0;
             const double rb_eq = prm->refine_newton_rho_eq > 0 ? prm->refine_newton_rho_eq : 1e4;
-            const int cap_nw = prm->refine_newton_max > 0 ? prm->refine_newton_max : 100;
+            const int cap_nw = prm->refine_newton_max > 0 ? prm->refine_newton_max : 300;
             const int ls_max = prm->refine_ls_max > 0 ? prm->refine_ls_max : 30;
             double *w = (double *)malloc(sizeof(double) * (size_t)(m + 1)), *sv = (double *)malloc(sizeof(double) * (size_t)(m + 1));
             double *dv = (double *)malloc(sizeof(double) * (size_t)n), *Pd = (double *)malloc(sizeof(double) * (size_t)n);
-            int first_fac = 1, nouter = 0, fail = 0;
+            int first_fac = 1, nouter = 0, fail = 0, certified = 0, final_done = 0;
             csc_mv(n, m, Ap0, Ai0, Ax, x, Axv);
             for (int i = 0; i < m; ++i) w[i] = Axv[i] + (ctype[i] == 0 ? y[i] / rb_in : (ctype[i] == 1 ? y[i] / rb_eq : 0.0));
             for (;;) {
@@ -1232,8 +1232,11 @@ resume_main:
                 const int dual_ok = dua_res < prm->refine_eps + prm->refine_eps * cinv * dn;
                 stop = dual_ok && pri_res < prm->refine_eps + prm->refine_eps * (nz > nAx ? nz : nAx);
                 if (g_refine_trace) fprintf(stderr, "  newton round %d step %d outer %d nfac %d  r_prim %.3e r_dual %.3e%s\n", round, it2, nouter, nfac, pri_res, dua_res, stop ? "  CERTIFIED" : "");
-                if (stop || it2 >= cap_nw) break;
-                if (dual_ok) { /* the inner problem is solved: multiplier update, w <- A x + (w - clip(w)) */
+                if (final_done) { stop = 1; break; } /* the point after the final correction step (certified before it) */
+                if (stop && !prm->refine_newton_final) break;
+                if (stop) certified = 1; /* refine_newton_final: one more Newton step from the certified point (quadratic convergence: residuals down to the noise floor) */
+                else if (it2 >= cap_nw) break;
+                if (!certified && dual_ok) { /* the inner problem is solved: multiplier update, w <- A x + (w - clip(w)) */
                     if (++nouter > 50) break;
                     /* a multiplier update that did not cut the primal residual by 4: the penalty grows 10 x (the multipliers stay, w is re-expressed) */
                     double ratio = 1.0;
@@ -1292,10 +1295,11 @@ resume_main:
                     fprintf(stderr, "      nact0 %d ninact %d |x|^2 %.9e |d|^2(all) %.9e\n", na, nb, sx, sd);
                     fprintf(stderr, "      c0 %.6e c1 %.6e f0 %.6e t %.9f\n", c0 / cscale, c1 / cscale, f0 / cscale, t);
                 }
-                if (fail) break; /* not a descent direction (rounding at the bottom of the merit): the attempt ends uncertified */
+                if (fail) { stop = certified; break; } /* not a descent direction (rounding at the bottom of the merit): the attempt ends here — certified if it was */
                 for (int i = 0; i < n; ++i) x[i] += t * dv[i];
                 for (int i = 0; i < m; ++i) w[i] += t * sv[i];
                 ++it2;
+                if (certified) final_done = 1;
             }
             free(w); free(sv); free(dv); free(Pd);
         } else

@@ -25,6 +25,7 @@ extern "C" hipError_t po_launch_solve_round(int form, const po::DevBatch *in, co
 extern "C" hipError_t po_launch_finalize_status(po_info *info, int B, hipStream_t st);
 extern "C" hipError_t po_launch_polish(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
 extern "C" hipError_t po_launch_newton(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
+extern "C" hipError_t po_launch_newton_fallback(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
 extern "C" int po_polish_state_doubles(int form, int N, int C, int keep);
 extern "C" hipError_t po_launch_scale(int form, const po::DevBatch *in, const po::DevParams *P, int passes, double *sc, hipStream_t st);
 extern "C" hipError_t po_launch_assemble(int form, const po::DevBatch *in, const po::DevParams *P, double *l, double *u, double *dyn, hipStream_t st);
@@ -129,6 +130,8 @@ struct po_handle_s {
     DevBuf pol_buf;  // per-lane ADMM state handed from the solve kernels to the polish kernel (po_params.polish)
     DevBuf ord_buf;  // po_params.probe_iters: the launch order of the second round
     DevBuf rq_buf;   // po_params.refine_chain: the two device-side queues of a chained-rounds solve
+    DevBuf fb_buf;   // split scheduling of refine = 2: the work list of newton_fallback_kernel
+    HostBuf fb_host; // ... and the pinned word its count is read back into (refine_chain = 2)
     // developer switches (po_debug_set; the library reads no environment variable): identity_order (block i solves path i), debug_cycles (per-phase shader
     // clocks of path 0 on stderr; synchronises), split (experimental stage-split mapping, only in builds made with `make SPLIT=1`), smoothing / DP-search A/B switches
     bool env_identity = false, env_cycles = false, env_split = false, env_smooth_seq = false, env_smooth_nopad = false, env_smooth_debug = false, env_dp_one_wave = false;
@@ -175,7 +178,7 @@ void po_default_params(po_params *p) {
     p->polish = 0; p->polish_delta = 1e-6; p->polish_refine_iter = 3; p->polish_passes = 1;  /* OSQP defaults (polish off) */
     p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-7; p->refine_rounds = 1; p->probe_iters = 0;
     p->refine_chain = 1; p->refine_extra_rounds = 0; p->refine_adapt = 1; p->refine_speculate = 1;
-    p->refine_newton_rho = 1e3; p->refine_newton_rho_eq = 1e4; p->refine_newton_rho_max = 1e5; p->refine_ls_tol = 1e-4; p->refine_ls_max = 30; p->refine_newton_max = 100; /* refine = 2 */
+    p->refine_newton_rho = 1e3; p->refine_newton_rho_eq = 1e4; p->refine_newton_rho_max = 1e5; p->refine_ls_tol = 1e-4; p->refine_ls_max = 30; p->refine_newton_max = 300; p->refine_newton_final = 1; /* refine = 2 */
 }
 
 int po_problem_dims(int form, int N, int keep, int *n, int *m, int *C) {
@@ -245,9 +248,10 @@ int po_destroy(po_handle h) {
     h->pol_buf.release();
     h->ord_buf.release();
     h->rq_buf.release();
+    h->fb_buf.release();
     h->trace_buf.release();
     h->in_buf.release(); h->out_buf.release(); h->asm_buf.release(); h->scale_buf.release(); h->dbg_buf.release(); h->map_buf.release(); h->post_buf.release(); h->coef_buf.release(); h->bnd_buf.release(); h->smooth_buf.release(); h->smooth_io.release(); h->plan_coef.release(); h->plan_io.release(); h->plan_arena.release(); h->plan_host.release();
-    h->pin_in.release(); h->pin_out.release();
+    h->pin_in.release(); h->pin_out.release(); h->fb_host.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (hipEvent_t e : h->evh) if (e) (void)hipEventDestroy(e);
@@ -280,6 +284,22 @@ int po_debug_set(po_handle h, const char *key, int value) {
     else if (k == "queue_policy") h->env_queue_policy = value < 0 ? -1 : (value > 31 ? 31 : value);
     else return PO_ERR_INVALID;
     return PO_OK;
+}
+
+int po_debug_get(po_handle h, const char *key, long long *value) {
+    if (!h || !key || !value) return PO_ERR_INVALID;
+    const std::string k(key);
+    if (k == "fallback_paths") {  // split scheduling of refine = 2: how many paths the last solve's Newton launch handed to the fallback launch
+        *value = 0;
+        if (!h->fb_buf.p) return PO_OK;
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        int c = 0;
+        HIP_TRY(hipMemcpy(&c, h->fb_buf.p, sizeof(int), hipMemcpyDeviceToHost));
+        *value = c;
+        return PO_OK;
+    }
+    return PO_ERR_INVALID;
 }
 
 int po_debug_trace_read(po_handle h, long long *out, int max_records) {
@@ -328,7 +348,7 @@ static int make_dev_params(const po_handle_s *h, int form, int keep, po::DevPara
     D->ref_extra = (p.refine && p.refine_extra_rounds > 0) ? p.refine_extra_rounds : 0; D->ref_adapt = p.refine_adapt; D->ref_spec = p.refine_speculate;
     D->slice = (!p.refine && p.probe_iters > 0) ? p.probe_iters : 0;
     D->ref_nw_rho = p.refine_newton_rho > 0 ? p.refine_newton_rho : 1e3; D->ref_nw_rho_max = p.refine_newton_rho_max; D->ref_nw_rho_eq = p.refine_newton_rho_eq > 0 ? p.refine_newton_rho_eq : 1e4; D->ref_ls_tol = p.refine_ls_tol > 0 ? p.refine_ls_tol : 1e-4;
-    D->ref_ls_max = p.refine_ls_max > 0 ? p.refine_ls_max : 30; D->ref_nw_max = p.refine_newton_max > 0 ? p.refine_newton_max : 100;
+    D->ref_nw_final = p.refine_newton_final; D->ref_ls_max = p.refine_ls_max > 0 ? p.refine_ls_max : 30; D->ref_nw_max = p.refine_newton_max > 0 ? p.refine_newton_max : 300;
     D->ref_split_warm = 0;
     return PO_OK;
 }
@@ -362,7 +382,7 @@ static void fill_dev_batch(const po_handle_s *h, po::DevBatch *D, const po_batch
     D->pol_state = nullptr; D->pol_stride = 0;
     D->use_split = 0;
     D->round = 0;
-    D->rq = nullptr; D->rq_cap = 0; D->spec_words = nullptr; D->rq_timeout = 0; D->rq_policy = h->env_queue_policy >= 0 ? h->env_queue_policy : (in->order != nullptr ? 1 : 0);  // auto: with the caller's longest-first order, hand-backs first
+    D->rq = nullptr; D->rq_cap = 0; D->spec_words = nullptr; D->rq_timeout = 0; D->fb_list = nullptr; D->rq_policy = h->env_queue_policy >= 0 ? h->env_queue_policy : (in->order != nullptr ? 1 : 0);  // auto: with the caller's longest-first order, hand-backs first
     D->dbg_trace = nullptr;
     D->n = n; D->m = m;
 }
@@ -404,7 +424,8 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     po::DevBatch DS = D;  // what the solve launches see (the polish launch keeps D: B workgroups, no queue)
     const int rounds_total = (h->params.refine_rounds > 1 ? h->params.refine_rounds : 1) + P.ref_extra;
     // refine = 2, refine_chain = 2: "split" scheduling — plain warm-start launch, the Newton refinement as its own launch, then the (nearly always empty) per-round launches
-    const bool split = h->params.refine == 2 && h->params.refine_chain == 2 && D.pol_state != nullptr && rounds_total < 32;
+    const bool split = h->params.refine == 2 && (h->params.refine_chain == 2 || h->params.refine_chain == 3) && D.pol_state != nullptr && rounds_total < 32;
+    if (split && ((rc = h->fb_buf.ensure(sizeof(int) * ((size_t)in->B + 1))) || (rc = h->fb_host.ensure(64)))) return rc;
     if (!split && h->params.refine && rounds_total > 1 && rounds_total < 32 && h->params.refine_chain && D.pol_state != nullptr && in->B < (1 << 24)) {
         // chained rounds: hand-backs and speculative continuations, at most one of each per path and round
         const size_t cap = 2 * (size_t)(rounds_total - 1) * (size_t)in->B, qints = 8 + cap;  // (po_fast.inc: kRqHdr)
@@ -458,9 +479,31 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
         P1.ref_split_warm = 1;
         HIP_TRY(po_launch_solve(in->formulation, &D, &P1, h->stream, nullptr));
         HIP_TRY(hipEventRecord(h->evp[0], h->stream));
+        D.fb_list = static_cast<int *>(h->fb_buf.p);
+        HIP_TRY(hipMemsetAsync(D.fb_list, 0, sizeof(int), h->stream));
         HIP_TRY(po_launch_newton(in->formulation, &D, &P, h->stream));
         HIP_TRY(hipEventRecord(h->evp[1], h->stream));
         h->timed_phases = true;
+        // The paths newton_kernel did not certify (rare) are on a device-side work list; newton_fallback_kernel takes them through the later rounds.  Its launch alone
+        // costs 0.5 ms whatever its grid (1.2 KB of private segment per lane: the runtime re-provisions scratch for it; 7 % of a BASELINE config-3 solve), so
+        // refine_chain = 2 reads the 4-byte count back and launches it only when there is something on the list — the call then returns when the Newton launch has
+        // finished (it blocks, like probe_iters).  refine_chain = 3: always launched, the call stays asynchronous.
+        bool need_fb = true;
+        if (h->params.refine_chain == 2) {
+            // the count lands in a pinned word the host SPINS on: a blocking hipStreamSynchronize wakes up through an interrupt — measured 0.5 ms, what the launch it
+            // is meant to save costs; falls back to the blocking wait after 20 ms of spinning (a long solve: the wake-up latency no longer matters)
+            volatile int *cnt = static_cast<volatile int *>(h->fb_host.p);
+            *cnt = -1;
+            HIP_TRY(hipMemcpyAsync(const_cast<int *>(cnt), D.fb_list, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            const auto ts0 = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            while (*cnt == -1) {
+                if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - ts0 > std::chrono::milliseconds(20)) { HIP_TRY(hipStreamSynchronize(h->stream)); break; }
+                __builtin_ia32_pause();
+            }
+            need_fb = *cnt != 0;
+        }
+        if (need_fb) HIP_TRY(po_launch_newton_fallback(in->formulation, &D, &P, h->stream));
         // (po_launch_newton = newton_kernel + newton_fallback_kernel: the rare path the first does not certify runs its later rounds in the second)
     } else {
         HIP_TRY(po_launch_solve(in->formulation, &DS, &P, h->stream, nullptr));

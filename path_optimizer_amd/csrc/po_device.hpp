@@ -39,7 +39,7 @@ struct DevParams {
     int slice;              // po_params.probe_iters (0 with refine): iterations of the first launch pair
     double ref_rho, ref_eps;
     double ref_nw_rho, ref_nw_rho_eq, ref_nw_rho_max, ref_ls_tol;  // po_params.refine = 2 (Newton refinement)
-    int ref_ls_max, ref_nw_max;
+    int ref_ls_max, ref_nw_max, ref_nw_final;
     int ref_split_warm;  // launcher only: this is the warm-start launch of the split scheduling (plain kernels although refine = 2)
 };
 
@@ -66,6 +66,7 @@ struct DevBatch {
     int rq_cap;             // chained refinement rounds: entries of the queue; the grid holds B + rq_cap workgroups (see rq_take in po_fast.inc)
     int *rq;                // ... and this launch's device-side queue [8 + rq_cap] (nullptr: one launch pair per round)
     int *spec_words;        // ... and the verdict words of the speculative continuations [B][3] (po_fast.inc, spec_post)
+    int *fb_list;           // split scheduling of refine = 2: work list of the paths newton_kernel hands back (count, then path ids; newton_fallback_kernel)
     long long rq_timeout;   // ... and how long a waiter waits for a hand-back before it flags the launch as failed (100 MHz ticks; 0: the 5 s floor)
 };
 

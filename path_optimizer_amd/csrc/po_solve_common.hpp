@@ -91,6 +91,12 @@ struct Resid { double rp, rd, nAx, nz, nPx, nAty, rps, rds, nAxs, nzs, nPxs, nAt
 
 // ---- launch wrappers used by the C ABI (po_capi.cpp) ----
 namespace po {
+template <class K> hipError_t launch_grid(K kern, const DevBatch *in, const DevParams *P, int grid, int nt, size_t lds, hipStream_t st) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), lds, st, *in, *P);
+    return hipGetLastError();
+}
 template <class K> hipError_t launch1(K kern, const DevBatch *in, const DevParams *P, int nt, size_t lds, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -214,21 +220,22 @@ template <int F> inline int polish_state_doubles(int N, int C, int keep) {
     return 0;
 #endif
 }
-// the Newton refinement of round 0 as its own launch (po_params.refine = 2, refine_chain = 2): same shapes as the polish
-template <int F> hipError_t launch_newton(const DevBatch *in, const DevParams *P, hipStream_t st) {
+// the Newton refinement of round 0 as its own launch (po_params.refine = 2, refine_chain = 2 / 3): same shapes as the polish.  FB: the fallback launch behind it
+// (newton_fallback_kernel walks the work list of the paths newton_kernel handed back; a small fixed grid)
+template <int F, bool FB> hipError_t launch_newton(const DevBatch *in, const DevParams *P, hipStream_t st) {
     Shape s;
     if (!resolve_shape(F, in->N, in->C, in->keep, &s) || !s.two) return hipErrorInvalidValue;
     const size_t lds = lds_bytes_fast<F>(in->N, in->C, s.spl, s.two, s.nt);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+#define PO_X(SPL_, NT_) { if constexpr (FB) return launch_grid(&newton_fallback_kernel<F, SPL_, NT_>, in, P, kFallbackGrid, NT_, lds, st); else return launch1(&newton_kernel<F, SPL_, NT_>, in, P, NT_, lds, st); }
 #ifdef PO_DEV_HEADLINE
-    if (s.spl == 4 && s.nt == 64) { hipError_t e_ = launch1(&newton_kernel<F, 4, 64>, in, P, 64, lds, st); return e_ != hipSuccess ? e_ : launch1(&newton_fallback_kernel<F, 4, 64>, in, P, 64, lds, st); }
+    if (s.spl == 4 && s.nt == 64) PO_X(4, 64)
     return hipErrorInvalidValue;
 #else
-#define PO_X(SPL_, NT_) { hipError_t e_ = launch1(&newton_kernel<F, SPL_, NT_>, in, P, NT_, lds, st); return e_ != hipSuccess ? e_ : launch1(&newton_fallback_kernel<F, SPL_, NT_>, in, P, NT_, lds, st); }
     PO_POLISH_SHAPES(PO_X)
-#undef PO_X
     return hipErrorInvalidValue;
 #endif
+#undef PO_X
 }
 template <int F> hipError_t launch_polish(const DevBatch *in, const DevParams *P, hipStream_t st) {
     Shape s;

@@ -39,7 +39,8 @@
 #else
 #define PO_NEWTON_ENTRY po_launch_newton_k
 #endif
-extern "C" hipError_t PO_NEWTON_ENTRY(const po::DevBatch *in, const po::DevParams *P, hipStream_t st) { return po::launch_newton<PO_FORM>(in, P, st); }
+extern "C" hipError_t PO_NEWTON_ENTRY(const po::DevBatch *in, const po::DevParams *P, hipStream_t st) { return po::launch_newton<PO_FORM, false>(in, P, st); }
+extern "C" hipError_t PO_CAT(PO_NEWTON_ENTRY, _fb)(const po::DevBatch *in, const po::DevParams *P, hipStream_t st) { return po::launch_newton<PO_FORM, true>(in, P, st); }
 #else
 extern "C" hipError_t PO_ENTRY(const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out) {
     return po::launch_form<PO_FORM, PO_UNI != 0, PO_REF>(in, P, st, lds_out);

@@ -11,6 +11,7 @@
 // reports it as an error instead of silently producing an empty "successful" path; parameters are captured in a
 // po_params block at construction instead of being read from gflags globals during assembly.
 #pragma once
+#include <algorithm>
 #include <chrono>
 #include <cstddef>
 #include <memory>
@@ -154,55 +155,94 @@ class OsqpSolver {
     static int solveShard(int formulation, const PlanningInstance *inst, size_t lo, size_t hi, size_t horizon, std::vector<std::vector<State>> *paths,
                           po_info *info, PoEngine *eng, int *keep_out) {
         const size_t N = horizon, B = hi - lo;
-        std::vector<double> rx(B * N), ry(B * N), rz(B * N), rk(B * N), rs(B * N), bd(B * N * 8), x0(B * 3), gz(B), mk, mkp;
-        if (formulation == PO_KPC) { mk.resize(B * N); mkp.resize(B * N); }
+        const auto tp0 = std::chrono::steady_clock::now();
+        // (uninitialised staging: every element is written by the pack below)
+        std::unique_ptr<double[]> buf(new double[B * N * (13 + (formulation == PO_KPC ? 2 : 0)) + B * 4]);
+        double *rx = buf.get(), *ry = rx + B * N, *rz = ry + B * N, *rk = rz + B * N, *rs = rk + B * N, *bd = rs + B * N, *x0 = bd + B * N * 8, *gz = x0 + B * 3;
+        double *mk = gz + B, *mkp = mk + (formulation == PO_KPC ? B * N : 0);
+        // AoS -> SoA pack on several host threads: contiguous slices of the shard (the multi-device caller already runs one thread per device)
+        const size_t nthr = std::max<size_t>(1, std::min<size_t>({(size_t)packThreads(), B / 64 + 1, (size_t)16}));
+        std::vector<int> trc(nthr, PO_OK), tkeep(nthr, 0);
+        auto pack = [&](size_t t) {
+            const size_t b0 = B * t / nthr, b1 = B * (t + 1) / nthr;
+            int keep_t = 0;
+            for (size_t b = b0; b < b1; ++b) {
+                const PlanningInstance &pi = inst[lo + b];
+                if (!pi.reference_path || !pi.vehicle_state) { trc[t] = PO_ERR_INVALID; return; }
+                const auto &st = pi.reference_path->getReferenceStates();
+                const auto &bnd = pi.reference_path->getBounds();
+                if (st.size() < N || bnd.size() < N) { trc[t] = PO_ERR_INVALID; return; }
+                for (size_t i = 0; i < N; ++i) {
+                    const size_t o = b * N + i;
+                    rx[o] = st[i].x; ry[o] = st[i].y; rz[o] = st[i].z; rk[o] = st[i].k; rs[o] = st[i].s;
+                    const CoveringCircleBounds::SingleCircleBounds *c[4] = {&bnd[i].c0, &bnd[i].c1, &bnd[i].c2, &bnd[i].c3};
+                    for (int j = 0; j < 4; ++j) { bd[o * 8 + 2 * j] = c[j]->lb; bd[o * 8 + 2 * j + 1] = c[j]->ub; }
+                }
+                if (formulation == PO_KPC) {
+                    const auto &a = pi.reference_path->getMaxKList();
+                    const auto &c = pi.reference_path->getMaxKpList();
+                    if (a.size() < N || c.size() < N) { trc[t] = PO_ERR_INVALID; return; }
+                    for (size_t i = 0; i < N; ++i) { mk[b * N + i] = a[i]; mkp[b * N + i] = c[i]; }
+                }
+                const auto e = pi.vehicle_state->getInitError();
+                x0[b * 3] = e[0]; x0[b * 3 + 1] = e[1]; x0[b * 3 + 2] = pi.vehicle_state->getStartState().k;
+                gz[b] = pi.vehicle_state->getEndState().z;
+                const int kb = po_keep_control_steps(formulation, &rs[b * N], (int)N);  // solver.cpp:22-27 + solver_kp_as_input.cpp:17
+                if (kb < 0) { trc[t] = kb; return; }
+                if (b == b0) keep_t = kb;
+                else if (kb != keep_t) { trc[t] = PO_ERR_INVALID; return; }  // one batch = one (N, keep)
+            }
+            tkeep[t] = keep_t;
+        };
+        runThreads(nthr, pack);
         int keep = 0;
-        for (size_t b = 0; b < B; ++b) {  // AoS -> SoA pack
-            const PlanningInstance &pi = inst[lo + b];
-            if (!pi.reference_path || !pi.vehicle_state) return PO_ERR_INVALID;
-            const auto &st = pi.reference_path->getReferenceStates();
-            const auto &bnd = pi.reference_path->getBounds();
-            if (st.size() < N || bnd.size() < N) return PO_ERR_INVALID;
-            for (size_t i = 0; i < N; ++i) {
-                const size_t o = b * N + i;
-                rx[o] = st[i].x; ry[o] = st[i].y; rz[o] = st[i].z; rk[o] = st[i].k; rs[o] = st[i].s;
-                const CoveringCircleBounds::SingleCircleBounds *c[4] = {&bnd[i].c0, &bnd[i].c1, &bnd[i].c2, &bnd[i].c3};
-                for (int j = 0; j < 4; ++j) { bd[o * 8 + 2 * j] = c[j]->lb; bd[o * 8 + 2 * j + 1] = c[j]->ub; }
-            }
-            if (formulation == PO_KPC) {
-                const auto &a = pi.reference_path->getMaxKList();
-                const auto &c = pi.reference_path->getMaxKpList();
-                if (a.size() < N || c.size() < N) return PO_ERR_INVALID;
-                for (size_t i = 0; i < N; ++i) { mk[b * N + i] = a[i]; mkp[b * N + i] = c[i]; }
-            }
-            const auto e = pi.vehicle_state->getInitError();
-            x0[b * 3] = e[0]; x0[b * 3 + 1] = e[1]; x0[b * 3 + 2] = pi.vehicle_state->getStartState().k;
-            gz[b] = pi.vehicle_state->getEndState().z;
-            const int kb = po_keep_control_steps(formulation, &rs[b * N], (int)N);  // solver.cpp:22-27 + solver_kp_as_input.cpp:17
-            if (kb < 0) return kb;
-            if (b == 0) keep = kb;
-            else if (kb != keep) return PO_ERR_INVALID;  // one batch = one (N, keep)
+        for (size_t t = 0; t < nthr; ++t) {
+            if (trc[t] != PO_OK) return trc[t];
+            if (B * t / nthr == B * (t + 1) / nthr) continue;  // (empty slice)
+            if (keep == 0) keep = tkeep[t];
+            else if (tkeep[t] != keep) return PO_ERR_INVALID;
         }
         *keep_out = keep;
+        const auto tp1 = std::chrono::steady_clock::now();
         int n, m, C;
         int rc = po_problem_dims(formulation, (int)N, keep, &n, &m, &C);
         if (rc) return rc;
-        po_batch_in in{formulation, (int)B, (int)N, keep, rx.data(), ry.data(), rz.data(), rk.data(), rs.data(), bd.data(), x0.data(), gz.data(),
-                       formulation == PO_KPC ? mk.data() : nullptr, formulation == PO_KPC ? mkp.data() : nullptr, nullptr, nullptr};
-        std::vector<double> states(B * N * 5);
-        po_batch_out out{states.data(), info + lo, nullptr};
+        po_batch_in in{formulation, (int)B, (int)N, keep, rx, ry, rz, rk, rs, bd, x0, gz, formulation == PO_KPC ? mk : nullptr, formulation == PO_KPC ? mkp : nullptr, nullptr, nullptr};
+        std::unique_ptr<double[]> states(new double[B * N * 5]);
+        po_batch_out out{states.get(), info + lo, nullptr};
         rc = po_solve_batch(eng->handle(), &in, &out);
         if (rc) return rc;
-        for (size_t b = 0; b < B; ++b) {
-            auto &p = (*paths)[lo + b];
-            p.clear();
-            p.reserve(N);
-            for (size_t i = 0; i < N; ++i) {
-                const double *s = &states[(b * N + i) * 5];
-                p.emplace_back(s[0], s[1], s[2], s[3], s[4]);  // v = a = 0, like getOptimizedPath
+        const auto tp2 = std::chrono::steady_clock::now();
+        auto unpack = [&](size_t t) {
+            for (size_t b = B * t / nthr; b < B * (t + 1) / nthr; ++b) {
+                auto &p = (*paths)[lo + b];
+                p.clear();
+                p.reserve(N);
+                for (size_t i = 0; i < N; ++i) {
+                    const double *s = &states[(b * N + i) * 5];
+                    p.emplace_back(s[0], s[1], s[2], s[3], s[4]);  // v = a = 0, like getOptimizedPath
+                }
             }
-        }
+        };
+        runThreads(nthr, unpack);
+        const auto tp3 = std::chrono::steady_clock::now();
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        lastShardMs()[0] = ms(tp0, tp1); lastShardMs()[1] = ms(tp1, tp2); lastShardMs()[2] = ms(tp2, tp3);
         return PO_OK;
+    }
+
+ public:
+    // host threads of the AoS <-> SoA pack / unpack of one shard (default: min(16, half the hardware threads); 1 = the caller's thread only)
+    static int &packThreads() { static int n = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 2)); return n; }
+    // what the calling thread's last shard spent where, ms: AoS -> SoA pack, po_solve_batch (pinned staging + H2D + solve + D2H: po_last_phase_ms splits it), unpack into State vectors
+    static double *lastShardMs() { static thread_local double v[3] = {0, 0, 0}; return v; }
+
+ private:
+    template <class Fn> static void runThreads(size_t n, Fn fn) {
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < n; ++t) th.emplace_back(fn, t);
+        fn(0);
+        for (auto &x : th) x.join();
     }
 
  protected:

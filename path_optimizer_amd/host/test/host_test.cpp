@@ -1,6 +1,7 @@
 // Host-side check of the OsqpSolver mirror: reads like the call site in the reference
 // (src/path_optimizer/path_optimizer.cpp:182-183).  Needs a GPU; prints a few numbers the pytest wrapper compares
 // with the oracle.  Usage: host_test <KP|KPC|K> <N> <B>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -15,7 +16,58 @@
 
 using namespace PathOptimizationNS;
 
+// host_test bench <KP|KPC|K> <N> <B> [reps]: what the drop-in's caller pays for a batch — OsqpSolver::solveBatch host to host (AoS -> SoA pack, po_solve_batch =
+// pinned staging + H2D + solve + D2H, unpack into std::vector<State>) at the setting bench.py quotes `value` at; printed per repetition (SURVEY.md §8d "H2D/D2H reported separately")
+static int bench_main(int argc, char **argv) {
+    const std::string type = argc > 2 ? argv[2] : "KP";
+    const size_t N = argc > 3 ? (size_t)std::atoi(argv[3]) : 200, B = argc > 4 ? (size_t)std::atoi(argv[4]) : 4096;
+    const int reps = argc > 5 ? std::atoi(argv[5]) : 5;
+    const int formulation = type == "KP" ? PO_KP : (type == "KPC" ? PO_KPC : PO_K);
+    std::vector<ReferencePath> refs(B);
+    std::vector<VehicleState> vs(B);
+    for (size_t b = 0; b < B; ++b) {
+        std::vector<State> st;
+        std::vector<CoveringCircleBounds> bd;
+        std::vector<double> mk, mkp;
+        double z = 0.3 * (double)(b % 17), x = 0, y = 0;
+        for (size_t i = 0; i < N; ++i) {
+            const double s = 0.25 * (double)i, k = 0.04 * std::sin(0.2 * s + (double)(b % 31));
+            st.emplace_back(x, y, z, k, s);
+            x += std::cos(z) * 0.25; y += std::sin(z) * 0.25; z += k * 0.25;
+            CoveringCircleBounds c;
+            const double w = 1.6 + 0.4 * std::sin(0.1 * (double)i + (double)(b % 13));
+            c.c0.lb = c.c1.lb = c.c2.lb = c.c3.lb = -w;
+            c.c0.ub = c.c1.ub = c.c2.ub = c.c3.ub = w;
+            bd.push_back(c);
+            mk.push_back(0.4 * 9.8 / 64.0); mkp.push_back(0.1 / 8.0);
+        }
+        refs[b].setReference(st); refs[b].setBounds(bd); refs[b].setLimits(mk, mkp);
+        vs[b] = VehicleState(State(0, 0, st[0].z, st[0].k), State(x, y, st[N - 1].z + 0.02), 0.2 - 0.01 * (double)(b % 29), 0.03);
+    }
+    std::vector<PlanningInstance> inst(B);
+    for (size_t b = 0; b < B; ++b) inst[b] = {&refs[b], &vs[b]};
+    po_params p;
+    po_default_params(&p);
+    p.refine = 2; p.refine_rounds = 5; p.refine_extra_rounds = 2; p.refine_eps = 1e-8; p.refine_chain = 2;  // bench.py HEADLINE
+    PoEngine eng(0, &p);
+    std::vector<std::vector<State>> paths;
+    std::vector<po_info> info;
+    for (int r = 0; r < reps + 1; ++r) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = OsqpSolver::solveBatch(formulation, inst.data(), B, N, &paths, &info, &eng);
+        const double tot = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        float ph[8] = {0};
+        po_last_phase_ms(eng.handle(), ph);
+        int solved = 0, cert = 0;
+        for (const po_info &i : info) { solved += i.status == PO_STATUS_SOLVED; cert += i.status_refine == 1; }
+        std::printf("bench rep %d rc=%d B=%zu N=%zu: solveBatch host-to-host %.2f ms = AoS->SoA pack %.2f + po_solve_batch %.2f (staging pack + H2D %.2f, solve %.2f, D2H %.2f, unpack %.2f) + State unpack %.2f; solved %d certified %d%s\n",
+                    r, rc, B, N, tot, OsqpSolver::lastShardMs()[0], OsqpSolver::lastShardMs()[1], ph[0], ph[1], ph[2], ph[4], OsqpSolver::lastShardMs()[2], solved, cert, r == 0 ? " (warm-up)" : "");
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && std::string(argv[1]) == "bench") return bench_main(argc, argv);
     std::string type = argc > 1 ? argv[1] : "KP";
     const size_t N = argc > 2 ? (size_t)std::atoi(argv[2]) : 60, B = argc > 3 ? (size_t)std::atoi(argv[3]) : 3;
     std::vector<ReferencePath> refs(B);

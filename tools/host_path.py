@@ -22,7 +22,7 @@ def main():
     threads = [int(a) for a in sys.argv[3:]] or [0]
     b = batch_of(name, B)
     p = binding.default_params()
-    p.refine, p.refine_rounds, p.refine_extra_rounds, p.refine_eps, p.refine_chain = 2, 5, 2, 3e-9, 2
+    p.refine, p.refine_rounds, p.refine_extra_rounds, p.refine_eps, p.refine_chain = 2, 5, 2, 1e-8, 2
     for nt in threads:
         eng = binding.Engine(0, p)
         eng.debug_set("host_threads", nt)

@@ -30,6 +30,10 @@ def main():
         setattr(p, k, type(getattr(p, k))(v))
     eng = binding.Engine(0, p)
     st, info, xs = eng.solve_batch(b, want_x=True)
+    try:
+        print("  paths handed to the fallback launch:", eng.debug_get("fallback_paths"))
+    except Exception as e:
+        print("  (no fallback count:", e, ")")
     t0 = time.time()
     ost, oinfo, oxs = O.solve_batch(b, O.device_equivalent_params(p))
     print(f"oracle {time.time() - t0:.1f} s")
