@@ -171,18 +171,28 @@ typedef struct po_params {
      * ~0.3 % of BASELINE config 3, and of a repeated polish); with it the method is monotone in phi and terminates finitely.  Certification, status_refine, the
      * rounds, the chained scheduling and the hand-back rules are those of refine = 1; po_info.iters counts a Newton step as one iteration. */
     double refine_newton_rho;           /* 1e3 (scaled problem) */
-    double refine_newton_rho_eq;        /* 1e4: penalty of the equality rows, fixed (NOT 1e3 x the inequality one as in OSQP's step vector: the merit's gradient carries
-                                           rho_eq x (a.x - b), a difference of O(1) numbers, whose rounding at rho_eq >= 1e6 alone sits above the dual tolerance) */
+    double refine_newton_rho_eq;        /* 1e4: penalty of the equality rows at the start of an attempt (NOT 1e3 x the inequality one as in OSQP's step vector: the merit's
+                                           gradient carries rho_eq x (a.x - b), a difference of O(1) numbers, whose rounding at rho_eq >= 1e6 sits near the dual tolerance);
+                                           raised only for a path whose multiplier updates stall, see refine_newton_rho_eq_max */
     double refine_newton_rho_max;       /* 1e5: a multiplier update that does not cut the primal residual by 4 raises the penalty 10 x, up to this (the slow
                                            case: active rows that are nearly dependent through the heavily weighted curvature-rate variables) */
-    double refine_ls_tol;               /* 1e-4: the line search stops at |psi'(t)| <= tol |psi'(0)| */
+    double refine_ls_tol;               /* 0.3: the line search stops at |psi'(t)| <= tol |psi'(0)| (the search is a safeguarded Newton iteration on the piecewise-linear psi', so
+                                           what it accepts is close to the root anyway; measured on the whole BASELINE batches against 1e-4: 3 - 7 % fewer Newton steps AND 14 %
+                                           fewer evaluations per step, every path certified at the same distance from the optimum).  The final correction steps always search to 1e-4. */
     int    refine_ls_max;               /* 30: evaluations of psi' per line search at most */
     int    refine_newton_max;           /* 300: Newton steps per attempt (every round).  BASELINE config 3: mean 16, max 60; config 5 (KPC): mean 28, max ~210 */
-    int    refine_newton_final;         /* 1: once the point is certified at refine_eps, ONE more Newton step is taken from it (Newton converges quadratically once the
-                                           active set is right: the residuals drop to the rounding floor) — the accuracy a tighter refine_eps would buy without asking the
-                                           termination test for tolerances below what fp64 delivers on the KPC rows weighted 1e5 (measured: refine_eps 3e-9 leaves
-                                           93 of 4096 KPC paths stalling at r_dual 5e-9 until the step budget is spent).  0: stop at the certified point. */
+    int    refine_newton_final;         /* 3: once the point is certified at refine_eps, Newton steps go on (tight line search, no multiplier update) until the dual residual — the
+                                           gradient of the merit — sits 1e3 x below its tolerance, at most this many (none when it already does at certification).  Newton converges
+                                           quadratically once the active set is right, so this is normally ONE step to the rounding floor: the accuracy a tighter refine_eps would
+                                           buy, without asking the termination test for tolerances below what fp64 delivers on the KPC rows weighted 1e5 (measured: refine_eps 3e-9
+                                           leaves 93 of 4096 KPC paths stalling at r_dual 5e-9 until the step budget is spent).  Exactly one step is not enough: a step that changes
+                                           the active set can land with a LARGER dual residual than the certified point's (2 of 4096 KPC paths ended 1.06e-4 m from their optimum
+                                           that way; the offset e_y carries no cost of its own, so a gradient of 1e-7 is 1e-4 m there).  0: stop at the certified point. */
     int    reserved_newton;
+    double refine_newton_rho_eq_max;    /* 1e6: once the inequality penalty sits at refine_newton_rho_max and a multiplier update still does not cut the primal residual by 4,
+                                           the EQUALITY rows' penalty grows 10 x instead, up to this.  The case: the primal residual left on the dynamics rows, whose multipliers
+                                           converge at H / (H + rho_eq) per update when the active inequality rows beside them carry 10 x their penalty (wide corridors with a
+                                           large initial offset: 24 of 4096 paths of `host_test bench` ran out of updates uncertified without it; config 5: hardest path 222 -> 129) */
 } po_params;
 
 typedef struct po_info {

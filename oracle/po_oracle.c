@@ -24,6 +24,8 @@ void po_oracle_set_portable_math(int on) { g_portable_math = on != 0; }
 int po_oracle_get_portable_math(void) { return g_portable_math; }
 static int g_refine_trace = 0; /* developer aid: one stderr line per refinement block and round (tools/refine_trace.py) */
 void po_oracle_set_refine_trace(int on) { g_refine_trace = on != 0; }
+static long long g_ls_evals = 0, g_nw_steps = 0; /* developer aid (tools/newton_eval.py): line-search evaluations and Newton steps since the last read; not thread-safe */
+long long po_oracle_ls_evals(long long *steps) { const long long e = g_ls_evals; if (steps) *steps = g_nw_steps; g_ls_evals = 0; g_nw_steps = 0; return e; }
 double po_oracle_psin(double x) { return po_psin(x); }
 double po_oracle_pcos(double x) { return po_pcos(x); }
 double po_oracle_patan2(double y, double x) { return po_patan2(y, x); }
@@ -100,7 +102,7 @@ void po_oracle_default_params(po_params *p) {
     p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-7; p->refine_rounds = 1; p->probe_iters = 0;  /* (probe_iters: device scheduling only, no effect on results) */
     p->refine_chain = 1; /* device scheduling only */
     p->refine_extra_rounds = 0; p->refine_adapt = 1; p->refine_speculate = 1; /* (device scheduling only) */
-    p->refine_newton_rho = 1e3; p->refine_newton_rho_eq = 1e4; p->refine_newton_rho_max = 1e5; p->refine_ls_tol = 1e-4; p->refine_ls_max = 30; p->refine_newton_max = 300; p->refine_newton_final = 1; /* refine = 2 */
+    p->refine_newton_rho = 1e3; p->refine_newton_rho_eq = 1e4; p->refine_newton_rho_max = 1e5; p->refine_ls_tol = 0.3; p->refine_ls_max = 30; p->refine_newton_max = 300; p->refine_newton_final = 3; p->reserved_newton = 0; p->refine_newton_rho_eq_max = 1e6; /* refine = 2 */
 }
 
 /* tools.hpp:24-35 — recursive in the reference; same fixed point as this loop */
@@ -1204,12 +1206,13 @@ resume_main:
             /* equality rows: a FIXED penalty (not 1e3 x the inequality one): the gradient carries rho_eq x (a.x - b), a difference of O(1) numbers — at 1e6 and more
              * its rounding alone (1e-16 x 1e6 x the unscaling) sits above the dual tolerance */
             double rb_in = rn_, pri_outer = -1.0;
-            const double rb_eq = prm->refine_newton_rho_eq > 0 ? prm->refine_newton_rho_eq : 1e4;
+            double rb_eq = prm->refine_newton_rho_eq > 0 ? prm->refine_newton_rho_eq : 1e4;
+            const double eq_cap = prm->refine_newton_rho_eq_max; /* (below rb_eq: never grows) */
             const int cap_nw = prm->refine_newton_max > 0 ? prm->refine_newton_max : 300;
             const int ls_max = prm->refine_ls_max > 0 ? prm->refine_ls_max : 30;
             double *w = (double *)malloc(sizeof(double) * (size_t)(m + 1)), *sv = (double *)malloc(sizeof(double) * (size_t)(m + 1));
             double *dv = (double *)malloc(sizeof(double) * (size_t)n), *Pd = (double *)malloc(sizeof(double) * (size_t)n);
-            int first_fac = 1, nouter = 0, fail = 0, certified = 0, final_done = 0;
+            int first_fac = 1, nouter = 0, fail = 0, certified = 0, nfinal = 0;
             csc_mv(n, m, Ap0, Ai0, Ax, x, Axv);
             for (int i = 0; i < m; ++i) w[i] = Axv[i] + (ctype[i] == 0 ? y[i] / rb_in : (ctype[i] == 1 ? y[i] / rb_eq : 0.0));
             for (;;) {
@@ -1229,20 +1232,29 @@ resume_main:
                 const double nAty = vnorm_inf_scaled(Dinv, Aty, n), nPx = vnorm_inf_scaled(Dinv, Pxv, n), nq = vnorm_inf_scaled(Dinv, q, n);
                 double dn = nq > nAty ? nq : nAty;
                 dn = dn > nPx ? dn : nPx;
-                const int dual_ok = dua_res < prm->refine_eps + prm->refine_eps * cinv * dn;
+                const double tol_d = prm->refine_eps + prm->refine_eps * cinv * dn;
+                const int dual_ok = dua_res < tol_d;
                 stop = dual_ok && pri_res < prm->refine_eps + prm->refine_eps * (nz > nAx ? nz : nAx);
                 if (g_refine_trace) fprintf(stderr, "  newton round %d step %d outer %d nfac %d  r_prim %.3e r_dual %.3e%s\n", round, it2, nouter, nfac, pri_res, dua_res, stop ? "  CERTIFIED" : "");
-                if (final_done) { stop = 1; break; } /* the point after the final correction step (certified before it) */
-                if (stop && !prm->refine_newton_final) break;
-                if (stop) certified = 1; /* refine_newton_final: one more Newton step from the certified point (quadratic convergence: residuals down to the noise floor) */
-                else if (it2 >= cap_nw) break;
+                /* refine_newton_final: from the certified point Newton steps go on (tight line search; quadratic convergence once the active set is right) until the
+                 * dual residual — the gradient of the merit — sits 100 x below its tolerance, at most that many steps */
+                if (certified) {
+                    if (dua_res < 1e-3 * tol_d || nfinal >= prm->refine_newton_final) { stop = 1; break; }
+                } else if (stop) {
+                    if (prm->refine_newton_final <= 0 || dua_res < 1e-3 * tol_d) break;
+                    certified = 1;
+                } else if (it2 >= cap_nw) break;
                 if (!certified && dual_ok) { /* the inner problem is solved: multiplier update, w <- A x + (w - clip(w)) */
                     if (++nouter > 50) break;
-                    /* a multiplier update that did not cut the primal residual by 4: the penalty grows 10 x (the multipliers stay, w is re-expressed) */
-                    double ratio = 1.0;
-                    if (pri_outer >= 0.0 && pri_res > 0.25 * pri_outer && rb_in * 10.0 <= prm->refine_newton_rho_max) { ratio = 0.1; rb_in *= 10.0; first_fac = 1; }
+                    /* a multiplier update that did not cut the primal residual by 4: the penalty grows 10 x (the multipliers stay, w is re-expressed) — the inequality
+                     * rows' up to refine_newton_rho_max, then the equality rows' up to refine_newton_rho_eq_max */
+                    double ratio = 1.0, ratio_eq = 1.0;
+                    if (pri_outer >= 0.0 && pri_res > 0.25 * pri_outer) {
+                        if (rb_in * 10.0 <= prm->refine_newton_rho_max) { ratio = 0.1; rb_in *= 10.0; first_fac = 1; }
+                        else if (rb_eq * 10.0 <= eq_cap) { ratio_eq = 0.1; rb_eq *= 10.0; first_fac = 1; }
+                    }
                     pri_outer = pri_res;
-                    for (int i = 0; i < m; ++i) w[i] = Axv[i] + (ctype[i] == 1 ? 1.0 : ratio) * (w[i] - z[i]);
+                    for (int i = 0; i < m; ++i) w[i] = Axv[i] + (ctype[i] == 1 ? ratio_eq : ratio) * (w[i] - z[i]);
                     continue;
                 }
                 /* Newton step: rows outside their bounds at rho_i, the others at RHO_MIN (the matrix of refine = 1) */
@@ -1274,6 +1286,7 @@ resume_main:
                 for (int ev = -1; ev < ls_max; ++ev) { /* ev = -1: psi'(0) */
                     const double tt = ev < 0 ? 0.0 : t;
                     double f = c0 + c1 * tt, fp = c1;
+                    ++g_ls_evals;
                     for (int i = 0; i < m; ++i)
                         if (ctype[i] == 0) {
                             const double ww = w[i] + tt * sv[i];
@@ -1281,7 +1294,7 @@ resume_main:
                             else if (ww > u[i]) { f += rb_in * (ww - u[i]) * sv[i]; fp += rb_in * sv[i] * sv[i]; }
                         }
                     if (ev < 0) { f0 = f; if (!(f0 < 0.0)) { fail = 1; break; } continue; }
-                    if (fabs(f) <= prm->refine_ls_tol * fabs(f0)) break;
+                    if (fabs(f) <= (certified && prm->refine_ls_tol > 1e-4 ? 1e-4 : prm->refine_ls_tol) * fabs(f0)) break; /* (the final correction step: always the tight search) */
                     if (f < 0) lo = t; else hi = t;
                     double tnx = fp > 0 ? t - f / fp : -1.0;
                     if (!(tnx > lo && (hi < 0 || tnx < hi))) tnx = hi < 0 ? 2.0 * t : 0.5 * (lo + hi);
@@ -1296,10 +1309,11 @@ resume_main:
                     fprintf(stderr, "      c0 %.6e c1 %.6e f0 %.6e t %.9f\n", c0 / cscale, c1 / cscale, f0 / cscale, t);
                 }
                 if (fail) { stop = certified; break; } /* not a descent direction (rounding at the bottom of the merit): the attempt ends here — certified if it was */
+                ++g_nw_steps;
                 for (int i = 0; i < n; ++i) x[i] += t * dv[i];
                 for (int i = 0; i < m; ++i) w[i] += t * sv[i];
                 ++it2;
-                if (certified) final_done = 1;
+                if (certified) ++nfinal;
             }
             free(w); free(sv); free(dv); free(Pd);
         } else

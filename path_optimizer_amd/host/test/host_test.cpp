@@ -63,6 +63,28 @@ static int bench_main(int argc, char **argv) {
         std::printf("bench rep %d rc=%d B=%zu N=%zu: solveBatch host-to-host %.2f ms = AoS->SoA pack %.2f + po_solve_batch %.2f (staging pack + H2D %.2f, solve %.2f, D2H %.2f, unpack %.2f) + State unpack %.2f; solved %d certified %d%s\n",
                     r, rc, B, N, tot, OsqpSolver::lastShardMs()[0], OsqpSolver::lastShardMs()[1], ph[0], ph[1], ph[2], ph[4], OsqpSolver::lastShardMs()[2], solved, cert, r == 0 ? " (warm-up)" : "");
     }
+    // the same batch split over E engines on ONE device (own handle, stream, pinned staging and host thread each; `host_test bench KP 200 4096 5 4`): slice k's H2D, solve and D2H
+    // overlap the other slices' — what SURVEY.md §8e asks the multi-device path not to serialise on, measured where there is one device
+    const int E = argc > 6 ? std::atoi(argv[6]) : 0;
+    if (E > 1) {
+        std::vector<std::unique_ptr<PoEngine>> own;
+        std::vector<PoEngine *> engs;
+        for (int e = 0; e < E; ++e) { own.emplace_back(new PoEngine(0, &p)); engs.push_back(own.back().get()); }
+        const int pt = OsqpSolver::packThreads();
+        OsqpSolver::packThreads() = std::max(1, pt / E);
+        for (int r = 0; r < reps + 1; ++r) {
+            std::vector<double> dms;
+            const auto t0 = std::chrono::steady_clock::now();
+            const int rc = OsqpSolver::solveBatch(formulation, inst.data(), B, N, &paths, &info, engs, &dms);
+            const double tot = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            int solved = 0, cert = 0;
+            for (const po_info &i : info) { solved += i.status == PO_STATUS_SOLVED; cert += i.status_refine == 1; }
+            std::printf("bench rep %d rc=%d B=%zu N=%zu over %d engines on device 0: solveBatch host-to-host %.2f ms; per shard", r, rc, B, N, E, tot);
+            for (double d : dms) std::printf(" %.2f", d);
+            std::printf("; solved %d certified %d%s\n", solved, cert, r == 0 ? " (warm-up)" : "");
+        }
+        OsqpSolver::packThreads() = pt;
+    }
     return 0;
 }
 

@@ -3,7 +3,7 @@
 Yardstick: tests/golden/tight_full_<set>.npz — the exact optimum of EVERY path of BASELINE config 3 (4096), config 2 (1024), config 5 (KPC, N = 400: all 4096 since
 round 4), the K formulation (4096) and of 1024 paths of the keep-3 / N = 231 shape the reference's own pipeline hands the QP (generator make_tight_full.py: oracle
 ADMM to 1e-6, then a primal-dual active-set solve on the full KKT system, KKT residuals <= 3e-14; 4e-7 absolute on KPC).  Setting under test: the one bench.py
-reports as `value` (bench.HEADLINE) — since round 4 the Newton refinement (po_params.refine = 2) entered after the first termination check, refine_eps 1e-8 plus one final Newton correction step (refine_newton_final), the
+reports as `value` (bench.HEADLINE) — since round 4 the Newton refinement (po_params.refine = 2) entered after the first termination check, refine_eps 1e-8 plus the final Newton correction steps (refine_newton_final), the
 same setting on every shape; the round-3 headline (activity-weighted ADMM continuation, refine = 1) is kept beside it on configs 3 and 2.
 
 CPU: the oracle's implementation on a sample of every set.  GPU: the device on every path of every set — 0 paths beyond 1e-4 m, every path certified

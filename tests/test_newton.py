@@ -37,7 +37,7 @@ def _rms(batch, xs, gold):
 
 def test_oracle_newton_defaults(oracle):
     p = oracle.default_params()
-    assert (p.refine_newton_rho, p.refine_newton_rho_eq, p.refine_newton_rho_max, p.refine_ls_tol, p.refine_ls_max, p.refine_newton_max, p.refine_newton_final) == (1e3, 1e4, 1e5, 1e-4, 30, 300, 1)
+    assert (p.refine_newton_rho, p.refine_newton_rho_eq, p.refine_newton_rho_max, p.refine_ls_tol, p.refine_ls_max, p.refine_newton_max, p.refine_newton_final, p.refine_newton_rho_eq_max) == (1e3, 1e4, 1e5, 0.3, 30, 300, 3, 1e6)
 
 
 @pytest.mark.parametrize("name,B", [("c3", 512), ("c2", 256), ("c5", 96), ("k", 128), ("keep3", 128)])
@@ -80,15 +80,51 @@ def test_oracle_newton_failed_attempt_falls_back_to_the_rounds(oracle):
     assert (i2["iters"] <= info["iters"]).all() and info["iters"].mean() > 2 * i2["iters"].mean()  # went on through the rounds
 
 
+def _host_bench_batch(B):
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    from host_workload import host_batch
+    return host_batch(B)
+
+
+def test_oracle_newton_wide_corridor_batch_needs_the_equality_penalty_growth(oracle):
+    """The synthetic batch of `host_test bench` (wide corridors, 0.2 m initial offset): once the inequality penalty sits at its cap the primal residual left on the
+    dynamics rows falls by < 1 % per multiplier update; with refine_newton_rho_eq_max (default 1e6) the equality penalty grows instead and every path certifies."""
+    b = _host_bench_batch(128)
+    p = _set(oracle.device_equivalent_params(), **NEWTON)
+    _, info, _ = oracle.solve_batch(b, p)
+    assert (info["status"] == 1).all() and (info["status_refine"] == 1).all() and info["iters"].max() < 200, (info["iters"].max(), (info["status_refine"] != 1).sum())
+    q = _set(oracle.device_equivalent_params(), **NEWTON)
+    q.refine_newton_rho_eq_max = 0.0  # (never grows: round-4 behaviour before the rule)
+    _, i0, _ = oracle.solve_batch(b, q)
+    assert (i0["status_refine"] != 1).sum() >= 1 and i0["iters"].max() > 400  # paths 2, 109: ~450 - 550 iterations, uncertified
+
+
+@pytest.mark.gpu
+def test_device_newton_wide_corridor_batch_matches_oracle(oracle):
+    from path_optimizer_amd import binding
+
+    b = _host_bench_batch(128)
+    p = _set(binding.default_params(), **NEWTON)
+    st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
+    ost, oinfo, oxs = oracle.solve_batch(b, oracle.device_equivalent_params(p))
+    assert (info["status"] == 1).all() and (info["status_refine"] == 1).all() and (oinfo["status_refine"] == 1).all()
+    assert abs(info["iters"].mean() - oinfo["iters"].mean()) <= 0.05 * oinfo["iters"].mean() and info["iters"].max() < 250
+    dx = np.abs(xs - oxs).max(axis=1)
+    assert dx.max() < 1e-4 and np.median(dx) < 1e-7, (dx.max(), np.median(dx))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,B,kw", [("c3", 256, {}), ("c2", 128, {}), ("c5", 32, {}), ("k", 64, {}), ("keep3", 64, {}),
                                        ("c3", 64, dict(refine_rounds=3)), ("c3", 64, dict(refine_chain=0)), ("c3", 64, dict(refine_chain=3)), ("c3", 64, dict(refine_chain=3, refine_newton_max=5)), ("c3", 256, dict(refine_chain=1)), ("c3", 64, dict(refine_chain=1, refine_speculate=-1)),
                                        ("c5", 32, dict(refine_chain=1)), ("k", 64, dict(refine_chain=1)), ("c3", 64, dict(refine_newton_max=5))])
 def test_device_newton_matches_oracle_and_optimum(oracle, name, B, kw):
     """Every scheduling of the same algorithm (split launches = the headline, chained single launch pair, one launch pair per round) against the oracle.
-    Newton step counts: the two implementations take the same steps until a row sits on its bound to rounding (a weakly active row is in or out of the
-    Newton matrix by the last bits of a.x; either choice converges) — measured on the whole batches: equal (iterations, refactorisations) on 78 % of
-    config 3, 62 % of config 2, 70 % of K, 26 - 42 % of config 5 (KPC: two more slack families sitting on their bounds), |difference| <= 3 on >= 95 %."""
+    Newton step counts: the two implementations take the same steps until a decision falls inside the rounding noise of one of them — a row that sits on its
+    bound to the last bits is in or out of the Newton matrix, the line search stops at |psi'| <= 0.3 |psi'(0)| one evaluation earlier or later, and the dual
+    residual of a certified point (~1e-10, below what either implementation resolves: the device's block-tridiagonal solve leaves 1e-10 .. 1e-12, the oracle's
+    sparse LDL' 1e-13) is or is not already 1e3 x below its tolerance, which decides whether a correction step follows.  Every such fork converges to the same
+    certified point.  Measured on the whole batches (tools/newton_dev.py): |difference in iterations| <= 1 on 93 % of config 3, 86 % of config 2, 96 % of K, 98 % of
+    keep 3, 79 % of config 5 (KPC: two more slack families on their bounds); <= 2 on 96 - 100 %; <= 3 on >= 99 %; equal means to 1 %."""
     from path_optimizer_amd import binding
 
     b = batch_of(name, B)
@@ -101,8 +137,8 @@ def test_device_newton_matches_oracle_and_optimum(oracle, name, B, kw):
     if "refine_newton_max" not in kw:
         assert (info["status_refine"] == 1).all() and (oinfo["status_refine"] == 1).all()
     di = np.abs(info["iters"].astype(int) - oinfo["iters"].astype(int))
-    same = (di == 0) & (info["n_refactor"] == oinfo["n_refactor"])
-    assert same.mean() >= (0.15 if name == "c5" else 0.4), (same.mean(), info["iters"][~same], oinfo["iters"][~same])
+    if "refine_newton_max" not in kw:
+        assert (di <= 1).mean() >= (0.6 if name == "c5" else 0.75) and (di <= 2).mean() >= (0.85 if name == "c5" else 0.95), ((di <= 1).mean(), (di <= 2).mean(), info["iters"][di > 1], oinfo["iters"][di > 1])
     assert (di <= 3).mean() >= 0.9 and abs(info["iters"].mean() - oinfo["iters"].mean()) <= 0.05 * oinfo["iters"].mean()
     dx = np.abs(xs - oxs).max(axis=1)
     assert dx.max() < 1e-4 and np.median(dx) < 1e-8, (dx.max(), np.median(dx))

@@ -47,6 +47,8 @@ def main():
     print(f"  device: status==1 {(info['status'] == 1).sum()} certified {(info['status_refine'] == 1).sum()} iters mean {info['iters'].mean():.1f} max {info['iters'].max()}  nref mean {info['n_refactor'].mean():.1f}")
     print(f"  oracle: status==1 {(oinfo['status'] == 1).sum()} certified {(oinfo['status_refine'] == 1).sum()} iters mean {oinfo['iters'].mean():.1f} max {oinfo['iters'].max()}  nref mean {oinfo['n_refactor'].mean():.1f}")
     print(f"  equal (iters, nref) {same.mean():.3f}; max |dx| {dx.max():.2e} median {np.median(dx):.2e}; rms vs exact max {rms.max():.2e} n>1e-4 {(rms > 1e-4).sum()}")
+    di = np.abs(info["iters"].astype(int) - oinfo["iters"].astype(int)); dn = np.abs(info["n_refactor"].astype(int) - oinfo["n_refactor"].astype(int))
+    print(f"  |d iters| <= 1: {(di <= 1).mean():.3f}  <= 2: {(di <= 2).mean():.3f}  <= 3: {(di <= 3).mean():.3f}; |d nref| <= 1: {(dn <= 1).mean():.3f} <= 2: {(dn <= 2).mean():.3f}; iters equal {(di == 0).mean():.3f}")
     bad = np.where(~same)[0][:10]
     for i in bad:
         print(f"   path {i}: dev it {info['iters'][i]} nref {info['n_refactor'][i]} sref {info['status_refine'][i]} rp {info['r_prim'][i]:.2e} rd {info['r_dual'][i]:.2e} | "
