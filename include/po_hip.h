@@ -488,7 +488,7 @@ int po_last_kernel_ms(po_handle h, float *ms);
 /* Where the last solve spent its time, ms8[8] (hipEvents on the handle's stream + host wall clock; valid after the call returned / the stream was synchronised):
  *   after po_solve_batch (host pointers: the caller's arrays are packed into a pinned staging block on several host threads while the slices already packed travel
  *   over PCIe, one D2H into a pinned block, threaded unpack): [0] pack + H2D, [1] the solve (= po_last_kernel_ms), [2] D2H, [3] host pack alone, [4] host unpack;
- *   with po_params.refine = 2, refine_chain = 2 (either entry): [5] equilibration + warm-start launches, [6] the Newton launch, [7] fallback launches + status sweep. */
+ *   with po_params.refine = 2, refine_chain = 2 (either entry): [5] equilibration + warm-start launches, [6] the Newton launch, [7] what follows it: the fallback launch when a path needs it (refine_chain = 3: always), status sweep. */
 int po_last_phase_ms(po_handle h, float *ms8);
 
 const char *po_strerror(int code);
