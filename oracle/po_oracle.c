@@ -102,7 +102,7 @@ void po_oracle_default_params(po_params *p) {
     p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-7; p->refine_rounds = 1; p->probe_iters = 0;  /* (probe_iters: device scheduling only, no effect on results) */
     p->refine_chain = 1; /* device scheduling only */
     p->refine_extra_rounds = 0; p->refine_adapt = 1; p->refine_speculate = 1; /* (device scheduling only) */
-    p->refine_newton_rho = 1e3; p->refine_newton_rho_eq = 1e4; p->refine_newton_rho_max = 1e5; p->refine_ls_tol = 0.3; p->refine_ls_max = 30; p->refine_newton_max = 300; p->refine_newton_final = 3; p->reserved_newton = 0; p->refine_newton_rho_eq_max = 1e6; /* refine = 2 */
+    p->refine_newton_rho = 100.0; p->refine_newton_rho_eq = 1e4; p->refine_newton_rho_max = 1e5; p->refine_ls_tol = 0.3; p->refine_ls_max = 30; p->refine_newton_max = 300; p->refine_newton_final = 3; p->reserved_newton = 0; p->refine_newton_rho_eq_max = 1e6; /* refine = 2 */
 }
 
 /* tools.hpp:24-35 — recursive in the reference; same fixed point as this loop */

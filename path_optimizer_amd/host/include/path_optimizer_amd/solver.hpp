@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cstddef>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -63,9 +64,21 @@ class PoEngine {
         static const All all;
         return all.view;
     }
+    // Grow-only SoA staging of this engine's batches (solveBatch): a fresh 85 MB allocation per call costs more in first-touch page faults than the pack itself.
+    // A handle runs one batch at a time (po_solve_batch is not re-entrant on one handle), so callers hold mutex() from the pack to the unpack.
+    std::mutex &mutex() { return mu_; }
+    double *stagingIn(size_t n) { return grow(in_, in_cap_, n); }
+    double *stagingOut(size_t n) { return grow(out_, out_cap_, n); }
  private:
+    static double *grow(std::unique_ptr<double[]> &b, size_t &cap, size_t n) {
+        if (n > cap) { b.reset(new double[n]); cap = n; }  // (uninitialised: every element a caller reads was written by its pack / by po_solve_batch)
+        return b.get();
+    }
     po_handle h_{};
     po_params params_{};
+    std::mutex mu_;
+    std::unique_ptr<double[]> in_, out_;
+    size_t in_cap_ = 0, out_cap_ = 0;
 };
 
 struct PlanningInstance {  // what one OsqpSolver object holds references to in the reference (solver.hpp:50-51)
@@ -155,10 +168,10 @@ class OsqpSolver {
     static int solveShard(int formulation, const PlanningInstance *inst, size_t lo, size_t hi, size_t horizon, std::vector<std::vector<State>> *paths,
                           po_info *info, PoEngine *eng, int *keep_out) {
         const size_t N = horizon, B = hi - lo;
+        std::lock_guard<std::mutex> engine_lock(eng->mutex());
         const auto tp0 = std::chrono::steady_clock::now();
-        // (uninitialised staging: every element is written by the pack below)
-        std::unique_ptr<double[]> buf(new double[B * N * (13 + (formulation == PO_KPC ? 2 : 0)) + B * 4]);
-        double *rx = buf.get(), *ry = rx + B * N, *rz = ry + B * N, *rk = rz + B * N, *rs = rk + B * N, *bd = rs + B * N, *x0 = bd + B * N * 8, *gz = x0 + B * 3;
+        double *const buf = eng->stagingIn(B * N * (13 + (formulation == PO_KPC ? 2 : 0)) + B * 4);
+        double *rx = buf, *ry = rx + B * N, *rz = ry + B * N, *rk = rz + B * N, *rs = rk + B * N, *bd = rs + B * N, *x0 = bd + B * N * 8, *gz = x0 + B * 3;
         double *mk = gz + B, *mkp = mk + (formulation == PO_KPC ? B * N : 0);
         // AoS -> SoA pack on several host threads: contiguous slices of the shard (the multi-device caller already runs one thread per device)
         const size_t nthr = std::max<size_t>(1, std::min<size_t>({(size_t)packThreads(), B / 64 + 1, (size_t)16}));
@@ -208,8 +221,8 @@ class OsqpSolver {
         int rc = po_problem_dims(formulation, (int)N, keep, &n, &m, &C);
         if (rc) return rc;
         po_batch_in in{formulation, (int)B, (int)N, keep, rx, ry, rz, rk, rs, bd, x0, gz, formulation == PO_KPC ? mk : nullptr, formulation == PO_KPC ? mkp : nullptr, nullptr, nullptr};
-        std::unique_ptr<double[]> states(new double[B * N * 5]);
-        po_batch_out out{states.get(), info + lo, nullptr};
+        double *const states = eng->stagingOut(B * N * 5);
+        po_batch_out out{states, info + lo, nullptr};
         rc = po_solve_batch(eng->handle(), &in, &out);
         if (rc) return rc;
         const auto tp2 = std::chrono::steady_clock::now();

@@ -16,13 +16,16 @@
 
 using namespace PathOptimizationNS;
 
-// host_test bench <KP|KPC|K> <N> <B> [reps]: what the drop-in's caller pays for a batch — OsqpSolver::solveBatch host to host (AoS -> SoA pack, po_solve_batch =
+// host_test bench <KP|KPC|K> <N> <B> [reps] [engines] [corridor half-width]: what the drop-in's caller pays for a batch — OsqpSolver::solveBatch host to host (AoS -> SoA pack, po_solve_batch =
 // pinned staging + H2D + solve + D2H, unpack into std::vector<State>) at the setting bench.py quotes `value` at; printed per repetition (SURVEY.md §8d "H2D/D2H reported separately")
 static int bench_main(int argc, char **argv) {
     const std::string type = argc > 2 ? argv[2] : "KP";
     const size_t N = argc > 3 ? (size_t)std::atoi(argv[3]) : 200, B = argc > 4 ? (size_t)std::atoi(argv[4]) : 4096;
     const int reps = argc > 5 ? std::atoi(argv[5]) : 5;
     const int formulation = type == "KP" ? PO_KP : (type == "KPC" ? PO_KPC : PO_K);
+    // corridor half-width 1.6 +- 0.4 m by default: NARROWER than the soft margin on part of every path, a degenerate and slow case for the refinement (tests/test_newton.py
+    // rebuilds this batch in numpy); argv[7] = 2.6 gives BASELINE-like corridors
+    const double w0 = argc > 7 ? std::atof(argv[7]) : 1.6;
     std::vector<ReferencePath> refs(B);
     std::vector<VehicleState> vs(B);
     for (size_t b = 0; b < B; ++b) {
@@ -35,7 +38,7 @@ static int bench_main(int argc, char **argv) {
             st.emplace_back(x, y, z, k, s);
             x += std::cos(z) * 0.25; y += std::sin(z) * 0.25; z += k * 0.25;
             CoveringCircleBounds c;
-            const double w = 1.6 + 0.4 * std::sin(0.1 * (double)i + (double)(b % 13));
+            const double w = w0 + 0.4 * std::sin(0.1 * (double)i + (double)(b % 13));
             c.c0.lb = c.c1.lb = c.c2.lb = c.c3.lb = -w;
             c.c0.ub = c.c1.ub = c.c2.ub = c.c3.ub = w;
             bd.push_back(c);
