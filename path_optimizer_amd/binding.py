@@ -142,6 +142,10 @@ class Engine:
         """po_debug_set: developer A/B switches (identity_order, debug_cycles, split, smooth_seq, smooth_waves, smooth_nopad, smooth_debug, dp_one_wave)."""
         _check(lib().po_debug_set(self._h, key.encode(), int(value)))
 
+    def solve_status(self):
+        """po_solve_status: 0 = the last solve's device-side work queue drained normally; PO_ERR_HIP = a waiter timed out (synchronises the handle's stream)."""
+        return int(lib().po_solve_status(self._h))
+
     def debug_get(self, key: str) -> int:
         v = C.c_longlong()
         _check(lib().po_debug_get(self._h, key.encode(), C.byref(v)))

@@ -189,3 +189,61 @@ def test_device_newton_every_keep_value_matches_oracle(oracle, keep, N, ds):
         assert (info["status_refine"][ok] == 1).all()
         assert (np.abs(info["iters"].astype(int) - oinfo["iters"].astype(int))[ok] <= 4).all(), (keep, N, pin, info["iters"], oinfo["iters"])
         assert np.abs(xs - oxs)[ok].max() < 1e-5, (keep, N, pin, np.abs(xs - oxs)[ok].max())
+
+
+@pytest.mark.gpu
+def test_device_newton_edge_cases_of_the_batch_interface(oracle):
+    """The headline setting through the cases the plain solve is tested on: empty batch, B = 1, N = 2 / 3 / 10, an infeasible corridor and non-finite inputs inside a
+    batch (never reported certified, the neighbours are unaffected), the caller's order hint (bit-identical), repeated solves (deterministic),
+    every scheduling giving the same statuses and certificates."""
+    import np_twin as T
+    from path_optimizer_amd import binding, synth
+
+    p = _set(binding.default_params(), **NEWTON)
+    eng = binding.Engine(0, p)
+    b0 = synth.make_batch(3, B=2); b0.B = 0
+    assert eng.solve_batch(b0)[0].shape[0] == 0
+    # B = 1 and tiny N, every formulation
+    for form in (T.PO_KP, T.PO_KPC, T.PO_K):
+        for N in (2, 3, 10):
+            rng = np.random.default_rng(7 + N)
+            i = T.random_instance(rng, N, ds=0.3)
+            one = lambda k: np.ascontiguousarray(i[k][None])
+            keep = 1 if form == T.PO_K else 4
+            b = synth.Batch(form, 1, N, keep, one("ref_x"), one("ref_y"), one("ref_z"), one("ref_k"), one("ref_s"), one("bounds"), one("x0"), np.array([i["goal_z"]]),
+                            one("max_k") if form == T.PO_KPC else None, one("max_kp") if form == T.PO_KPC else None)
+            st, info, xs = eng.solve_batch(b, want_x=True)
+            ost, oinfo, oxs = oracle.solve_batch(b, oracle.device_equivalent_params(p))
+            assert np.array_equal(info["status"], oinfo["status"]) and np.array_equal(info["status_refine"], oinfo["status_refine"]), (form, N, info, oinfo)
+            assert np.abs(xs - oxs).max() < 1e-6, (form, N, np.abs(xs - oxs).max())
+    # an infeasible corridor and non-finite inputs inside a batch
+    b = synth.make_batch(3, B=8)
+    clean = eng.solve_batch(b, want_x=True)
+    assert (clean[1]["status"] == 1).all() and (clean[1]["status_refine"] == 1).all()
+    b.bounds[1, 10, :, :] = [0.9, 1.0]
+    b.bounds[1, 11, :, :] = [-1.0, -0.9]
+    b.ref_k[3, 50] = np.nan
+    b.x0[6, 0] = np.inf
+    st, info, xs = eng.solve_batch(b, want_x=True)
+    ost, oinfo, oxs = oracle.solve_batch(b, oracle.device_equivalent_params(p))
+    good = np.array([0, 2, 4, 5, 7])
+    # (the infeasible path passes OSQP's test at 1e4 x eps, fails its Newton attempt and is found infeasible by the type-based iteration of a later round: -1, like the oracle)
+    assert info["status"][1] == oinfo["status"][1] and info["status"][1] != 1 and info["status_refine"][1] == oinfo["status_refine"][1] and info["status_refine"][1] != 1
+    assert (info["status"][[3, 6]] == -8).all() and (info["status_refine"][[3, 6]] == 0).all() and not np.isnan(st[3]).any()  # (a NaN input: outputs zeroed before any work; an Inf start state is caught in the iterate)
+    assert (info["status"][good] == 1).all() and (info["status_refine"][good] == 1).all()
+    assert np.array_equal(xs[good], clean[2][good]) and np.array_equal(info["iters"][good], clean[1]["iters"][good])
+    # order hint: bit-identical; repeated solve: bit-identical; schedulings: same statuses / certificates, same points to rounding
+    b = synth.make_batch(3, B=48)
+    st0, info0, x0 = eng.solve_batch(b, want_x=True)
+    order = np.argsort(-info0["iters"].astype(np.int64), kind="stable")
+    st1, info1, x1 = eng.solve_batch(b, want_x=True, order=order)
+    assert np.array_equal(x0, x1) and np.array_equal(info0["iters"], info1["iters"]) and np.array_equal(info0["n_refactor"], info1["n_refactor"])
+    st2, info2, x2 = eng.solve_batch(b, want_x=True)
+    assert np.array_equal(x0, x2) and np.array_equal(st0, st2)
+    for chain in (0, 1, 3):
+        q = _set(binding.default_params(), **NEWTON); q.refine_chain = chain
+        e2 = binding.Engine(0, q)
+        st3, info3, x3 = e2.solve_batch(b, want_x=True)
+        assert e2.solve_status() == 0
+        assert np.array_equal(info3["status"], info0["status"]) and np.array_equal(info3["status_refine"], info0["status_refine"])
+        assert np.abs(x3 - x0).max() < 1e-5 and (np.abs(info3["iters"].astype(int) - info0["iters"].astype(int)) <= 3).all()
