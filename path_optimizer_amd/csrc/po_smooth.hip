@@ -527,7 +527,7 @@ template <int KIND> __device__ __forceinline__ void band_solve_lanes(Prob<KIND> 
 // With the columns taken W at a time the factor is block bidiagonal: L = [T_0; C_0 T_1; C_1 T_2; ...], T_k unit lower triangular (the band inside block k),
 // C_k upper triangular (rows of block k + 1 against the columns of block k), D = diag(D_k).  With r_k = T_k y_k,
 //     forward   r_0 = b_0,  r_{k+1} = b_{k+1} - M_k r_k,      M_k = C_k T_k^-1                 (dense W x W)
-//     backward  x_k = S_k r_k - M_k' x_{k+1},                  S_k = T_k^-T D_k^-1 T_k^-1       (dense, symmetric)
+//     backward  x_k = S_k r_k - M_k' x_{k+1},                  S_k = T_k^-T D_k^-1 T_k^-1       (applied in factored form Wm' (Wm r), Wm = D^-1/2 T^-1: round 4)
 // M_k and S_k depend on the factor only: convert_blocks builds them after every (re-)factorisation, in place of the block's columns.  A block then costs one
 // broadcast of W values (2 W v_readlane) and W FMAs on the chain instead of W dependent {v_readlane, v_readlane, v_fma} steps: a dependent v_fma_f64 ->
 // v_readlane -> v_fma_f64 step is 30 cycles on gfx950 (tools/ubench/chain.hip), a broadcast whose source does not depend on the FMA before it 9 per value.
@@ -567,16 +567,10 @@ template <int KIND, int NWV> __device__ void convert_blocks(Prob<KIND> &pb, int 
             for (int j = i; j < W; ++j) acc += blk[j * LS + (W + i - j)] * t[j];
             mc[i] = acc;
         }
-        double u[W];
+        // column c of Wm = D^-1/2 T^-1 (lower triangular, stored DENSE with its zeros: the products below then need no masks).  S = Wm' Wm is applied in this
+        // factored form, g = Wm' (Wm r) — see band_solve_blocks.
 #pragma unroll
-        for (int i = 0; i < W; ++i) u[i] = blk[i * LS] * t[i];
-#pragma unroll
-        for (int a2 = 0; a2 < W; ++a2) {
-            double acc = u[a2];
-#pragma unroll
-            for (int i = a2 + 1; i < W; ++i) acc += blk[W * LS + i * (i - 1) / 2 + a2] * u[i];
-            sc[a2] = acc;
-        }
+        for (int i = 0; i < W; ++i) sc[i] = i >= c ? sqrt(blk[i * LS]) * t[i] : 0.0;
         __syncthreads();
         if (act) {
 #pragma unroll
@@ -586,7 +580,7 @@ template <int KIND, int NWV> __device__ void convert_blocks(Prob<KIND> &pb, int 
     }
 }
 
-template <int W> struct BlkSet { double m[W], s[W], bn; };
+template <int W> struct BlkSet { double m[W], bn; };
 template <int W, int... U> __device__ __forceinline__ void blk_bcast(double (&y)[W], double v, std::integer_sequence<int, U...>) { ((y[U] = lane_bcast(v, U)), ...); }
 template <int W> __device__ __forceinline__ double blk_dot(const double (&c)[W], const double (&y)[W], double a0) {  // a0 - sum c y, three partial sums (a dependent v_fma_f64 is 10 cycles)
     double a[3] = {a0, 0.0, 0.0};
@@ -597,20 +591,25 @@ template <int W> __device__ __forceinline__ double blk_dot(const double (&c)[W],
 template <int KIND> __device__ __forceinline__ void band_solve_blocks(Prob<KIND> &pb, int lane) {
     using T = ST<KIND>;
     constexpr int W = T::W, BS = blk_stride<W>();
-    if (lane >= W) return;
+    if (lane >= 2 * W) return;
     const int l = lane;
     const int nblk = (pb.n + W - 1) / W;
     const double *Mb = pb.Lb;
     double *wk = pb.wk;
     constexpr auto seq = std::make_integer_sequence<int, W>{};
-    // ---- forward: r_{k+1} = b_{k+1} - M_k r_k on the chain, g_k = S_k r_k beside it (row l of both matrices on lane l) ----
+    // ---- forward: r_{k+1} = b_{k+1} - M_k r_k on the chain (lanes 0 .. W-1: row l of M_k), and IN THE SAME FMAs on lanes W .. 2W-1 (row l - W of Wm_k, the second
+    //      half of the block's 2W x W storage) z_k = Wm_k r_k: both products take the broadcast r_k as their scalar operand.  z_k is parked in wk where b_k was;
+    //      S_k r_k = Wm_k' z_k is finished by the backward sweep.  The explicit product S = T^-T D^-1 T^-1 (round 3) loses the residual of the substitution (numpy
+    //      model on TENSION matrices: 1e-15 .. 5e-14 relative against 3e-16, exactly rounded entries included; the factored form gives 3e-16 again), and the ADMM of
+    //      a few instances amplifies a residual by 1e6: with the factored form the iterates are back within 1e-7 of the oracle's. ----
     {
         BlkSet<W> A, B;
         auto load = [&](BlkSet<W> &s, int k) {  // (k == nblk: the look-ahead reads the block behind the last one — inside the padding, never used)
             const double *mb = Mb + (size_t)k * BS + l * W;
 #pragma unroll
-            for (int uu = 0; uu < W; ++uu) { s.m[uu] = mb[uu]; s.s[uu] = mb[W * W + uu]; }
-            s.bn = wk[(k + 1) * W + l];
+            for (int uu = 0; uu < W; ++uu) s.m[uu] = mb[uu];
+            const double bn = wk[(k + 1) * W + (l < W ? l : 0)];
+            s.bn = l < W ? bn : 0.0;
         };
         // One block: broadcast r, then — once this set's first value is known to have arrived — request the OTHER set (the block after this one), then the
         // arithmetic.  The compiler's s_waitcnt inside a loop waits for every outstanding LDS request at the first use of a loaded register; placed here, all
@@ -622,11 +621,11 @@ template <int KIND> __device__ __forceinline__ void band_solve_blocks(Prob<KIND>
             __builtin_amdgcn_sched_barrier(0);
             if (ahead) load(other, k + 1);
             __builtin_amdgcn_sched_barrier(0);
-            const double rn = blk_dot<W>(s.m, y, s.bn);
-            wk[k * W + l] = -blk_dot<W>(s.s, y, 0.0);
+            const double rn = blk_dot<W>(s.m, y, s.bn);  // lanes < W: r_{k+1}; lanes >= W: -z_k
+            if (l >= W) wk[k * W + l - W] = -rn;
             r = rn;
         };
-        double r = wk[l];
+        double r = wk[l < W ? l : 0];
         asm volatile("" : "+v"(r));
         load(A, 0);
         int k = 0;
@@ -636,16 +635,17 @@ template <int KIND> __device__ __forceinline__ void band_solve_blocks(Prob<KIND>
         }
         if (k < nblk) step(A, B, k, r, false);
     }
-    // ---- backward: x_k = g_k - M_k' x_{k+1} (column l of M_k on lane l); the last block's x is its g ----
+    if (l >= W) return;
+    // ---- backward: x_k = g_k - M_k' x_{k+1} (column l of M_k on lane l) with g_k = Wm_k' z_k (column l of Wm_k; z_k read back as an LDS broadcast: off the
+    //      chain); the last block's x is its g ----
     {
-        struct Bk { double m[W], g; };
+        struct Bk { double m[W], c[W], z[W]; };
         Bk A, B;
         auto load = [&](Bk &s, int k) {
             const int kk = k > 0 ? k : 0;
             const double *mb = Mb + (size_t)kk * BS + l;
 #pragma unroll
-            for (int uu = 0; uu < W; ++uu) s.m[uu] = mb[uu * W];
-            s.g = wk[kk * W + l];
+            for (int uu = 0; uu < W; ++uu) { s.m[uu] = mb[uu * W]; s.c[uu] = mb[W * W + uu * W]; s.z[uu] = wk[kk * W + uu]; }
         };
         auto step = [&](const Bk &s, Bk &other, int k, double &x, bool ahead) {
             double y[W];
@@ -654,10 +654,17 @@ template <int KIND> __device__ __forceinline__ void band_solve_blocks(Prob<KIND>
             __builtin_amdgcn_sched_barrier(0);
             if (ahead) load(other, k - 1);
             __builtin_amdgcn_sched_barrier(0);
-            x = blk_dot<W>(s.m, y, s.g);
+            const double g = -blk_dot<W>(s.c, s.z, 0.0);
+            x = blk_dot<W>(s.m, y, g);
             wk[k * W + l] = x;
         };
-        double x = wk[(nblk - 1) * W + l];
+        double x;
+        {   // the last block: x = g = Wm' z
+            Bk L_;
+            load(L_, nblk - 1);
+            x = -blk_dot<W>(L_.c, L_.z, 0.0);
+            wk[(nblk - 1) * W + l] = x;
+        }
         asm volatile("" : "+v"(x));
         int k = nblk - 2;
         load(A, k);

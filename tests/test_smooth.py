@@ -161,19 +161,18 @@ def engine(dmap):
     return e
 
 
-def _compare(kind, dev, orc, inp, tol=1e-7, frac=0.9, blocked=True):
+def _compare(kind, dev, orc, inp, tol=1e-7, frac=0.9, blocked=True, wide=None):
     dx, dy, ds, dinfo, draw = dev
     ox, oy, os_, oinfo, oraw = orc
     assert np.array_equal(dinfo["status"], oinfo["status"]), (dinfo["status"], oinfo["status"])
     same = dinfo["iters"] == oinfo["iters"]
     assert same.mean() >= frac, (dinfo["iters"], oinfo["iters"])  # a residual within round-off of eps may flip one check
     assert np.array_equal(dinfo["n_refactor"][same], oinfo["n_refactor"][same])
-    # kinds 0 and 2: every instance within tol.  Kind 1 (TENSION, W = 9): the device's blocked substitution applies explicit inverses of the 9 x 9 triangles of the
-    # factor (po_smooth.hip band_solve_blocks) — a few ulp more round-off per solve than the oracle's substitution, which the ADMM of a few badly conditioned
-    # instances amplifies over hundreds of iterations (measured on this file's batches: 3 of 40 instances beyond 1e-7, worst 7.4e-7 m on coordinates of 60 m;
-    # the column-by-column device path: worst 5e-8 on the same instance).  At least `frac` of the instances within tol, all within 20 tol (eps is 1e-3).
+    # every instance within tol.  Kind 1 (TENSION, W = 9) runs the BLOCKED substitution (po_smooth.hip band_solve_blocks): since round 4 with S_k applied in factored
+    # form (Wm' (Wm r)), which has the residual of plain substitution — round 3's explicit S_k had 10 - 100 x that, which the ADMM of a few badly conditioned instances
+    # amplified to 7.4e-7 m (the bar was 2e-6 then); now the blocked and the column-by-column path sit equally close to the oracle (worst 9.4e-8 / 5.2e-8 on this file's batches).
     per = np.abs(draw - oraw).reshape(len(draw), -1).max(axis=1)[same]
-    wide = 20 * tol if (kind == 1 and blocked) else tol
+    wide = wide or tol
     assert per.max() < wide and (per < tol).mean() >= frac, (per.max(), (per < tol).mean())
     assert np.abs(dx[same] - ox[same]).max() < wide
     if kind < 2:
@@ -203,7 +202,9 @@ def test_device_matches_oracle(oracle, omap, dmap, kind, eps):
     op.eps_abs = op.eps_rel = eps
     orc = oracle.smooth_batch(kind, op, inp, m_map=omap, want_raw=True)
     assert (dev[3]["status"] == PO_STATUS_SOLVED).all()
-    _compare(kind, dev, orc, inp)
+    # TENSION at eps 1e-4 runs 1 200 - 2 000 iterations on its slowest instances: one of the 48 ends 1.15e-7 from the oracle on the blocked path (2.9e-9 column by column;
+    # the other batches measured, tools/smooth_tension_check.py: both paths <= 2.5e-8).  Everything else, and TENSION at the reference's eps 1e-3: 1e-7 on every instance.
+    _compare(kind, dev, orc, inp, wide=3e-7 if (kind == 1 and eps < 1e-3) else None)
 
 
 @pytest.mark.gpu
@@ -242,7 +243,7 @@ def test_device_matches_reference_fixtures(oracle, dmap, kind):
     inp = _gold_inputs(g, kind)
     dx, dy, ds, info, raw = eng.smooth_batch(kind, inp, want_raw=True)
     assert (info["status"] == PO_STATUS_SOLVED).all()
-    tol = 2e-6 if kind == 1 else 1e-7  # (kind 1: the blocked substitution's round-off, amplified by the ADMM — see _compare; measured worst 1.7e-7 here)
+    tol = 1e-7  # (kind 1 too since round 4: the blocked substitution applies S_k in factored form, see _compare)
     for b in range(6):
         n_pts = int(inp["n_points"][b])
         n, _ = oracle.smooth_dims(kind, n_pts)
@@ -356,7 +357,7 @@ def test_device_waves_per_qp_agree(engine, oracle, omap, kind, P):
 @pytest.mark.gpu
 def test_device_tension_full_batch_blocked_against_column_by_column(engine):
     """4096 TENSION QPs of 100 points (the size the stage is measured on; 256 distinct instances): the blocked substitution and the column-by-column one give the
-    same statuses and iteration counts on every instance and the same points to 2e-6; QPs of more points than the block layout's LDS budget allows (P = 160: natural
+    same statuses and iteration counts on every instance and the same points to 2e-7; QPs of more points than the block layout's LDS budget allows (P = 160: natural
     layout, column-by-column substitution on eight waves) agree with one wave per QP bit for bit."""
     base = synth.make_smooth_inputs(30, 256, P=100, kind=1)
     inp = {k: (None if v is None else np.concatenate([v] * 16)) for k, v in base.items()}
@@ -370,7 +371,7 @@ def test_device_tension_full_batch_blocked_against_column_by_column(engine):
     a, b = res["blocked"], res["columns"]
     assert (a[3]["status"] == PO_STATUS_SOLVED).all() and np.array_equal(a[3]["status"], b[3]["status"])
     assert np.array_equal(a[3]["iters"], b[3]["iters"]) and np.array_equal(a[3]["n_refactor"], b[3]["n_refactor"])
-    assert np.abs(a[4] - b[4]).max() < 2e-6 and np.abs(a[0] - b[0]).max() < 2e-6
+    assert np.abs(a[4] - b[4]).max() < 2e-7 and np.abs(a[0] - b[0]).max() < 2e-7
     assert np.array_equal(a[4][:256], a[4][256:512]) and np.array_equal(a[4][:256], a[4][-256:])  # the same instance gives the same bits wherever it sits in the batch
     from path_optimizer_amd import binding
     assert binding.lib().po_smooth_blocked(1, 100) == 1 and binding.lib().po_smooth_blocked(1, 160) == 0 and binding.lib().po_smooth_blocked(0, 100) == 0
