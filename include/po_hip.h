@@ -163,8 +163,8 @@ typedef struct po_params {
                                            point cancels the continuation; one that fails hands the path to it.  Takes the failed attempts of the hardest paths — up to
                                            600 refinement iterations each on BASELINE config 3 — off the launch's critical path.  -1: off. */
     /* refine = 2 (round 4): the refinement phase is a GLOBALISED method instead of the activity-weighted ADMM continuation of refine = 1 — semismooth Newton on
-     * the augmented Lagrangian  phi_y(x) = 1/2 x'Px + sum_i rho_i / 2 dist^2(a_i x + y_i / rho_i, [l_i, u_i])  (rho_i = refine_newton_rho on inequality rows, 1e3 x
-     * that on equality rows, scaled problem) with an EXACT line search on the piecewise-quadratic merit (safeguarded Newton on its piecewise-linear derivative),
+     * the augmented Lagrangian  phi_y(x) = 1/2 x'Px + sum_i rho_i / 2 dist^2(a_i x + y_i / rho_i, [l_i, u_i])  (rho_i = refine_newton_rho on inequality rows,
+     * refine_newton_rho_eq on equality rows, scaled problem) with a line search on the piecewise-quadratic merit (safeguarded Newton on its piecewise-linear derivative, run to refine_ls_tol),
      * and a multiplier update  y <- rho (w - clip(w))  whenever the inner problem is solved to the dual tolerance.  Each Newton step is ONE factorisation of the same
      * block-tridiagonal matrix the ADMM iteration uses, with the rows outside their bounds at rho_i and the others at OSQP's RHO_MIN (exactly the matrix of
      * refine = 1), one solve, and a few row passes for the line search.  Without the line search the activity set cycles (that is the failure mode of refine = 1 on

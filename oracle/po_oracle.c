@@ -1200,7 +1200,7 @@ resume_main:
         memcpy(snap + n + m, y, sizeof(double) * (size_t)m);
         if (prm->refine == 2) {
             /* ---- refine = 2: semismooth Newton on the augmented Lagrangian with an exact line search (po_hip.h).  State: x and w_i = a_i x + y_i / rho_i
-             * (one number per row, like the engine's v); implied z = clip(w), y = rho (w - z).  rho_i: rb on inequality rows, 1e3 rb on equality rows. ---- */
+             * (one number per row, like the engine's v); implied z = clip(w), y = rho (w - z).  rho_i: rb_in on inequality rows, rb_eq on equality rows (both grow on a stall, see below). ---- */
             double rn_ = prm->refine_newton_rho;
             rn_ = rn_ < OSQP_RHO_MIN ? OSQP_RHO_MIN : (rn_ > OSQP_RHO_MAX ? OSQP_RHO_MAX : rn_);
             /* equality rows: a FIXED penalty (not 1e3 x the inequality one): the gradient carries rho_eq x (a.x - b), a difference of O(1) numbers — at 1e6 and more
