@@ -190,7 +190,11 @@ typedef struct po_params {
                                            leaves 93 of 4096 KPC paths stalling at r_dual 5e-9 until the step budget is spent).  Exactly one step is not enough: a step that changes
                                            the active set can land with a LARGER dual residual than the certified point's (2 of 4096 KPC paths ended 1.06e-4 m from their optimum
                                            that way; the offset e_y carries no cost of its own, so a gradient of 1e-7 is 1e-4 m there).  0: stop at the certified point. */
-    int    reserved_newton;
+    int    refine_newton_escalate;      /* 12: from this many multiplier updates of an attempt on, refine_newton_rho_max and refine_newton_rho_eq_max stand 10 x higher, from twice as
+                                           many on 100 x.  For DEGENERATE optima (linearly dependent active rows — corridors narrower than the soft margin produce them): the
+                                           multipliers are not unique, the method of multipliers converges sublinearly at any fixed penalty (measured: the primal residual falls
+                                           0.4 % per update at 1.2 x its tolerance), and only a larger penalty shortens it.  On the narrow-corridor batch of `host_test bench`: 2 of
+                                           4096 paths uncertified and 15 - 18 through the fall-back rounds (12 - 27 ms) without it, none with it; no BASELINE path gets that far.  0: off. */
     double refine_newton_rho_eq_max;    /* 1e6: once the inequality penalty sits at refine_newton_rho_max and a multiplier update still does not cut the primal residual by 4,
                                            the EQUALITY rows' penalty grows 10 x instead, up to this.  The case: the primal residual left on the dynamics rows, whose multipliers
                                            converge at H / (H + rho_eq) per update when the active inequality rows beside them carry 10 x their penalty (wide corridors with a

@@ -102,7 +102,7 @@ void po_oracle_default_params(po_params *p) {
     p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-7; p->refine_rounds = 1; p->probe_iters = 0;  /* (probe_iters: device scheduling only, no effect on results) */
     p->refine_chain = 1; /* device scheduling only */
     p->refine_extra_rounds = 0; p->refine_adapt = 1; p->refine_speculate = 1; /* (device scheduling only) */
-    p->refine_newton_rho = 100.0; p->refine_newton_rho_eq = 1e4; p->refine_newton_rho_max = 1e5; p->refine_ls_tol = 0.3; p->refine_ls_max = 30; p->refine_newton_max = 300; p->refine_newton_final = 3; p->reserved_newton = 0; p->refine_newton_rho_eq_max = 1e6; /* refine = 2 */
+    p->refine_newton_rho = 100.0; p->refine_newton_rho_eq = 1e4; p->refine_newton_rho_max = 1e5; p->refine_ls_tol = 0.3; p->refine_ls_max = 30; p->refine_newton_max = 300; p->refine_newton_final = 3; p->refine_newton_escalate = 12; p->refine_newton_rho_eq_max = 1e6; /* refine = 2 */
 }
 
 /* tools.hpp:24-35 — recursive in the reference; same fixed point as this loop */
@@ -1249,9 +1249,13 @@ resume_main:
                     /* a multiplier update that did not cut the primal residual by 4: the penalty grows 10 x (the multipliers stay, w is re-expressed) — the inequality
                      * rows' up to refine_newton_rho_max, then the equality rows' up to refine_newton_rho_eq_max */
                     double ratio = 1.0, ratio_eq = 1.0;
+                    /* a long stall (degenerate optima: the multipliers are not unique and the method of multipliers converges sublinearly at any fixed penalty): from the
+                     * refine_newton_escalate-th update on both caps stand 10 x higher, from twice that on 100 x */
+                    const int esc_n = prm->refine_newton_escalate;
+                    const double esc = esc_n > 0 && nouter >= esc_n ? (nouter >= 2 * esc_n ? 100.0 : 10.0) : 1.0;
                     if (pri_outer >= 0.0 && pri_res > 0.25 * pri_outer) {
-                        if (rb_in * 10.0 <= prm->refine_newton_rho_max) { ratio = 0.1; rb_in *= 10.0; first_fac = 1; }
-                        else if (rb_eq * 10.0 <= eq_cap) { ratio_eq = 0.1; rb_eq *= 10.0; first_fac = 1; }
+                        if (rb_in * 10.0 <= prm->refine_newton_rho_max * esc) { ratio = 0.1; rb_in *= 10.0; first_fac = 1; }
+                        else if (rb_eq * 10.0 <= eq_cap * esc) { ratio_eq = 0.1; rb_eq *= 10.0; first_fac = 1; }
                     }
                     pri_outer = pri_res;
                     for (int i = 0; i < m; ++i) w[i] = Axv[i] + (ctype[i] == 1 ? ratio_eq : ratio) * (w[i] - z[i]);

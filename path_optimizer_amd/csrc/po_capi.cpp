@@ -178,7 +178,7 @@ void po_default_params(po_params *p) {
     p->polish = 0; p->polish_delta = 1e-6; p->polish_refine_iter = 3; p->polish_passes = 1;  /* OSQP defaults (polish off) */
     p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-7; p->refine_rounds = 1; p->probe_iters = 0;
     p->refine_chain = 1; p->refine_extra_rounds = 0; p->refine_adapt = 1; p->refine_speculate = 1;
-    p->refine_newton_rho = 100.0; p->refine_newton_rho_eq = 1e4; p->refine_newton_rho_max = 1e5; p->refine_ls_tol = 0.3; p->refine_ls_max = 30; p->refine_newton_max = 300; p->refine_newton_final = 3; p->reserved_newton = 0; p->refine_newton_rho_eq_max = 1e6; /* refine = 2 */
+    p->refine_newton_rho = 100.0; p->refine_newton_rho_eq = 1e4; p->refine_newton_rho_max = 1e5; p->refine_ls_tol = 0.3; p->refine_ls_max = 30; p->refine_newton_max = 300; p->refine_newton_final = 3; p->refine_newton_escalate = 12; p->refine_newton_rho_eq_max = 1e6; /* refine = 2 */
 }
 
 int po_problem_dims(int form, int N, int keep, int *n, int *m, int *C) {
@@ -348,7 +348,7 @@ static int make_dev_params(const po_handle_s *h, int form, int keep, po::DevPara
     D->ref_extra = (p.refine && p.refine_extra_rounds > 0) ? p.refine_extra_rounds : 0; D->ref_adapt = p.refine_adapt; D->ref_spec = p.refine_speculate;
     D->slice = (!p.refine && p.probe_iters > 0) ? p.probe_iters : 0;
     D->ref_nw_rho = p.refine_newton_rho > 0 ? p.refine_newton_rho : 100.0; D->ref_nw_rho_max = p.refine_newton_rho_max; D->ref_nw_rho_eq_max = p.refine_newton_rho_eq_max; D->ref_nw_rho_eq = p.refine_newton_rho_eq > 0 ? p.refine_newton_rho_eq : 1e4; D->ref_ls_tol = p.refine_ls_tol > 0 ? p.refine_ls_tol : 1e-4;
-    D->ref_nw_final = p.refine_newton_final; D->ref_ls_max = p.refine_ls_max > 0 ? p.refine_ls_max : 30; D->ref_nw_max = p.refine_newton_max > 0 ? p.refine_newton_max : 300;
+    D->ref_nw_final = p.refine_newton_final; D->ref_nw_esc = p.refine_newton_escalate; D->ref_ls_max = p.refine_ls_max > 0 ? p.refine_ls_max : 30; D->ref_nw_max = p.refine_newton_max > 0 ? p.refine_newton_max : 300;
     D->ref_split_warm = 0;
     return PO_OK;
 }

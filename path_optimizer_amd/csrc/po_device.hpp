@@ -39,7 +39,7 @@ struct DevParams {
     int slice;              // po_params.probe_iters (0 with refine): iterations of the first launch pair
     double ref_rho, ref_eps;
     double ref_nw_rho, ref_nw_rho_eq, ref_nw_rho_max, ref_nw_rho_eq_max, ref_ls_tol;  // po_params.refine = 2 (Newton refinement)
-    int ref_ls_max, ref_nw_max, ref_nw_final;
+    int ref_ls_max, ref_nw_max, ref_nw_final, ref_nw_esc;
     int ref_split_warm;  // launcher only: this is the warm-start launch of the split scheduling (plain kernels although refine = 2)
 };
 

@@ -37,7 +37,7 @@ def _rms(batch, xs, gold):
 
 def test_oracle_newton_defaults(oracle):
     p = oracle.default_params()
-    assert (p.refine_newton_rho, p.refine_newton_rho_eq, p.refine_newton_rho_max, p.refine_ls_tol, p.refine_ls_max, p.refine_newton_max, p.refine_newton_final, p.refine_newton_rho_eq_max) == (100.0, 1e4, 1e5, 0.3, 30, 300, 3, 1e6)
+    assert (p.refine_newton_rho, p.refine_newton_rho_eq, p.refine_newton_rho_max, p.refine_ls_tol, p.refine_ls_max, p.refine_newton_max, p.refine_newton_final, p.refine_newton_rho_eq_max, p.refine_newton_escalate) == (100.0, 1e4, 1e5, 0.3, 30, 300, 3, 1e6, 12)
 
 
 @pytest.mark.parametrize("name,B", [("c3", 512), ("c2", 256), ("c5", 96), ("k", 128), ("keep3", 128)])
@@ -88,13 +88,15 @@ def _host_bench_batch(B):
 
 def test_oracle_newton_wide_corridor_batch_needs_the_equality_penalty_growth(oracle):
     """The synthetic batch of `host_test bench` (wide corridors, 0.2 m initial offset): once the inequality penalty sits at its cap the primal residual left on the
-    dynamics rows falls by < 1 % per multiplier update; with refine_newton_rho_eq_max (default 1e6) the equality penalty grows instead and every path certifies."""
+    dynamics rows falls by < 1 % per multiplier update; with refine_newton_rho_eq_max (default 1e6) the equality penalty grows instead, and on a long stall (the degenerate
+    optima of this batch) refine_newton_escalate raises both caps: every path certifies within 80 iterations (whole batch of 4096, oracle: max 80; before: 548 and two uncertified)."""
     b = _host_bench_batch(128)
     p = _set(oracle.device_equivalent_params(), **NEWTON)
     _, info, _ = oracle.solve_batch(b, p)
-    assert (info["status"] == 1).all() and (info["status_refine"] == 1).all() and info["iters"].max() < 200, (info["iters"].max(), (info["status_refine"] != 1).sum())
+    assert (info["status"] == 1).all() and (info["status_refine"] == 1).all() and info["iters"].max() < 120, (info["iters"].max(), (info["status_refine"] != 1).sum())
     q = _set(oracle.device_equivalent_params(), **NEWTON)
-    q.refine_newton_rho_eq_max = 0.0  # (never grows: round-4 behaviour before the rule)
+    q.refine_newton_rho_eq_max = 0.0  # (never grows: the behaviour before the two rules)
+    q.refine_newton_escalate = 0
     _, i0, _ = oracle.solve_batch(b, q)
     assert (i0["status_refine"] != 1).sum() >= 1 and i0["iters"].max() > 400  # paths 2, 109: ~450 - 550 iterations, uncertified
 
