@@ -1,5 +1,5 @@
-"""Dev tool (GPU box): the headline setting (chained rounds, speculation) against the oracle on random batches of every formulation / keep / ragged lengths; prints disagreements.
-python tools/headline_fuzz.py [cases] [seed]"""
+"""Dev tool (GPU box): the headline setting (round 4: Newton refinement, every scheduling; `r3` as third argument: round 3's chained rounds with speculation) against the oracle on random batches of every formulation / keep / ragged lengths; prints disagreements.
+python tools/headline_fuzz.py [cases] [seed] [r3]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -22,15 +22,21 @@ for case in range(n_cases):
     if rng.integers(0, 2):  # ragged
         npts = rng.integers(max(8, b.N // 2), b.N + 1, B).astype(np.int32); npts[0] = b.N
         b.n_points = npts
-    p = binding.default_params(); p.refine, p.refine_rounds, p.refine_extra_rounds = 1, 3, 2
-    p.refine_chain = int(rng.integers(0, 2)); p.refine_speculate = int(rng.choice([1, 0, -1, 2]))
+    p = binding.default_params()
+    if len(sys.argv) > 3 and sys.argv[3] == "r3":
+        p.refine, p.refine_rounds, p.refine_extra_rounds = 1, 3, 2
+        p.refine_chain = int(rng.integers(0, 2)); p.refine_speculate = int(rng.choice([1, 0, -1, 2]))
+    else:
+        p.refine, p.refine_rounds, p.refine_extra_rounds, p.refine_eps = 2, 5, 2, 1e-8
+        p.refine_chain = int(rng.choice([2, 2, 3, 1, 0])); p.refine_speculate = int(rng.choice([1, -1]))
+        if rng.integers(0, 3) == 0: b.bounds *= float(rng.choice([0.5, 0.7]))  # narrower corridors: soft margins bind, degenerate optima
     if rng.integers(0, 4) == 0: p.max_iter = int(rng.choice([300, 700, 1500]))
     try:
         st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
     except Exception as e:
         print("case", case, "device error", e, form, B, kw); bad += 1; continue
     ost, oinfo, oxs = O.solve_batch(b, O.device_equivalent_params(p), want_x=True)
-    same = info["iters"] == oinfo["iters"]
+    same = np.abs(info["iters"].astype(int) - oinfo["iters"].astype(int)) <= (3 if p.refine == 2 else 0)
     ok = np.array_equal(info["status"], oinfo["status"]) and np.array_equal(info["status_refine"][same], oinfo["status_refine"][same])
     err = float(np.abs(xs[same] - oxs[same]).max()) if same.any() else 0.0
     tot += B; eq += int(same.sum()); worst = max(worst, err)
