@@ -164,7 +164,7 @@ def config_legs(torch, binding, synth, dev, stream, steps=3):
 
 
 # The setting `value` is quoted at — ONE setting for every shape (round 4): a short OSQP-faithful ADMM run (to the first termination check) as the warm start, then
-# the Newton refinement (po_params.refine = 2: semismooth Newton on the augmented Lagrangian with an exact line search) until OSQP's termination test holds at refine_eps.
+# the Newton refinement (po_params.refine = 2: semismooth Newton on the augmented Lagrangian with a line search on the merit (safeguarded Newton on its piecewise-linear derivative)) until OSQP's termination test holds at refine_eps.
 HEADLINE = {"label": "ADMM warm start (25 it) + Newton refinement (refine = 2, refine_eps 1e-8 + final correction steps), split launches",
             "params": dict(refine=2, refine_rounds=5, refine_extra_rounds=2, refine_eps=1e-8, refine_chain=2),
             "algorithm": "EXTENSION (closer to the QP's optimum than the reference's OSQP run): certified per path, po_info.status_refine"}
@@ -795,7 +795,7 @@ def main():
             "data": "synthetic" + (" (DRY RUN: no GPU, faked device times)" if dry else ""),
             "config": {"workload": f"BASELINE config {cfg}: KP, B={B} paths/GPU x {world} GPU, N={N} points, per-path random obstacle clearances; one batch after the other on one stream",
                        "setting": HEADLINE["label"] + ": OSQP-faithful ADMM (scaling 10, check every 25) up to its first termination check as the warm start, then semismooth "
-                                  "Newton on the augmented Lagrangian with an exact line search until OSQP's termination test holds at refine_eps — every path certified and within "
+                                  "Newton on the augmented Lagrangian with a line search on the merit (safeguarded Newton on its piecewise-linear derivative) until OSQP's termination test holds at refine_eps — every path certified and within "
                                   "1e-4 m of its exact optimum (accuracy clause of the metric, see `accuracy`); the same setting on every BASELINE shape (`configs`); `osqp_default` = no extension",
                        "which_leg_is_what": {"value": HEADLINE["algorithm"], "osqp_default": OSQP_DEFAULT["algorithm"]},
                        "batch_per_gpu": B, "points": N, "formulation": "KP", "parallelism": f"batch-split x{world}",

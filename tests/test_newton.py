@@ -1,4 +1,4 @@
-"""Newton refinement (po_params.refine = 2, round 4): semismooth Newton on the augmented Lagrangian with an exact line search, from the point a SHORT
+"""Newton refinement (po_params.refine = 2, round 4): semismooth Newton on the augmented Lagrangian with a line search on the merit (safeguarded Newton on its piecewise-linear derivative), from the point a SHORT
 type-based ADMM run stops at (include/po_hip.h).  It replaces the activity-weighted ADMM continuation (refine = 1) as the setting `value` is quoted at:
 globally convergent (the merit falls monotonically), so the activity set cannot cycle — the failure mode that left ~0.3 % of BASELINE config 3 at
 1 500 – 1 900 iterations and four KPC paths of config 5 uncertified.
