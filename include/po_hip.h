@@ -150,8 +150,9 @@ typedef struct po_params {
     int    refine_extra_rounds;         /* 0.  E > 0: a path that the last regular round does not certify at refine_eps continues BELOW eps — type-based iteration at
                                            eps / 10, refinement again, eps / 100, ... — for up to E more rounds (full refinement budget each).  A path returned after
                                            them is certified, or satisfies OSQP's test at eps / 10^E — or ran out of max_iter in one of these rounds: then the point it ends on is tested
-                                           against OSQP's criteria at the caller's eps once more — passes: PO_STATUS_SOLVED with status_refine -1; fails (ADMM residuals are
-                                           not monotone): PO_STATUS_MAX_ITER with that iterate, like any other path that runs out of iterations (po_plan_batch: ok = 0).  For the handful of nearly flat QPs on which the activity-set
+                                           against OSQP's criteria at the caller's eps once more — passes: that point, PO_STATUS_SOLVED with status_refine -1; fails (ADMM residuals
+                                           are not monotone): the point that round STARTED from (it met eps in the round before), PO_STATUS_SOLVED with status_refine -1.  A round
+                                           below eps never turns a solved path into MAX_ITER (round 4; before, the failing iterate was returned as MAX_ITER).  For the handful of nearly flat QPs on which the activity-set
                                            iteration cycles (BASELINE config 3: 11 of 4096 paths): they are the ones left > 0.1 m from the optimum at eps. */
     int    refine_adapt;                /* 1.  OSQP's adaptive-rho rule (balance of the relative residuals, applied when the estimate leaves [rho / adapt_tol, rho x adapt_tol])
                                            on the refinement's own rho, after a block of refine_every iterations that kept its step vector.  Once the activity set has

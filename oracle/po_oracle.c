@@ -887,6 +887,7 @@ int po_oracle_qp_solve_ext(int n, int m, const int *Pp0, const int *Pi0, const d
     if (n <= 0 || m < 0 || !prm || !x || !y || !z || !info) return PO_ERR_INVALID;
     const int pnz = Pp0[n], anz = Ap0[n];
     int rc = PO_OK;
+    double *entry = NULL; /* the point a round BELOW eps starts from (x, z, y): what the path returns if that round runs out of iterations on a worse one */
     /* working (scaled) copies */
     double *Px = (double *)malloc(sizeof(double) * (size_t)(pnz + 1));
     double *Ax = (double *)malloc(sizeof(double) * (size_t)(anz + 1));
@@ -1049,6 +1050,7 @@ int po_oracle_qp_solve_ext(int n, int m, const int *Pp0, const int *Pi0, const d
      * up to E more rounds (each with the full refinement budget) */
     const int rounds_total = rounds + (prm->refine && prm->refine_extra_rounds > 0 ? prm->refine_extra_rounds : 0);
     int round = 0, refine_its = 0, refine_fac = 0, exhausted = 0;
+    double entry_res[3] = {0, 0, 0}; /* (r_prim, r_dual, rho of `entry`) */
     double eps_mul = 1.0;
     for (int r_ = 1; r_ < rounds; ++r_) eps_mul *= 10.0;
 resume_main:
@@ -1177,7 +1179,17 @@ resume_main:
     }
     if (iter > prm->max_iter) {
         iter = prm->max_iter;
-        if (info->status == PO_STATUS_UNSOLVED) info->status = PO_STATUS_MAX_ITER;
+        if (info->status == PO_STATUS_UNSOLVED) {
+            info->status = PO_STATUS_MAX_ITER;
+            if (round >= rounds && entry) { /* a round below eps never unsolves a path: back to the point it started from (solved at eps in the round before), not certified */
+                memcpy(x, entry, sizeof(double) * (size_t)n);
+                memcpy(z, entry + n, sizeof(double) * (size_t)m);
+                memcpy(y, entry + n + m, sizeof(double) * (size_t)m);
+                pri_res = entry_res[0]; dua_res = entry_res[1]; rho = entry_res[2];
+                info->status = PO_STATUS_SOLVED;
+                exhausted = 1;
+            }
+        }
     }
     (void)checked_this_iter;
     info->iters = iter + refine_its;          /* (refinement iterations / refactorisations of earlier rounds: po_params.refine_rounds) */
@@ -1414,6 +1426,13 @@ resume_main:
         free(snap);
         if (!stop && round + 1 < rounds_total) { /* not certified at refine_eps: back to the type-based iteration (its own rho) at a 10 x tighter eps, then again */
             ++round;
+            if (round >= rounds) { /* a round below eps: remember where it starts (this point meets the caller's eps) */
+                if (!entry) entry = (double *)malloc(sizeof(double) * (size_t)(n + 2 * m));
+                memcpy(entry, x, sizeof(double) * (size_t)n);
+                memcpy(entry + n, z, sizeof(double) * (size_t)m);
+                memcpy(entry + n + m, y, sizeof(double) * (size_t)m);
+                entry_res[0] = pri_res; entry_res[1] = dua_res; entry_res[2] = rho;
+            }
             eps_mul *= 0.1;
             for (int i = 0; i < m; ++i) {
                 rho_vec[i] = ctype[i] == -1 ? OSQP_RHO_MIN : (ctype[i] == 1 ? OSQP_RHO_EQ_OVER_INEQ * rho : rho);
@@ -1540,6 +1559,7 @@ resume_main:
         info->obj = o;
     }
 done:
+    free(entry);
     ldl_free(&F);
     kkt_free(&K);
     free(Px); free(Ax); free(q); free(l); free(u); free(D); free(Dinv); free(E); free(Einv);

@@ -449,6 +449,43 @@ def test_oracle_round_below_eps_out_of_iterations_keeps_the_path_solved(oracle):
     assert i0["status"][i] == 1 and i0["iters"][i] == 575
 
 
+def test_oracle_round_below_eps_never_unsolves_a_path(oracle):
+    """... and when the round below eps runs out of iterations on a point that FAILS the caller's eps (ADMM residuals are not monotone: max_iter 725 .. 950 on path 2410 —
+    MAX_ITER before round 4), the path returns the point that round STARTED from: exactly what it returns without rounds below eps, solved and not certified."""
+    b, kw = _exhausted_case()
+    p = oracle.device_equivalent_params()
+    for k, v in dict(kw, max_iter=800).items():
+        setattr(p, k, v)
+    _, info, xs = oracle.solve_batch(b, p, want_x=True)
+    assert (info["status"] == 1).all(), info["status"]
+    q = oracle.device_equivalent_params()
+    for k, v in dict(kw, max_iter=800, refine_extra_rounds=0).items():
+        setattr(q, k, v)
+    _, i0, x0 = oracle.solve_batch(b, q, want_x=True)
+    i = 10
+    assert info["status_refine"][i] == -1 and i0["status_refine"][i] == -1 and i0["status"][i] == 1
+    assert np.array_equal(xs[i], x0[i]) and info["r_prim"][i] == i0["r_prim"][i] and info["r_dual"][i] == i0["r_dual"][i]
+    assert info["iters"][i] > i0["iters"][i]  # (the iterations of the failed round are counted)
+
+
+@pytest.mark.gpu
+def test_device_round_below_eps_never_unsolves_a_path(oracle):
+    from path_optimizer_amd import binding
+
+    b, kw = _exhausted_case()
+    for chain, mi in ((1, 800), (0, 800), (1, 925)):
+        p = binding.default_params()
+        for k, v in dict(kw, refine_chain=chain, max_iter=mi).items():
+            setattr(p, k, v)
+        st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
+        ost, oinfo, oxs = oracle.solve_batch(b, oracle.device_equivalent_params(p), want_x=True)
+        assert (info["status"] == 1).all() and np.array_equal(info["status"], oinfo["status"]), (chain, mi, info["status"], oinfo["status"])
+        assert np.array_equal(info["status_refine"], oinfo["status_refine"]) and info["status_refine"][10] == -1
+        same = info["iters"] == oinfo["iters"]
+        assert same[10] and same.mean() >= 0.8 and np.abs(xs[same] - oxs[same]).max() < 1e-6
+        assert abs(info["r_prim"][10] - oinfo["r_prim"][10]) < 1e-9 and abs(info["r_dual"][10] - oinfo["r_dual"][10]) < 1e-7
+
+
 @pytest.mark.gpu
 def test_device_round_below_eps_out_of_iterations_matches_the_oracle(oracle):
     from path_optimizer_amd import binding
