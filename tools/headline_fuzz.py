@@ -38,10 +38,13 @@ for case in range(n_cases):
     ost, oinfo, oxs = O.solve_batch(b, O.device_equivalent_params(p), want_x=True)
     same = np.abs(info["iters"].astype(int) - oinfo["iters"].astype(int)) <= (3 if p.refine == 2 else 0)
     ok = np.array_equal(info["status"], oinfo["status"]) and np.array_equal(info["status_refine"][same], oinfo["status_refine"][same])
-    err = float(np.abs(xs[same] - oxs[same]).max()) if same.any() else 0.0
+    cmpx = same & (info["status"] == 1) & (oinfo["status"] == 1)  # (an unsolved path's iterate is not a result)
+    err = float(np.abs(xs[cmpx] - oxs[cmpx]).max()) if cmpx.any() else 0.0
+    cert = cmpx & (info["status_refine"] == 1) & (oinfo["status_refine"] == 1)
+    err_c = float(np.abs(xs[cert] - oxs[cert]).max()) if cert.any() else 0.0
     tot += B; eq += int(same.sum()); worst = max(worst, err)
     if not ok or err > 1e-5 or same.mean() < 0.6:
         bad += 1
         print("MISMATCH case", case, "form", form, "B", B, kw, "chain", p.refine_chain, "spec", p.refine_speculate, "max_iter", p.max_iter, "| status equal", np.array_equal(info["status"], oinfo["status"]),
-              "same iters %.2f" % same.mean(), "err %.2e" % err, "dev status", info["status"][~same][:5], "orc", oinfo["status"][~same][:5], flush=True)
+              "same iters %.2f" % same.mean(), "err %.2e (certified on both: %.2e, n solved %d certified %d)" % (err, err_c, cmpx.sum(), cert.sum()), "dev status", info["status"][~same][:5], "orc", oinfo["status"][~same][:5], flush=True)
 print("cases", n_cases, "paths", tot, "equal iteration counts", eq, "mismatching cases", bad, "worst |dx| on equal-count paths %.2e" % worst, "%.0f s" % (time.time() - t0))
