@@ -125,8 +125,8 @@ def test_device_newton_matches_oracle_and_optimum(oracle, name, B, kw):
     bound to the last bits is in or out of the Newton matrix, the line search stops at |psi'| <= 0.3 |psi'(0)| one evaluation earlier or later, and the dual
     residual of a certified point (~1e-10, below what either implementation resolves: the device's block-tridiagonal solve leaves 1e-10 .. 1e-12, the oracle's
     sparse LDL' 1e-13) is or is not already 1e3 x below its tolerance, which decides whether a correction step follows.  Every such fork converges to the same
-    certified point.  Measured on the whole batches (tools/newton_dev.py): |difference in iterations| <= 1 on 93 % of config 3, 86 % of config 2, 96 % of K, 98 % of
-    keep 3, 79 % of config 5 (KPC: two more slack families on their bounds); <= 2 on 96 - 100 %; <= 3 on >= 99 %; equal means to 1 %."""
+    certified point.  Measured on the whole batches (tools/newton_dev.py, final defaults): |difference in iterations| <= 1 on 99.3 % of config 3, 97.9 % of config 2, 96.7 % of K,
+    99.9 % of keep 3, 81.7 % of config 5 (KPC: two more slack families on their bounds); <= 2 on 96 - 100 %; <= 3 on >= 99.6 %; equal counts on 86 % / 76 % / 81 % / 99 % / 45 %; equal means to 1 %."""
     from path_optimizer_amd import binding
 
     b = batch_of(name, B)
@@ -140,7 +140,7 @@ def test_device_newton_matches_oracle_and_optimum(oracle, name, B, kw):
         assert (info["status_refine"] == 1).all() and (oinfo["status_refine"] == 1).all()
     di = np.abs(info["iters"].astype(int) - oinfo["iters"].astype(int))
     if "refine_newton_max" not in kw:
-        assert (di <= 1).mean() >= (0.6 if name == "c5" else 0.75) and (di <= 2).mean() >= (0.85 if name == "c5" else 0.95), ((di <= 1).mean(), (di <= 2).mean(), info["iters"][di > 1], oinfo["iters"][di > 1])
+        assert (di <= 1).mean() >= (0.65 if name == "c5" else 0.88) and (di <= 2).mean() >= (0.85 if name == "c5" else 0.95), ((di <= 1).mean(), (di <= 2).mean(), info["iters"][di > 1], oinfo["iters"][di > 1])
     assert (di <= 3).mean() >= 0.9 and abs(info["iters"].mean() - oinfo["iters"].mean()) <= 0.05 * oinfo["iters"].mean()
     dx = np.abs(xs - oxs).max(axis=1)
     assert dx.max() < 1e-4 and np.median(dx) < 1e-8, (dx.max(), np.median(dx))
