@@ -574,58 +574,73 @@ template <int KIND, int NWV> __device__ void convert_blocks(Prob<KIND> &pb, int 
         __syncthreads();
         if (act) {
 #pragma unroll
-            for (int i = 0; i < W; ++i) { blk[i * W + c] = mc[i]; blk[W * W + i * W + c] = sc[i]; }
+            for (int i = 0; i < W; ++i) { blk[i * W + c] = -mc[i]; blk[W * W + i * W + c] = sc[i]; }  // (-M_k: the sweeps are pure multiply-adds)
         }
         __syncthreads();
     }
 }
 
 template <int W> struct BlkSet { double m[W], bn; };
-template <int W, int... U> __device__ __forceinline__ void blk_bcast(double (&y)[W], double v, std::integer_sequence<int, U...>) { ((y[U] = lane_bcast(v, U)), ...); }
-template <int W> __device__ __forceinline__ double blk_dot(const double (&c)[W], const double (&y)[W], double a0) {  // a0 - sum c y, three partial sums (a dependent v_fma_f64 is 10 cycles)
+// acc += (lane N of the caller's 16-lane row of v) * c in ONE instruction: gfx950 has DPP on 64-bit FMAC with row_newbcast (v_fmac_f64_dpp), so the broadcast of the block's
+// vector costs no instruction of its own (the round-3 form: 2 v_readlane per value, 18 per block and sweep = a third of the substitution's VALU issue).  FIRST = the first
+// use of v after the VALU instruction that wrote it (and after whatever touched EXEC): the DPP read needs wait states the compiler does not see inside inline assembly.
+template <int N, bool FIRST> __device__ __forceinline__ void fmac_bcast(double &acc, double v, double c) {
+    if constexpr (FIRST) asm volatile("s_nop 4\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(c), "i"(N));
+    else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(c), "i"(N));
+}
+template <int W, int... U> __device__ __forceinline__ double blk_dot_bcast(const double (&c)[W], double v, double a0, std::integer_sequence<int, U...>) {  // a0 + sum_u c[u] * v(lane u of the row); three partial sums
+    double a[3] = {a0, 0.0, 0.0};
+    (fmac_bcast<U, U == 0>(a[U % 3], v, c[U]), ...);
+    return a[0] + (a[1] + a[2]);
+}
+template <int W> __device__ __forceinline__ double blk_dot(const double (&c)[W], const double (&y)[W], double a0) {  // a0 + sum c y, three partial sums (a dependent v_fma_f64 is 10 cycles)
     double a[3] = {a0, 0.0, 0.0};
 #pragma unroll
-    for (int uu = 0; uu < W; ++uu) a[uu % 3] = __builtin_fma(-c[uu], y[uu], a[uu % 3]);
+    for (int uu = 0; uu < W; ++uu) a[uu % 3] = __builtin_fma(c[uu], y[uu], a[uu % 3]);
     return a[0] + (a[1] + a[2]);
 }
 template <int KIND> __device__ __forceinline__ void band_solve_blocks(Prob<KIND> &pb, int lane) {
     using T = ST<KIND>;
     constexpr int W = T::W, BS = blk_stride<W>();
-    if (lane >= 2 * W) return;
-    const int l = lane;
+    static_assert(W <= 9 && 2 * (16 - W) >= W, "lane map below: W chain lanes + (16 - W) Wm rows per 16-lane DPP row, two rows");
+    if (lane >= 32) return;
+    // Lane map (two DPP rows of 16 lanes; row_newbcast broadcasts inside a row): positions 0 .. W-1 of BOTH rows run the chain (row 1 repeats row 0: the same instructions, it only
+    // has to hold r_k for its own broadcasts), positions W .. 15 hold rows of Wm: row 0 the first 16 - W of them, row 1 the rest.
+    const int pos = lane & 15, drow = lane >> 4;
+    const bool chain = pos < W;
+    const int wrow = (pos - W) + drow * (16 - W);   // Wm row of a non-chain lane
+    const bool wm = !chain && wrow < W;
+    const int l = chain ? pos : (wm ? W + wrow : 0);  // row of the block's stacked 2W x W storage [-M_k; Wm_k] this lane multiplies with
     const int nblk = (pb.n + W - 1) / W;
     const double *Mb = pb.Lb;
     double *wk = pb.wk;
     constexpr auto seq = std::make_integer_sequence<int, W>{};
-    // ---- forward: r_{k+1} = b_{k+1} - M_k r_k on the chain (lanes 0 .. W-1: row l of M_k), and IN THE SAME FMAs on lanes W .. 2W-1 (row l - W of Wm_k, the second
-    //      half of the block's 2W x W storage) z_k = Wm_k r_k: both products take the broadcast r_k as their scalar operand.  z_k is parked in wk where b_k was;
-    //      S_k r_k = Wm_k' z_k is finished by the backward sweep.  The explicit product S = T^-T D^-1 T^-1 (round 3) loses the residual of the substitution (numpy
-    //      model on TENSION matrices: 1e-15 .. 5e-14 relative against 3e-16, exactly rounded entries included; the factored form gives 3e-16 again), and the ADMM of
-    //      a few instances amplifies a residual by 1e6: with the factored form the iterates are back within 1e-7 of the oracle's. ----
+    // ---- forward: r_{k+1} = b_{k+1} + (-M_k) r_k on the chain lanes (row l of -M_k), and IN THE SAME FMAs on the Wm lanes z_k = Wm_k r_k: both products take the broadcast
+    //      r_k as their operand.  z_k is parked in wk where b_k was; S_k r_k = Wm_k' z_k is finished by the backward sweep.  The explicit product S = T^-T D^-1 T^-1 (round 3)
+    //      loses the residual of the substitution (tools/tension_block_model.py: 1e-15 .. 5e-14 relative against 3e-16, exactly rounded entries included; the factored form gives
+    //      3e-16 again), and the ADMM of a few instances amplifies a residual by 1e6: with the factored form the iterates are back within 1e-7 of the oracle's. ----
     {
         BlkSet<W> A, B;
         auto load = [&](BlkSet<W> &s, int k) {  // (k == nblk: the look-ahead reads the block behind the last one — inside the padding, never used)
             const double *mb = Mb + (size_t)k * BS + l * W;
 #pragma unroll
             for (int uu = 0; uu < W; ++uu) s.m[uu] = mb[uu];
-            const double bn = wk[(k + 1) * W + (l < W ? l : 0)];
-            s.bn = l < W ? bn : 0.0;
+            const double bn = wk[(k + 1) * W + (chain ? pos : 0)];
+            s.bn = chain ? bn : 0.0;
         };
-        // One block: broadcast r, then — once this set's first value is known to have arrived — request the OTHER set (the block after this one), then the
-        // arithmetic.  The compiler's s_waitcnt inside a loop waits for every outstanding LDS request at the first use of a loaded register; placed here, all
-        // that is outstanding is this block's own set, requested a whole block earlier.
+        // One block: once this set's first value is known to have arrived, request the OTHER set (the block after this one), then the arithmetic.  The compiler's s_waitcnt
+        // inside a loop waits for every outstanding LDS request at the first use of a loaded register; placed here, all that is outstanding is this block's own set,
+        // requested a whole block earlier.
         auto step = [&](const BlkSet<W> &s, BlkSet<W> &other, int k, double &r, bool ahead) {
-            double y[W];
-            blk_bcast<W>(y, r, seq);
             asm volatile("" ::"v"(s.m[0]));
             __builtin_amdgcn_sched_barrier(0);
             if (ahead) load(other, k + 1);
             __builtin_amdgcn_sched_barrier(0);
-            const double rn = blk_dot<W>(s.m, y, s.bn);  // lanes < W: r_{k+1}; lanes >= W: -z_k
-            if (l >= W) wk[k * W + l - W] = -rn;
+            const double rn = blk_dot_bcast<W>(s.m, r, s.bn, seq);  // chain lanes: r_{k+1}; Wm lanes: z_k
+            if (wm) wk[k * W + wrow] = rn;
             r = rn;
         };
-        double r = wk[l < W ? l : 0];
+        double r = wk[chain ? pos : 0];
         asm volatile("" : "+v"(r));
         load(A, 0);
         int k = 0;
@@ -635,35 +650,34 @@ template <int KIND> __device__ __forceinline__ void band_solve_blocks(Prob<KIND>
         }
         if (k < nblk) step(A, B, k, r, false);
     }
-    if (l >= W) return;
-    // ---- backward: x_k = g_k - M_k' x_{k+1} (column l of M_k on lane l) with g_k = Wm_k' z_k (column l of Wm_k; z_k read back as an LDS broadcast: off the
-    //      chain); the last block's x is its g ----
+    if (lane >= W) return;
+    // ---- backward: x_k = g_k + (-M_k)' x_{k+1} (column l of -M_k on lane l, x_{k+1} broadcast inside the FMAs) with g_k = Wm_k' z_k (column l of Wm_k; z_k read back as an LDS
+    //      broadcast: off the chain); the last block's x is its g ----
     {
         struct Bk { double m[W], c[W], z[W]; };
         Bk A, B;
+        const int lc = lane;
         auto load = [&](Bk &s, int k) {
             const int kk = k > 0 ? k : 0;
-            const double *mb = Mb + (size_t)kk * BS + l;
+            const double *mb = Mb + (size_t)kk * BS + lc;
 #pragma unroll
             for (int uu = 0; uu < W; ++uu) { s.m[uu] = mb[uu * W]; s.c[uu] = mb[W * W + uu * W]; s.z[uu] = wk[kk * W + uu]; }
         };
         auto step = [&](const Bk &s, Bk &other, int k, double &x, bool ahead) {
-            double y[W];
-            blk_bcast<W>(y, x, seq);
             asm volatile("" ::"v"(s.m[0]));
             __builtin_amdgcn_sched_barrier(0);
             if (ahead) load(other, k - 1);
             __builtin_amdgcn_sched_barrier(0);
-            const double g = -blk_dot<W>(s.c, s.z, 0.0);
-            x = blk_dot<W>(s.m, y, g);
-            wk[k * W + l] = x;
+            const double g = blk_dot<W>(s.c, s.z, 0.0);
+            x = blk_dot_bcast<W>(s.m, x, 0.0, seq) + g;
+            wk[k * W + lc] = x;
         };
         double x;
         {   // the last block: x = g = Wm' z
             Bk L_;
             load(L_, nblk - 1);
-            x = -blk_dot<W>(L_.c, L_.z, 0.0);
-            wk[(nblk - 1) * W + l] = x;
+            x = blk_dot<W>(L_.c, L_.z, 0.0);
+            wk[(nblk - 1) * W + lc] = x;
         }
         asm volatile("" : "+v"(x));
         int k = nblk - 2;
