@@ -584,13 +584,18 @@ template <int W> struct BlkSet { double m[W], bn; };
 // acc += (lane N of the caller's 16-lane row of v) * c in ONE instruction: gfx950 has DPP on 64-bit FMAC with row_newbcast (v_fmac_f64_dpp), so the broadcast of the block's
 // vector costs no instruction of its own (the round-3 form: 2 v_readlane per value, 18 per block and sweep = a third of the substitution's VALU issue).  FIRST = the first
 // use of v after the VALU instruction that wrote it (and after whatever touched EXEC): the DPP read needs wait states the compiler does not see inside inline assembly.
-template <int N, bool FIRST> __device__ __forceinline__ void fmac_bcast(double &acc, double v, double c) {
-    if constexpr (FIRST) asm volatile("s_nop 4\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(c), "i"(N));
-    else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(c), "i"(N));
+// The broadcast operand is declared read-write (it is not modified): the statements of one product are then ordered among themselves — the wait states sit in front of the FIRST
+// one only — while loads and everything else may still move across them (with `asm volatile` instead: 13.8 instead of 13.4 ms per 4096 QPs).
+template <int N, bool FIRST> __device__ __forceinline__ void fmac_bcast(double &acc, double &v, double c) {
+    if constexpr (FIRST) asm("s_nop 4\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc), "+v"(v) : "v"(c), "i"(N));
+    else asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc), "+v"(v) : "v"(c), "i"(N));
 }
-template <int W, int... U> __device__ __forceinline__ double blk_dot_bcast(const double (&c)[W], double v, double a0, std::integer_sequence<int, U...>) {  // a0 + sum_u c[u] * v(lane u of the row); three partial sums
-    double a[3] = {a0, 0.0, 0.0};
+template <int W, int... U> __device__ __forceinline__ void blk_acc_bcast(double (&a)[3], const double (&c)[W], double &v, std::integer_sequence<int, U...>) {  // a[u % 3] += c[u] * v(lane u of the row)
     (fmac_bcast<U, U == 0>(a[U % 3], v, c[U]), ...);
+}
+template <int W, int... U> __device__ __forceinline__ double blk_dot_bcast(const double (&c)[W], double &v, double a0, std::integer_sequence<int, U...> sq) {  // a0 + sum_u c[u] * v(lane u of the row); three partial sums
+    double a[3] = {a0, 0.0, 0.0};
+    blk_acc_bcast<W>(a, c, v, sq);
     return a[0] + (a[1] + a[2]);
 }
 template <int W> __device__ __forceinline__ double blk_dot(const double (&c)[W], const double (&y)[W], double a0) {  // a0 + sum c y, three partial sums (a dependent v_fma_f64 is 10 cycles)
@@ -654,29 +659,32 @@ template <int KIND> __device__ __forceinline__ void band_solve_blocks(Prob<KIND>
     // ---- backward: x_k = g_k + (-M_k)' x_{k+1} (column l of -M_k on lane l, x_{k+1} broadcast inside the FMAs) with g_k = Wm_k' z_k (column l of Wm_k; z_k read back as an LDS
     //      broadcast: off the chain); the last block's x is its g ----
     {
-        struct Bk { double m[W], c[W], z[W]; };
+        struct Bk { double m[W], c[W], z; };
         Bk A, B;
         const int lc = lane;
         auto load = [&](Bk &s, int k) {
             const int kk = k > 0 ? k : 0;
             const double *mb = Mb + (size_t)kk * BS + lc;
 #pragma unroll
-            for (int uu = 0; uu < W; ++uu) { s.m[uu] = mb[uu * W]; s.c[uu] = mb[W * W + uu * W]; s.z[uu] = wk[kk * W + uu]; }
+            for (int uu = 0; uu < W; ++uu) { s.m[uu] = mb[uu * W]; s.c[uu] = mb[W * W + uu * W]; }
+            s.z = wk[kk * W + lc];  // z_k, one entry per lane: broadcast inside the FMAs like x
         };
-        auto step = [&](const Bk &s, Bk &other, int k, double &x, bool ahead) {
+        auto step = [&](Bk &s, Bk &other, int k, double &x, bool ahead) {
             asm volatile("" ::"v"(s.m[0]));
             __builtin_amdgcn_sched_barrier(0);
             if (ahead) load(other, k - 1);
             __builtin_amdgcn_sched_barrier(0);
-            const double g = blk_dot<W>(s.c, s.z, 0.0);
-            x = blk_dot_bcast<W>(s.m, x, 0.0, seq) + g;
+            double a[3] = {0.0, 0.0, 0.0};
+            blk_acc_bcast<W>(a, s.c, s.z, seq);  // g_k = Wm_k' z_k (does not wait for x)
+            blk_acc_bcast<W>(a, s.m, x, seq);    // + (-M_k)' x_{k+1}
+            x = a[0] + (a[1] + a[2]);
             wk[k * W + lc] = x;
         };
         double x;
         {   // the last block: x = g = Wm' z
             Bk L_;
             load(L_, nblk - 1);
-            x = blk_dot<W>(L_.c, L_.z, 0.0);
+            x = blk_dot_bcast<W>(L_.c, L_.z, 0.0, seq);
             wk[(nblk - 1) * W + lc] = x;
         }
         asm volatile("" : "+v"(x));
