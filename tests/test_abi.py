@@ -68,3 +68,18 @@ def test_no_cpu_fallback():
 def test_host_mirror_compiles():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "path_optimizer_amd", "host")], stdout=subprocess.DEVNULL)
     assert os.path.exists(os.path.join(ROOT, "path_optimizer_amd", "host", "host_test"))
+
+
+def test_inline_dpp_fmacs_of_the_tension_solve_have_their_wait_states():
+    """po_smooth.hip's blocked substitution broadcasts the block vector inside v_fmac_f64_dpp (row_newbcast) — inline assembly, invisible to the compiler's hazard recogniser.
+    Compile the file to ISA and check that no VALU write of a DPP source register sits within two instructions in front of such an FMAC (tools/dpp_hazard_check.py)."""
+    import shutil
+    import sys
+
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc here")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from dpp_hazard_check import check
+
+    total, findings = check()
+    assert total >= 100 and not findings, (total, findings[:3])
