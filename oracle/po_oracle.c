@@ -1218,8 +1218,10 @@ resume_main:
             /* equality rows: a FIXED penalty (not 1e3 x the inequality one): the gradient carries rho_eq x (a.x - b), a difference of O(1) numbers — at 1e6 and more
              * its rounding alone (1e-16 x 1e6 x the unscaling) sits above the dual tolerance */
             double rb_in = rn_, pri_outer = -1.0;
-            double rb_eq = prm->refine_newton_rho_eq > 0 ? prm->refine_newton_rho_eq : 1e4;
-            const double eq_cap = prm->refine_newton_rho_eq_max; /* (below rb_eq: never grows) */
+            double rb_eq = prm->refine_newton_rho_eq > 0 ? (prm->refine_newton_rho_eq < 1e8 ? prm->refine_newton_rho_eq : 1e8) : 1e4;
+            /* the caps, defaulted and bounded exactly as the engine's make_dev_params does (csrc/po_capi.cpp): 0 in refine_newton_rho_eq_max is the documented "never grows" */
+            const double in_cap = prm->refine_newton_rho_max > 0 ? (prm->refine_newton_rho_max < OSQP_RHO_MAX / 100.0 ? prm->refine_newton_rho_max : OSQP_RHO_MAX / 100.0) : 1e5;
+            const double eq_cap = prm->refine_newton_rho_eq_max > 0 ? (prm->refine_newton_rho_eq_max < 1e6 ? prm->refine_newton_rho_eq_max : 1e6) : (prm->refine_newton_rho_eq_max < 0 ? 1e6 : 0.0); /* (below rb_eq: never grows) */
             const int cap_nw = prm->refine_newton_max > 0 ? prm->refine_newton_max : 300;
             const int ls_max = prm->refine_ls_max > 0 ? prm->refine_ls_max : 30;
             double *w = (double *)malloc(sizeof(double) * (size_t)(m + 1)), *sv = (double *)malloc(sizeof(double) * (size_t)(m + 1));
@@ -1250,12 +1252,16 @@ resume_main:
                 if (g_refine_trace) fprintf(stderr, "  newton round %d step %d outer %d nfac %d  r_prim %.3e r_dual %.3e%s\n", round, it2, nouter, nfac, pri_res, dua_res, stop ? "  CERTIFIED" : "");
                 /* refine_newton_final: from the certified point Newton steps go on (tight line search; quadratic convergence once the active set is right) until the
                  * dual residual — the gradient of the merit — sits 100 x below its tolerance, at most that many steps */
-                if (certified) {
-                    if (dua_res < 1e-3 * tol_d || nfinal >= prm->refine_newton_final) { stop = 1; break; }
-                } else if (stop) {
-                    if (prm->refine_newton_final <= 0 || dua_res < 1e-3 * tol_d) break;
+                /* (round 5) the test is re-evaluated on EVERY point, the ones the correction steps produce included: `stop` is only ever true for a point that passes
+                 * it, so status_refine = 1 always describes the point that is returned.  A correction step that leaves the test's region (a step that changes the
+                 * active set can land with a larger dual residual) takes the path back to the regular iteration — multiplier updates and all — until it is certified again */
+                if (stop) {
+                    if (prm->refine_newton_final <= 0 || dua_res < 1e-3 * tol_d || nfinal >= prm->refine_newton_final) break;
                     certified = 1;
-                } else if (it2 >= cap_nw) break;
+                } else {
+                    certified = 0;
+                    if (it2 >= cap_nw) break;
+                }
                 if (!certified && dual_ok) { /* the inner problem is solved: multiplier update, w <- A x + (w - clip(w)) */
                     if (++nouter > 50) break;
                     /* a multiplier update that did not cut the primal residual by 4: the penalty grows 10 x (the multipliers stay, w is re-expressed) — the inequality
@@ -1266,7 +1272,7 @@ resume_main:
                     const int esc_n = prm->refine_newton_escalate;
                     const double esc = esc_n > 0 && nouter >= esc_n ? (nouter >= 2 * esc_n ? 100.0 : 10.0) : 1.0;
                     if (pri_outer >= 0.0 && pri_res > 0.25 * pri_outer) {
-                        if (rb_in * 10.0 <= prm->refine_newton_rho_max * esc) { ratio = 0.1; rb_in *= 10.0; first_fac = 1; }
+                        if (rb_in * 10.0 <= in_cap * esc) { ratio = 0.1; rb_in *= 10.0; first_fac = 1; }
                         else if (rb_eq * 10.0 <= eq_cap * esc) { ratio_eq = 0.1; rb_eq *= 10.0; first_fac = 1; }
                     }
                     pri_outer = pri_res;

@@ -289,6 +289,7 @@ int po_debug_set(po_handle h, const char *key, int value) {
 int po_debug_get(po_handle h, const char *key, long long *value) {
     if (!h || !key || !value) return PO_ERR_INVALID;
     const std::string k(key);
+    std::lock_guard<std::mutex> g(h->mu);
     if (k == "fallback_paths") {  // split scheduling of refine = 2: how many paths the last solve's Newton launch handed to the fallback launch
         *value = 0;
         if (!h->fb_buf.p) return PO_OK;
@@ -347,7 +348,14 @@ static int make_dev_params(const po_handle_s *h, int form, int keep, po::DevPara
     D->ref_rho = p.refine_rho; D->ref_eps = p.refine_eps; D->ref_rounds = p.refine_rounds;
     D->ref_extra = (p.refine && p.refine_extra_rounds > 0) ? p.refine_extra_rounds : 0; D->ref_adapt = p.refine_adapt; D->ref_spec = p.refine_speculate;
     D->slice = (!p.refine && p.probe_iters > 0) ? p.probe_iters : 0;
-    D->ref_nw_rho = p.refine_newton_rho > 0 ? p.refine_newton_rho : 100.0; D->ref_nw_rho_max = p.refine_newton_rho_max; D->ref_nw_rho_eq_max = p.refine_newton_rho_eq_max; D->ref_nw_rho_eq = p.refine_newton_rho_eq > 0 ? p.refine_newton_rho_eq : 1e4; D->ref_ls_tol = p.refine_ls_tol > 0 ? p.refine_ls_tol : 1e-4;
+    // every refine_newton_* field is defaulted when it is not positive (a zero-initialised po_params must not silently disable the penalty growth) and the caps are
+    // held inside what the rest of the engine allows: with refine_newton_escalate the caps stand up to 100 x higher, so rho_max <= kRhoMax / 100 keeps the escalated
+    // inequality penalty <= kRhoMax, and rho_eq <= 1e8 / 100 keeps rho_eq (a.x - b) above its rounding at the dual tolerance (po_hip.h)
+    D->ref_nw_rho = p.refine_newton_rho > 0 ? std::min(p.refine_newton_rho, po::kRhoMax) : 100.0;
+    D->ref_nw_rho_eq = p.refine_newton_rho_eq > 0 ? std::min(p.refine_newton_rho_eq, 1e8) : 1e4;
+    D->ref_nw_rho_max = p.refine_newton_rho_max > 0 ? std::min(p.refine_newton_rho_max, po::kRhoMax / 100.0) : 1e5;
+    D->ref_nw_rho_eq_max = p.refine_newton_rho_eq_max > 0 ? std::min(p.refine_newton_rho_eq_max, 1e6) : (p.refine_newton_rho_eq_max < 0 ? 1e6 : 0.0);  // 0: the equality penalty never grows (documented switch)
+    D->ref_ls_tol = p.refine_ls_tol > 0 ? p.refine_ls_tol : 1e-4;
     D->ref_nw_final = p.refine_newton_final; D->ref_nw_esc = p.refine_newton_escalate; D->ref_ls_max = p.refine_ls_max > 0 ? p.refine_ls_max : 30; D->ref_nw_max = p.refine_newton_max > 0 ? p.refine_newton_max : 300;
     D->ref_split_warm = 0;
     return PO_OK;
@@ -395,6 +403,7 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     if (in->B == 0) return PO_OK;
     std::lock_guard<std::mutex> g(h->mu);
     HIP_TRY(hipSetDevice(h->device));
+    h->timed_host = false;  // (set again by po_solve_batch when this call is its inner solve: po_last_phase_ms never mixes this solve's events with an older call's)
     po::DevParams P;
     make_dev_params(h, in->formulation, in->keep, &P);
     po::DevBatch D;
@@ -489,7 +498,10 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
         // refine_chain = 2 reads the 4-byte count back and launches it only when there is something on the list — the call then returns when the Newton launch has
         // finished (it blocks, like probe_iters).  refine_chain = 3: always launched, the call stays asynchronous.
         bool need_fb = true;
-        if (h->params.refine_chain == 2) {
+        // a stream that is being captured cannot be waited on (the copy below would never run and a synchronise invalidates the capture): always issue the launch then
+        hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing(h->stream, &cap_st) == hipSuccess && cap_st != hipStreamCaptureStatusNone;
+        if (h->params.refine_chain == 2 && !capturing) {
             // the count lands in a pinned word the host SPINS on: a blocking hipStreamSynchronize wakes up through an interrupt — measured 0.5 ms, what the launch it
             // is meant to save costs; falls back to the blocking wait after 20 ms of spinning (a long solve: the wake-up latency no longer matters)
             volatile int *cnt = static_cast<volatile int *>(h->fb_host.p);
@@ -499,7 +511,11 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
             unsigned spins = 0;
             while (*cnt == -1) {
                 if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - ts0 > std::chrono::milliseconds(20)) { HIP_TRY(hipStreamSynchronize(h->stream)); break; }
+#if defined(__x86_64__) || defined(__i386__)
                 __builtin_ia32_pause();
+#else
+                std::this_thread::yield();
+#endif
             }
             need_fb = *cnt != 0;
         }

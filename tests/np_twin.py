@@ -255,3 +255,38 @@ def random_instance(rng, N, ds=0.25, form=PO_KP, narrow=False):
     max_k = 0.4 * 9.8 / v ** 2
     max_kp = 0.1 / v
     return dict(ref_x=x, ref_y=y, ref_z=z, ref_k=k, ref_s=s, bounds=bounds, x0=x0, goal_z=goal, max_k=max_k, max_kp=max_kp)
+
+
+def kkt_certificate(P, A, l, u, x, act_tol=1e-6):
+    """Solver-independent optimality certificate of a primal point x of  min 1/2 x'Px  s.t.  l <= Ax <= u  (P upper-triangular CSC as the
+    assemblers return it).  No multipliers are taken from any solver: the rows active at x are read off Ax, and scipy's bounded least squares finds the
+    multipliers of the right sign (y <= 0 at a lower bound, y >= 0 at an upper bound, free on equality rows) that minimise ||Px + A'y||.  x is optimal
+    iff the primal violation and that minimum are zero; returns both (inf-norms), the second also relative to ||Px||_inf."""
+    import scipy.sparse as sp
+    from scipy.optimize import lsq_linear
+
+    P = sp.csc_matrix(P)
+    Pf = P + P.T - sp.diags(P.diagonal())
+    A = sp.csr_matrix(A)
+    x = np.asarray(x, dtype=np.float64)
+    ax = A @ x
+    fin_l, fin_u = l > -1e20, u < 1e20
+    viol = float(max(0.0, np.max(np.where(fin_l, l - ax, 0.0)), np.max(np.where(fin_u, ax - u, 0.0))))
+    eq = fin_l & fin_u & (u - l < 1e-9)
+    at_l = fin_l & (ax - l <= act_tol * (1.0 + np.abs(np.where(fin_l, l, 0.0))))
+    at_u = fin_u & (u - ax <= act_tol * (1.0 + np.abs(np.where(fin_u, u, 0.0))))
+    rows = np.flatnonzero(eq | at_l | at_u)
+    g = Pf @ x
+    if rows.size == 0:
+        r = float(np.abs(g).max())
+        return dict(primal_violation=viol, stationarity=r, stationarity_rel=r / max(1.0, float(np.abs(g).max())), n_active=0)
+    free = eq[rows] | (at_l[rows] & at_u[rows])
+    lb = np.where(free | at_l[rows], -np.inf, 0.0)
+    ub = np.where(free | at_u[rows], np.inf, 0.0)
+    At = sp.csc_matrix(A[rows].T)
+    # column scaling (rows of A differ by orders of magnitude between the formulations' slack / curvature rows): plain diagonal preconditioning
+    cn = np.sqrt(np.asarray(At.multiply(At).sum(axis=0)).ravel())
+    cn[cn == 0] = 1.0
+    res = lsq_linear(At @ sp.diags(1.0 / cn), -g, bounds=(lb, ub), method="trf", tol=1e-13, lsmr_tol="auto", max_iter=400)
+    r = float(np.abs(At @ (res.x / cn) + g).max())
+    return dict(primal_violation=viol, stationarity=r, stationarity_rel=r / max(1.0, float(np.abs(g).max())), n_active=int(rows.size))

@@ -103,3 +103,55 @@ def test_random_case_refinement_matches_oracle(oracle, seed):
     conv = ok & (info["r_prim"] < 2e-6) & (info["r_dual"] < 2e-6) & (oinfo["r_prim"] < 2e-6) & (oinfo["r_dual"] < 2e-6)
     if conv.any():
         assert np.abs(st - ost)[conv][..., :3].max() < 1e-3, (seed, np.abs(st - ost)[conv][..., :3].max())
+
+
+HEADLINE = dict(refine=2, refine_rounds=5, refine_extra_rounds=2, refine_eps=1e-8)
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_case_newton_matches_oracle(oracle, seed):
+    """The HEADLINE setting (25 OSQP-faithful ADMM iterations + the Newton refinement, po_params.refine = 2) on the same random cases and parameter draws as the
+    refine = 0 sweep, a third of them with the corridors shrunk to 0.5 - 0.7 (soft margins bind, degenerate optima): statuses and certificates equal to the
+    oracle's, solved points within 1e-5, every solved path certified — and, independent of the oracle's own Newton code, a KKT certificate of the DEVICE
+    point computed from the assembled QP alone (np_twin.kkt_certificate: scipy's bounded least squares finds the multipliers)."""
+    from path_optimizer_amd import binding
+
+    rng, form, b = _case(seed)
+    if form == T.PO_KP:
+        b.keep = binding.keep_control_steps(form, b.ref_s[0])
+    st0 = rng.bit_generator.state
+    p = _params(rng, binding.default_params)
+    rng.bit_generator.state = st0
+    po = oracle.device_equivalent_params(_params(rng, binding.default_params))
+    if seed % 3 == 0:
+        b.bounds = b.bounds * float(rng.choice([0.5, 0.7]))
+    chain = int(rng.choice([2, 3]))
+    for q in (p, po):
+        for k, v in HEADLINE.items():
+            setattr(q, k, v)
+        q.refine_chain = chain
+    st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
+    ost, oinfo, oxs = oracle.solve_batch(b, po, want_x=True)
+    # a marginally infeasible corridor may trip OSQP's certificate before max_iter on one side only (-3 against -2): a failure status either way
+    fail_d, fail_o = info["status"] != 1, oinfo["status"] != 1
+    assert np.array_equal(fail_d, fail_o), (seed, info["status"], oinfo["status"])
+    ok = ~fail_d
+    assert np.array_equal(info["status_refine"][ok], oinfo["status_refine"][ok]), (seed, info["status_refine"], oinfo["status_refine"])
+    assert (info["status_refine"][ok] == 1).all(), (seed, form, b.N, b.keep, info["status_refine"], info["iters"])  # every solved path is certified
+    if ok.any():
+        assert np.abs(xs - oxs)[ok].max() < 1e-5, (seed, form, b.N, b.keep, np.abs(xs - oxs)[ok].max())
+        assert np.abs(st - ost)[ok].max() < 1e-5
+    # solver-independent: the KKT conditions of the reference's QP (oracle assembly = the reference's, bit for bit) at the device's point
+    pa = oracle.default_params()
+    for f in ("w_curv", "w_curv_rate", "w_slack", "w_dev", "k_w_curv", "k_w_curv_rate", "k_w_dev", "w_k_slack", "w_kp_slack", "margin", "max_steer", "wheel_base", "constraint_end_heading"):
+        setattr(pa, f, getattr(p, f))
+    checked = 0
+    for i in np.flatnonzero(ok)[:2]:
+        n_i = b.N if b.n_points is None else int(b.n_points[i])
+        nv, _, _ = oracle.dims(form, n_i, b.keep)
+        P, A, l, u = oracle.assemble(form, pa, n_i, b.keep, b.ref_k[i, :n_i], b.ref_s[i, :n_i], b.ref_z[i, n_i - 1], b.bounds[i, :n_i], b.x0[i], b.goal_z[i],
+                                     None if b.max_k is None else b.max_k[i, :n_i], None if b.max_kp is None else b.max_kp[i, :n_i])
+        k = T.kkt_certificate(P, A, l, u, xs[i, :nv])
+        assert k["primal_violation"] < 1e-6 and k["stationarity_rel"] < 1e-5, (seed, form, n_i, b.keep, int(i), k)
+        checked += 1
+    assert checked > 0 or not ok.any()

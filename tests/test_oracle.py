@@ -333,3 +333,22 @@ def test_frozen_tight_optima(oracle, form, name):
     assert (info["status"] == 1).all()
     rms = np.sqrt((((xs - xg)[:, ey]) ** 2).mean(axis=1))
     assert rms.max() < 2e-3, rms.max()
+
+
+def test_kkt_certificate_separates_certified_from_eps_1e_4_points(oracle):
+    """np_twin.kkt_certificate (what tests/test_gpu_fuzz.py holds the device's headline points to) takes no multipliers from any solver: on the points the
+    oracle certifies at refine_eps it finds multipliers that close the stationarity gap to 1e-7 of ||Px||; on the OSQP-faithful points at eps 1e-4 it cannot."""
+    from path_optimizer_amd import synth
+
+    b = synth.make_batch(3, B=2)
+    p = oracle.default_params()
+    ph = oracle.device_equivalent_params(oracle.default_params())
+    ph.refine, ph.refine_rounds, ph.refine_extra_rounds, ph.refine_eps = 2, 5, 2, 1e-8
+    _, hinfo, hx = oracle.solve_batch(b, ph, want_x=True)
+    _, dinfo, dx = oracle.solve_batch(b, oracle.device_equivalent_params(oracle.default_params()), want_x=True)
+    assert (hinfo["status_refine"] == 1).all() and (dinfo["status"] == 1).all()
+    for i in range(b.B):
+        P, A, l, u = oracle.assemble(b.formulation, p, b.N, b.keep, b.ref_k[i], b.ref_s[i], b.ref_z[i, -1], b.bounds[i], b.x0[i], b.goal_z[i])
+        kh, kd = T.kkt_certificate(P, A, l, u, hx[i]), T.kkt_certificate(P, A, l, u, dx[i])
+        assert kh["primal_violation"] < 1e-7 and kh["stationarity_rel"] < 1e-6, kh
+        assert kd["stationarity_rel"] > 1e-4, kd
