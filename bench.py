@@ -106,7 +106,7 @@ def config_legs(torch, binding, synth, dev, stream, steps=3):
         ref = {}
         gold, _gn = gold_for(b)
         dbx = binding.DeviceBatch(b, device=dev, want_x=True) if gold is not None else db
-        for tag, mut in (("headline_setting", dict(HEADLINE["params"])), ("round3_headline_setting", dict(HEADLINE_R3["params"]))):
+        for tag, mut in (("headline_setting", dict(HEADLINE["params"])),):
             p = binding.default_params()
             if not hasattr(p, "refine_newton_rho"):
                 break
@@ -168,8 +168,6 @@ def config_legs(torch, binding, synth, dev, stream, steps=3):
 HEADLINE = {"label": "ADMM warm start (25 it) + Newton refinement (refine = 2, refine_eps 1e-8 + final correction steps), split launches",
             "params": dict(refine=2, refine_rounds=5, refine_extra_rounds=2, refine_eps=1e-8, refine_chain=2),
             "algorithm": "EXTENSION (closer to the QP's optimum than the reference's OSQP run): certified per path, po_info.status_refine"}
-HEADLINE_R3 = {"label": "round-3 headline: eps 1e-4 + activity-weighted ADMM refinement (refine = 1; 3 rounds + 2 below eps, chained; refine_eps 1e-7)",
-               "params": dict(refine=1, refine_rounds=3, refine_extra_rounds=2)}
 OSQP_DEFAULT = {"label": "eps 1e-4, OSQP defaults only (no extension)", "params": {},
                 "algorithm": "OSQP-FAITHFUL (identical to the reference's algorithm: same iteration counts as the CPU restatement of OSQP)"}
 
@@ -235,24 +233,16 @@ def settings_table(torch, binding, batch, dev, stream, gold):
     rows = []
     for label, kw in (("eps 1e-4 (OSQP defaults only)", {}),
                       ("eps 1e-4 + polish (OSQP: 1 pass)", dict(polish=1)),
-                      ("eps 1e-4 + polish (active-set passes <= 6)", dict(polish=1, polish_passes=6)),
-                      ("eps 1e-4 + refine (1 round)", dict(refine=1)),
-                      ("eps 1e-4 + refine, 3 rounds, one launch pair per round", dict(refine=1, refine_rounds=3, refine_chain=0)),
-                      ("eps 1e-4 + refine, 3 rounds, chained", dict(refine=1, refine_rounds=3)),
-                      ("eps 1e-4 + refine, 3 rounds + 2 below eps, one launch pair per round", dict(refine=1, refine_rounds=3, refine_extra_rounds=2, refine_chain=0)),
-                      (HEADLINE_R3["label"], HEADLINE_R3["params"]),
                       (HEADLINE["label"], HEADLINE["params"]),
                       ("Newton refinement, fallback launch always issued: fully asynchronous (refine_chain = 3)", dict(HEADLINE["params"], refine_chain=3)),
-                      ("Newton refinement, chained in one launch pair (refine_chain = 1)", dict(HEADLINE["params"], refine_chain=1)),
                       ("Newton refinement, entered at 1e3 x eps (refine_rounds = 4)", dict(HEADLINE["params"], refine_rounds=4)),
                       ("Newton refinement, entered at 1e2 x eps (refine_rounds = 3)", dict(HEADLINE["params"], refine_rounds=3)),
                       ("Newton refinement, without the final correction steps", dict(HEADLINE["params"], refine_newton_final=0)),
                       ("Newton refinement, line search to 1e-4 and ONE correction step (the defaults profiles/r4b was taken with)", dict(HEADLINE["params"], refine_ls_tol=1e-4, refine_newton_final=1)),
                       ("Newton refinement, equality penalty fixed (refine_newton_rho_eq_max = 0)", dict(HEADLINE["params"], refine_newton_rho_eq_max=0.0)),
                       ("Newton refinement, refine_eps 3e-9", dict(HEADLINE["params"], refine_eps=3e-9)),
-                      ("eps 1e-4 + refine, 3 + 2 rounds, refine_adapt off", dict(refine=1, refine_rounds=3, refine_extra_rounds=2, refine_adapt=0)),
-                      ("eps 1e-4 + refine, 3 + 2 rounds, refine_eps 1e-6", dict(refine=1, refine_rounds=3, refine_extra_rounds=2, refine_eps=1e-6)),
-                      ("eps 1e-3 (OSQP's own default, what the reference runs) + refine 3 + 3 rounds", dict(refine=1, refine_rounds=3, refine_extra_rounds=3, eps_abs=1e-3, eps_rel=1e-3)),
+                      ("Newton refinement from the point eps 1e-4 stops at (refine_rounds = 1)", dict(HEADLINE["params"], refine_rounds=1)),
+                      ("eps 1e-3 (OSQP's own default, what the reference runs) + Newton refinement", dict(HEADLINE["params"], eps_abs=1e-3, eps_rel=1e-3)),
                       ("eps 1e-5, max_iter 20000", dict(eps_abs=1e-5, eps_rel=1e-5, max_iter=20000)),
                       ("eps 1e-6, max_iter 20000", dict(eps_abs=1e-6, eps_rel=1e-6, max_iter=20000))):
         row, x, info = run_setting(torch, binding, stream, db, kw)
@@ -370,9 +360,7 @@ def stage_legs_gpu(torch, binding, synth, eng, stream, dbatch, B):
                                                        "qp_iters_mean": float(pinf4["iters"].mean())}
     e4.close()
     # the same 4096 instances with the path QP's refinement phase (po_params.refine, include/po_hip.h): every path ends at residuals of 1e-6 or keeps its plain point
-    # ... and with the probe + longest-first schedule of the path QP (po_params.probe_iters: results bit-identical to the plain leg)
-    for tag, kw in (("headline_setting", dict(HEADLINE["params"])), ("headline_setting_adapt_tol_2", dict(HEADLINE["params"], adapt_tol=2.0)),
-                    ("probe_150_then_longest_first", dict(probe_iters=150))):
+    for tag, kw in (("headline_setting", dict(HEADLINE["params"])), ("headline_setting_adapt_tol_2", dict(HEADLINE["params"], adapt_tol=2.0))):
         p5 = binding.default_params()
         for k_, v_ in kw.items():
             setattr(p5, k_, v_)

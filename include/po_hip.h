@@ -108,69 +108,36 @@ typedef struct po_params {
                                            iterative refinement (OSQP polish.c); the result replaces the ADMM solution when OSQP's acceptance rule holds */
     double polish_delta;                /* OSQP `delta` (1e-6) */
     int    polish_refine_iter;          /* OSQP `polish_refine_iter` (3) */
-    int    polish_passes;               /* 1 = OSQP's polish.  > 1 (extension): the active set is re-derived from the polished point and the solve repeated, up
-                                           to this many times, until it reproduces itself (then the point satisfies the KKT conditions exactly) */
-    /* Refinement (extension, off by default; runs after a path is solved and before the polish): the ADMM iteration continued with OSQP's per-constraint step
-     * vector set by ACTIVITY instead of by bound type alone — equality rows 1e3 * refine_rho (as OSQP), inequality rows that are active (z at a bound with a
-     * multiplier of the right sign) refine_rho, inactive rows OSQP's RHO_MIN — re-derived every refine_every iterations (numeric refactorisation when it
-     * changed, at most refine_max_refactor times), until OSQP's termination test holds at refine_eps or refine_max_iter iterations are spent.  Still ADMM on
-     * the same QP (any positive step vector has the same fixed point), but on these nearly flat problems it reaches in tens of iterations what the
-     * type-based vector needs thousands for; it puts every path of the BASELINE config-3 sample within 1e-4 m of the exact optimum (39 % without). */
+    /* Refinement (extension, off by default; runs after a path is solved and before the polish).  refine = 2: semismooth Newton on the augmented Lagrangian
+     *     phi_y(x) = 1/2 x'Px + sum_i rho_i / 2 dist^2(a_i x + y_i / rho_i, [l_i, u_i])
+     * (rho_i = refine_newton_rho on inequality rows, refine_newton_rho_eq on equality rows, scaled problem) with a line search on the piecewise-quadratic merit (safeguarded
+     * Newton on its piecewise-linear derivative, run to refine_ls_tol), and a multiplier update  y <- rho (w - clip(w))  whenever the inner problem is solved to the dual
+     * tolerance.  Each Newton step is ONE factorisation of the same block-tridiagonal matrix the ADMM iteration uses, with the rows outside their bounds at rho_i and the
+     * others at OSQP's RHO_MIN, one solve, and a few row passes for the line search; the method is monotone in phi and terminates finitely.  It runs from the point the
+     * OSQP-faithful ADMM iteration stops at (refine_rounds: how early) until OSQP's termination test holds at refine_eps (po_info.status_refine = 1: certified).
+     * po_info.iters counts a Newton step as one iteration.  On BASELINE config 3 every path ends within 1e-4 m of the exact optimum (39 % at eps 1e-4 without).
+     * Values: 0 off (the library default: OSQP-faithful), 2 on.  (ABI 5 removed refine = 1 — the activity-weighted ADMM continuation of rounds 2 - 3 —, its knobs
+     * refine_every / refine_max_iter / refine_max_refactor / refine_rho / refine_adapt, the chained-rounds scheduling refine_chain 0 / 1 with refine_speculate, probe_iters
+     * and polish_passes: the Newton phase in its own launches is faster on every shape, profiles/README.md; po_create returns PO_ERR_INVALID for refine = 1.) */
     int    refine;
-    int    refine_every;                /* 10 */
-    int    refine_max_iter;             /* 400 */
-    int    refine_max_refactor;         /* 40: free re-derivation for the first half of this budget, then active rows stay active (the set only grows, which
-                                           ends any flip-flopping); when it is spent the vector goes back to the bound types at refine_rho */
-    double refine_rho;                  /* 10 (scaled problem, like rho0) */
     double refine_eps;                  /* 1e-7: eps_abs = eps_rel of the termination test of this phase (what po_info.status_refine = 1 certifies).  Measured on all 4096
                                            paths of BASELINE config 3 against their exact optima: certified at 1e-7 -> max e_y RMS error 1e-5 m; at 1e-6 seven certified
                                            paths were 1e-4 .. 4e-4 m away (these QPs are flat: e_y is the double integral of the curvature) */
-    int    refine_rounds;               /* 1.  R > 1: the solve first stops at 10^(R-1) x (eps_abs, eps_rel) and is refined from there (budget refine_max_iter / 4);
-                                           a path the refinement does not certify at refine_eps goes back to the type-based iteration at a 10 x tighter eps and is
-                                           refined again, down to eps itself (last round: the full budget).  Every path returned satisfies OSQP's test at eps_abs /
-                                           eps_rel or at refine_eps; most never run the slow type-based iteration to the end (BASELINE config 3, R = 3: mean 159
-                                           iterations instead of 340, longest path 925 instead of 1 600) */
-    int    probe_iters;                 /* 0 = off.  > 0 (scheduling only, results bit-identical; ignored with refine, two-level shapes only): the solve runs
-                                           in two launch pairs.  The first runs every path for at most this many ADMM iterations; unfinished paths are handed back
-                                           (iterate in the engine's state block).  The host then orders them by the dual residual they had at the hand-back, largest
-                                           first — a fair predictor of the iterations still to go — and the second pair resumes them in that order (a caller-supplied
-                                           po_batch_in.order is used instead when there is one).  For batches whose total work per resident slot exceeds the longest
-                                           path (the planning pipeline's 4096 QPs on 512 slots: iteration counts 125 .. 1 900, half of them above 500): a launch in
-                                           arbitrary order ends with a long tail of half-empty CUs; longest-first packs it.  150 is a good value there.
-                                           NOTE: with probe_iters > 0 the device-pointer entry is NOT asynchronous (the host reads po_info between the two launch
-                                           pairs and sorts): it blocks, cannot be stream-captured, and po_last_kernel_ms then includes that host time. */
-    int    refine_chain;                /* 1 (default).  refine_rounds > 1 only; scheduling only, results bit-identical.  (2 / 3, with refine = 2 only: "split" — the short type-based
-                                           warm start runs in the plain solve kernels, the Newton refinement of round 0 as a launch of its own, and the paths it does not
-                                           certify (rare) go through their later rounds in a fallback launch: each kernel keeps its own register allocation, nothing waits on
-                                           a queue.  2: the fallback launch is issued only when a path needs it — the engine reads a 4-byte count back, so the device-pointer
-                                           entry returns when the Newton launch has FINISHED (it blocks; the launch it saves costs 0.5 ms); 3: always issued, fully asynchronous.)  1: all rounds run inside ONE launch pair —
-                                           a workgroup that does not certify its path pushes it onto a device-side queue and a follow-up workgroup of the same launch
-                                           resumes it, so a later round fills the tail of the one before instead of waiting for its slowest path.  0: one launch pair per
-                                           round (every round ends with a chip-wide barrier). */
+    int    refine_rounds;               /* 1.  R > 1: the solve first stops at 10^(R-1) x (eps_abs, eps_rel) and is refined from there; a path the refinement does not
+                                           certify at refine_eps goes back to the type-based iteration at a 10 x tighter eps and is refined again, down to eps itself.
+                                           Every path returned satisfies OSQP's test at eps_abs / eps_rel or at refine_eps.  The headline setting uses 5: the ADMM
+                                           iteration is then only a 25-iteration warm start (its first termination check passes at 1e4 x eps) */
+    int    refine_chain;                /* 2 (default) or 3; scheduling only, results bit-identical.  The solve is three launches on one stream: the plain solve kernels as the
+                                           warm start, the Newton refinement of round 0 as a launch of its own, and a fallback launch that takes the paths it did not
+                                           certify (rare) through their later rounds.  2: the fallback launch is issued only when a path needs it — the engine reads a
+                                           4-byte count back, so the device-pointer entry returns when the Newton launch has FINISHED (it blocks; the launch it saves
+                                           costs 0.5 ms; a stream that is being captured is detected and treated as 3); 3: always issued, fully asynchronous. */
     int    refine_extra_rounds;         /* 0.  E > 0: a path that the last regular round does not certify at refine_eps continues BELOW eps — type-based iteration at
-                                           eps / 10, refinement again, eps / 100, ... — for up to E more rounds (full refinement budget each).  A path returned after
-                                           them is certified, or satisfies OSQP's test at eps / 10^E — or ran out of max_iter in one of these rounds: then the point it ends on is tested
-                                           against OSQP's criteria at the caller's eps once more — passes: that point, PO_STATUS_SOLVED with status_refine -1; fails (ADMM residuals
-                                           are not monotone): the point that round STARTED from (it met eps in the round before), PO_STATUS_SOLVED with status_refine -1.  A round
-                                           below eps never turns a solved path into MAX_ITER (round 4; before, the failing iterate was returned as MAX_ITER).  For the handful of nearly flat QPs on which the activity-set
-                                           iteration cycles (BASELINE config 3: 11 of 4096 paths): they are the ones left > 0.1 m from the optimum at eps. */
-    int    refine_adapt;                /* 1.  OSQP's adaptive-rho rule (balance of the relative residuals, applied when the estimate leaves [rho / adapt_tol, rho x adapt_tol])
-                                           on the refinement's own rho, after a block of refine_every iterations that kept its step vector.  Once the activity set has
-                                           settled the phase is dual ascent on the active rows; with a fixed refine_rho a multiplier that must grow to O(1) takes
-                                           thousands of iterations (primal residual stuck at 1e-4 while the dual one is 1e-10).  0: refine_rho stays fixed. */
-    int    refine_speculate;            /* 1.  Chained rounds only; scheduling only, results bit-identical.  k >= 0: from round k on, while a workgroup refines a
-                                           solved path another one already runs the NEXT round's type-based iteration from the same solved point — which is what the
-                                           path does anyway when the refinement fails (it then returns to that point).  A refinement that certifies (or improves) the
-                                           point cancels the continuation; one that fails hands the path to it.  Takes the failed attempts of the hardest paths — up to
-                                           600 refinement iterations each on BASELINE config 3 — off the launch's critical path.  -1: off. */
-    /* refine = 2 (round 4): the refinement phase is a GLOBALISED method instead of the activity-weighted ADMM continuation of refine = 1 — semismooth Newton on
-     * the augmented Lagrangian  phi_y(x) = 1/2 x'Px + sum_i rho_i / 2 dist^2(a_i x + y_i / rho_i, [l_i, u_i])  (rho_i = refine_newton_rho on inequality rows,
-     * refine_newton_rho_eq on equality rows, scaled problem) with a line search on the piecewise-quadratic merit (safeguarded Newton on its piecewise-linear derivative, run to refine_ls_tol),
-     * and a multiplier update  y <- rho (w - clip(w))  whenever the inner problem is solved to the dual tolerance.  Each Newton step is ONE factorisation of the same
-     * block-tridiagonal matrix the ADMM iteration uses, with the rows outside their bounds at rho_i and the others at OSQP's RHO_MIN (exactly the matrix of
-     * refine = 1), one solve, and a few row passes for the line search.  Without the line search the activity set cycles (that is the failure mode of refine = 1 on
-     * ~0.3 % of BASELINE config 3, and of a repeated polish); with it the method is monotone in phi and terminates finitely.  Certification, status_refine, the
-     * rounds, the chained scheduling and the hand-back rules are those of refine = 1; po_info.iters counts a Newton step as one iteration. */
+                                           eps / 10, refinement again, eps / 100, ... — for up to E more rounds.  A path returned after them is certified, or satisfies
+                                           OSQP's test at eps / 10^E — or ran out of max_iter in one of these rounds: then the point it ends on is tested against OSQP's
+                                           criteria at the caller's eps once more — passes: that point, PO_STATUS_SOLVED with status_refine -1; fails (ADMM residuals are
+                                           not monotone): the point that round STARTED from (it met eps in the round before), PO_STATUS_SOLVED with status_refine -1.  A
+                                           round below eps never turns a solved path into MAX_ITER. */
     double refine_newton_rho;           /* 100 (scaled problem): penalty of the inequality rows at the start of an attempt; it grows 10 x whenever a multiplier update does not cut the
                                            primal residual by 4.  Measured on the whole BASELINE batches (oracle): 100 needs the fewest steps AND has the shortest tail (config 3:
                                            mean 14.8 / max 40 Newton steps; 1e3: 16.1 / 52; 1e4: 18.4 / 240; 30: 16.3 / 40 but 4 of 512 narrow-corridor paths uncertified) */
@@ -178,7 +145,8 @@ typedef struct po_params {
                                            gradient carries rho_eq x (a.x - b), a difference of O(1) numbers, whose rounding at rho_eq >= 1e6 sits near the dual tolerance);
                                            raised only for a path whose multiplier updates stall, see refine_newton_rho_eq_max */
     double refine_newton_rho_max;       /* 1e5: a multiplier update that does not cut the primal residual by 4 raises the penalty 10 x, up to this (the slow
-                                           case: active rows that are nearly dependent through the heavily weighted curvature-rate variables) */
+                                           case: active rows that are nearly dependent through the heavily weighted curvature-rate variables).  <= 0: the default;
+                                           at most OSQP's RHO_MAX = 1e6, which also bounds what refine_newton_escalate raises it to */
     double refine_ls_tol;               /* 0.3: the line search stops at |psi'(t)| <= tol |psi'(0)| (the search is a safeguarded Newton iteration on the piecewise-linear psi', so
                                            what it accepts is close to the root anyway; measured on the whole BASELINE batches against 1e-4: 3 - 7 % fewer Newton steps AND 14 %
                                            fewer evaluations per step, every path certified at the same distance from the optimum).  The final correction steps always search to 1e-4. */
@@ -199,7 +167,8 @@ typedef struct po_params {
     double refine_newton_rho_eq_max;    /* 1e6: once the inequality penalty sits at refine_newton_rho_max and a multiplier update still does not cut the primal residual by 4,
                                            the EQUALITY rows' penalty grows 10 x instead, up to this.  The case: the primal residual left on the dynamics rows, whose multipliers
                                            converge at H / (H + rho_eq) per update when the active inequality rows beside them carry 10 x their penalty (wide corridors with a
-                                           large initial offset: 24 of 4096 paths of `host_test bench` ran out of updates uncertified without it; config 5: hardest path 222 -> 129) */
+                                           large initial offset: 24 of 4096 paths of `host_test bench` ran out of updates uncertified without it; config 5: hardest path 222 -> 129).
+                                           0: the equality penalty never grows; < 0: the default; at most 1e8, which also bounds what refine_newton_escalate raises it to */
 } po_params;
 
 typedef struct po_info {
@@ -212,7 +181,8 @@ typedef struct po_info {
     double rho;         /* final rho                                    */
     double obj;         /* 0.5 x'Px at exit                             */
     int    status_refine; /* po_params.refine: 0 the refinement did not run on this path (refine off, or the path was not solved); 1 CERTIFIED: OSQP's
-                             termination test holds on the returned point at refine_eps (default 1e-7), i.e. the point is the QP's optimum to that tolerance; -1 the
+                             termination test holds ON THE RETURNED POINT at refine_eps (default 1e-7; re-evaluated after every step, the final correction steps included:
+                             ABI 5), i.e. the point is the QP's optimum to that tolerance; -1 the
                              refinement ran out of its budget before that: the returned point satisfies OSQP's test at eps_abs / eps_rel only (it is the refined
                              point when its residuals are no worse than the solved point's, else the solved point) — a caller that needs the <= 1e-4 m accuracy
                              clause per path treats -1 as "not certified" */
@@ -284,30 +254,19 @@ int po_create(int device, const po_params *params, po_handle *out);
 int po_destroy(po_handle h);
 /* Use an existing hipStream_t (e.g. torch's current stream); NULL = the handle's own stream. */
 int po_set_stream(po_handle h, void *hip_stream);
-/* Developer switches for A/B measurements and tests (the library reads NO environment variable; results never depend on these except "split", which
- * selects an experimental kernel with equal results to rounding).  Keys: "identity_order" (workgroup i solves path i instead of the XCD-aware mixing),
- * "debug_cycles" (per-phase shader clocks of path 0 on stderr; makes the solve entry synchronous), "split" (stage-split two-wave mapping of the keep-4
- * kernel; PO_ERR_UNSUPPORTED unless the library was built with `make SPLIT=1`), "smooth_seq", "smooth_waves", "smooth_nopad", "smooth_debug" (smoothing-QP
- * engine variants), "dp_one_wave" (DP lattice search on one wave per instance whatever the batch size), "queue_policy" (chained refinement rounds: 0 = a workgroup takes a
- * fresh path before a hand-back, k >= 1 = hand-backs of round >= k first, -1 = automatic: 0, or 1 when the caller supplies po_batch_in.order; scheduling only).  Unknown key: PO_ERR_INVALID. */
+/* Developer switches for A/B measurements and tests (the library reads NO environment variable; results never depend on these).  Keys: "identity_order" (workgroup i
+ * solves path i instead of the XCD-aware mixing), "debug_cycles" (per-phase shader clocks of path 0 on stderr; makes the solve entry synchronous), "host_threads",
+ * "smooth_seq", "smooth_waves", "smooth_nopad", "smooth_debug" (smoothing-QP engine variants), "dp_one_wave" (DP lattice search on one wave per instance whatever
+ * the batch size).  Unknown key: PO_ERR_INVALID. */
 int po_debug_set(po_handle h, const char *key, int value);
-/* Developer read-back (synchronises the stream): "fallback_paths" = how many paths the Newton launch of the last split-scheduled solve (refine = 2, refine_chain 2 / 3)
- * did not certify and handed to the fallback launch. */
+/* Developer read-back (synchronises the stream): "fallback_paths" = how many paths the Newton launch of the last solve with refine = 2 did not certify and handed to
+ * the fallback launch. */
 int po_debug_get(po_handle h, const char *key, long long *value);
-/* Developer tool: with po_debug_set(h, "queue_trace", 1), the item timeline of the last chained-rounds solve — records of 4 int64: path | round << 32 |
- * speculative << 40 | outcome << 48 (0 final, 1 handed back, 2 failed attempt handed to its continuation, 3 / 4 continuation cancelled), start, end
- * (100 MHz device wall clock), workgroup index.  Returns the number of records copied (synchronises the stream). */
-int po_debug_trace_read(po_handle h, long long *out, int max_records);
 
 /* Host-pointer entry: H2D, solve, D2H, synchronous. */
 int po_solve_batch(po_handle h, const po_batch_in *in, const po_batch_out *out);
 /* Device-pointer entry: all pointers in `in`/`out` are device pointers; asynchronous on the stream. */
 int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out *out);
-/* Synchronises the handle's stream and reports whether the last solve ran to its end: PO_OK, or PO_ERR_HIP when a workgroup of a chained-rounds launch
- * (po_params.refine_chain = 1) gave up waiting for a hand-back — a protocol time-out (5 s, or longer in proportion to max_iter / refine_max_iter / the rounds); every
- * other waiter then leaves at once and the affected paths are reported PO_STATUS_UNSOLVED.  po_solve_batch (host pointers) performs this check itself. */
-int po_solve_status(po_handle h);
-
 /* ---- post-solve step: PathOptimizer::optimizePath, src/path_optimizer/path_optimizer.cpp:183-200 ----
  * Upload the obstacle-distance layer (host pointer in `map->distance`) to the handle's device; kept until replaced. */
 int po_set_map(po_handle h, const po_map *map);
@@ -495,11 +454,13 @@ int po_last_kernel_ms(po_handle h, float *ms);
 /* Where the last solve spent its time, ms8[8] (hipEvents on the handle's stream + host wall clock; valid after the call returned / the stream was synchronised):
  *   after po_solve_batch (host pointers: the caller's arrays are packed into a pinned staging block on several host threads while the slices already packed travel
  *   over PCIe, one D2H into a pinned block, threaded unpack): [0] pack + H2D, [1] the solve (= po_last_kernel_ms), [2] D2H, [3] host pack alone, [4] host unpack;
- *   with po_params.refine = 2, refine_chain = 2 (either entry): [5] equilibration + warm-start launches, [6] the Newton launch, [7] what follows it: the fallback launch when a path needs it (refine_chain = 3: always), status sweep. */
+ *   with po_params.refine = 2 (either entry): [5] equilibration + warm-start launches, [6] the Newton launch, [7] what follows it: the fallback launch when a path needs it (refine_chain = 3: always), status sweep. */
 int po_last_phase_ms(po_handle h, float *ms8);
 
 const char *po_strerror(int code);
 const char *po_last_hip_error(void);
+/* "po_hip <abi> (gfx950)"; PO_ABI_VERSION is bumped whenever a struct layout or an entry point changes (5: round 5, see po_params.refine) */
+#define PO_ABI_VERSION 5
 const char *po_version(void);
 
 #ifdef __cplusplus

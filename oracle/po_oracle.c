@@ -98,10 +98,8 @@ void po_oracle_default_params(po_params *p) {
     p->mu = 0.4; p->max_curvature_rate = 0.1; p->search_lateral_range = 10.0; p->search_long_spacing = 1.5; p->search_lat_spacing = 0.6;
     p->enable_dynamic_segmentation = 1;
     p->enable_raw_output = 1; p->output_spacing = 0.3; /* planning_flags.cpp:127-129 */
-    p->polish = 0; p->polish_delta = 1e-6; p->polish_refine_iter = 3; p->polish_passes = 1; /* OSQP defaults (polish off) */
-    p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-7; p->refine_rounds = 1; p->probe_iters = 0;  /* (probe_iters: device scheduling only, no effect on results) */
-    p->refine_chain = 1; /* device scheduling only */
-    p->refine_extra_rounds = 0; p->refine_adapt = 1; p->refine_speculate = 1; /* (device scheduling only) */
+    p->polish = 0; p->polish_delta = 1e-6; p->polish_refine_iter = 3; /* OSQP defaults (polish off) */
+    p->refine = 0; p->refine_eps = 1e-7; p->refine_rounds = 1; p->refine_chain = 2 /* device scheduling only */; p->refine_extra_rounds = 0;
     p->refine_newton_rho = 100.0; p->refine_newton_rho_eq = 1e4; p->refine_newton_rho_max = 1e5; p->refine_ls_tol = 0.3; p->refine_ls_max = 30; p->refine_newton_max = 300; p->refine_newton_final = 3; p->refine_newton_escalate = 12; p->refine_newton_rho_eq_max = 1e6; /* refine = 2 */
 }
 
@@ -1197,21 +1195,17 @@ resume_main:
     info->r_prim = pri_res;
     info->r_dual = dua_res;
     info->rho = rho;
-    /* ---- refinement (po_params.refine; extension, not OSQP): the same ADMM iteration continued with the step vector set by activity (see po_hip.h) ---- */
-    if (prm->refine && info->status == PO_STATUS_SOLVED && !exhausted) {
-        double rb = prm->refine_rho < OSQP_RHO_MIN ? OSQP_RHO_MIN : (prm->refine_rho > OSQP_RHO_MAX ? OSQP_RHO_MAX : prm->refine_rho);
-        double rb_next = rb;
-        const int every = prm->refine_every > 0 ? prm->refine_every : 10;
-        int nfac = 0, it2 = 0, frozen = 0, stop = 0;
-        (void)frozen;
-        const int cap_it = round + 1 < rounds ? (prm->refine_max_iter / 4 > every ? prm->refine_max_iter / 4 : every) : prm->refine_max_iter;
+    /* ---- refinement (po_params.refine = 2; extension, not OSQP): semismooth Newton on the augmented Lagrangian from the point the ADMM iteration stopped at (see po_hip.h;
+     * the activity-weighted ADMM continuation refine = 1 of rounds 2 - 3 was removed in round 5) ---- */
+    if (prm->refine == 2 && info->status == PO_STATUS_SOLVED && !exhausted) {
+        int nfac = 0, it2 = 0, stop = 0;
         double *snap = (double *)malloc(sizeof(double) * (size_t)(n + 2 * m)); /* the solved point: kept if the phase does not end at least as well */
         const double pri0 = pri_res, dua0 = dua_res;
         memcpy(snap, x, sizeof(double) * (size_t)n);
         memcpy(snap + n, z, sizeof(double) * (size_t)m);
         memcpy(snap + n + m, y, sizeof(double) * (size_t)m);
-        if (prm->refine == 2) {
-            /* ---- refine = 2: semismooth Newton on the augmented Lagrangian with an exact line search (po_hip.h).  State: x and w_i = a_i x + y_i / rho_i
+        {
+            /* ---- semismooth Newton on the augmented Lagrangian with an exact line search (po_hip.h).  State: x and w_i = a_i x + y_i / rho_i
              * (one number per row, like the engine's v); implied z = clip(w), y = rho (w - z).  rho_i: rb_in on inequality rows, rb_eq on equality rows (both grow on a stall, see below). ---- */
             double rn_ = prm->refine_newton_rho;
             rn_ = rn_ < OSQP_RHO_MIN ? OSQP_RHO_MIN : (rn_ > OSQP_RHO_MAX ? OSQP_RHO_MAX : rn_);
@@ -1220,8 +1214,8 @@ resume_main:
             double rb_in = rn_, pri_outer = -1.0;
             double rb_eq = prm->refine_newton_rho_eq > 0 ? (prm->refine_newton_rho_eq < 1e8 ? prm->refine_newton_rho_eq : 1e8) : 1e4;
             /* the caps, defaulted and bounded exactly as the engine's make_dev_params does (csrc/po_capi.cpp): 0 in refine_newton_rho_eq_max is the documented "never grows" */
-            const double in_cap = prm->refine_newton_rho_max > 0 ? (prm->refine_newton_rho_max < OSQP_RHO_MAX / 100.0 ? prm->refine_newton_rho_max : OSQP_RHO_MAX / 100.0) : 1e5;
-            const double eq_cap = prm->refine_newton_rho_eq_max > 0 ? (prm->refine_newton_rho_eq_max < 1e6 ? prm->refine_newton_rho_eq_max : 1e6) : (prm->refine_newton_rho_eq_max < 0 ? 1e6 : 0.0); /* (below rb_eq: never grows) */
+            const double in_cap = prm->refine_newton_rho_max > 0 ? (prm->refine_newton_rho_max < OSQP_RHO_MAX ? prm->refine_newton_rho_max : OSQP_RHO_MAX) : 1e5;
+            const double eq_cap = prm->refine_newton_rho_eq_max > 0 ? (prm->refine_newton_rho_eq_max < 1e8 ? prm->refine_newton_rho_eq_max : 1e8) : (prm->refine_newton_rho_eq_max < 0 ? 1e6 : 0.0); /* (below rb_eq: never grows) */
             const int cap_nw = prm->refine_newton_max > 0 ? prm->refine_newton_max : 300;
             const int ls_max = prm->refine_ls_max > 0 ? prm->refine_ls_max : 30;
             double *w = (double *)malloc(sizeof(double) * (size_t)(m + 1)), *sv = (double *)malloc(sizeof(double) * (size_t)(m + 1));
@@ -1272,8 +1266,9 @@ resume_main:
                     const int esc_n = prm->refine_newton_escalate;
                     const double esc = esc_n > 0 && nouter >= esc_n ? (nouter >= 2 * esc_n ? 100.0 : 10.0) : 1.0;
                     if (pri_outer >= 0.0 && pri_res > 0.25 * pri_outer) {
-                        if (rb_in * 10.0 <= in_cap * esc) { ratio = 0.1; rb_in *= 10.0; first_fac = 1; }
-                        else if (rb_eq * 10.0 <= eq_cap * esc) { ratio_eq = 0.1; rb_eq *= 10.0; first_fac = 1; }
+                        /* (the escalated caps stay inside OSQP's RHO_MAX for the inequality rows, 1e8 for the equality rows) */
+                        if (rb_in * 10.0 <= (in_cap * esc < OSQP_RHO_MAX ? in_cap * esc : OSQP_RHO_MAX)) { ratio = 0.1; rb_in *= 10.0; first_fac = 1; }
+                        else if (rb_eq * 10.0 <= (eq_cap * esc < 1e8 ? eq_cap * esc : 1e8)) { ratio_eq = 0.1; rb_eq *= 10.0; first_fac = 1; }
                     }
                     pri_outer = pri_res;
                     for (int i = 0; i < m; ++i) w[i] = Axv[i] + (ctype[i] == 1 ? ratio_eq : ratio) * (w[i] - z[i]);
@@ -1338,80 +1333,6 @@ resume_main:
                 if (certified) ++nfinal;
             }
             free(w); free(sv); free(dv); free(Pd);
-        } else
-        for (;;) {
-            /* step vector from the bound type (as set_rho_vec) and, for inequality rows, from activity: z at a bound with a multiplier of the matching sign.
-             * Once the refactorisation budget is spent (an active set that keeps flipping) the vector goes back to the type-based one and stays. */
-            int changed = 0;
-            const double rb_old = rb;
-            rb = rb_next;
-            if (!frozen || rb != rb_old) {
-                if (nfac >= prm->refine_max_refactor) frozen = 1;
-                for (int i = 0; i < m; ++i) {
-                    double r;
-                    if (ctype[i] == -1) r = OSQP_RHO_MIN;
-                    else if (ctype[i] == 1) r = OSQP_RHO_EQ_OVER_INEQ * rb;
-                    else {
-                        /* active: z at a bound with a multiplier of the matching sign, tested on v = z + y / rho like the engine does (a multiplier so small
-                         * that it moves v off the bound by less than 1e-9 (1 + |bound|) counts as zero: its sign is rounding noise) */
-                        const double v = z[i] + rho_inv[i] * y[i];
-                        const double tl_ = 1e-9 * (1.0 + fabs(l[i])), tu_ = 1e-9 * (1.0 + fabs(u[i])); /* a numerically zero multiplier is no multiplier */
-                        r = (frozen || v < l[i] - tl_ || v > u[i] + tu_ || (2 * nfac >= prm->refine_max_refactor && rho_vec[i] == rb_old)) ? rb : OSQP_RHO_MIN;
-                    }
-                    if (r != rho_vec[i]) { rho_vec[i] = r; changed = 1; }
-                }
-            }
-            if (changed) {
-                for (int i = 0; i < m; ++i) { rho_inv[i] = 1.0 / rho_vec[i]; K.Kx[K.rho_pos[i]] = -rho_inv[i]; }
-                if (ldl_numeric(&F, K.Kp, K.Ki, K.Kx)) { free(snap); rc = PO_ERR_INVALID; goto done; }
-                ++nfac;
-            }
-            stop = 0;
-            for (int k = 0; k < every && it2 < cap_it; ++k) {
-                ++it2;
-                memcpy(x_prev, x, sizeof(double) * (size_t)n);
-                memcpy(z_prev, z, sizeof(double) * (size_t)m);
-                for (int i = 0; i < n; ++i) rhs[pinv[i]] = sigma * x_prev[i] - q[i];
-                for (int i = 0; i < m; ++i) rhs[pinv[n + i]] = z_prev[i] - rho_inv[i] * y[i];
-                ldl_solve(&F, rhs);
-                for (int i = 0; i < n; ++i) x[i] = alpha * rhs[pinv[i]] + (1.0 - alpha) * x_prev[i];
-                for (int i = 0; i < m; ++i) {
-                    const double zt = z_prev[i] + rho_inv[i] * (rhs[pinv[n + i]] - y[i]);
-                    const double zr = alpha * zt + (1.0 - alpha) * z_prev[i];
-                    const double v = zr + rho_inv[i] * y[i];
-                    z[i] = v < l[i] ? l[i] : (v > u[i] ? u[i] : v);
-                    y[i] += rho_vec[i] * (zr - z[i]);
-                }
-            }
-            /* OSQP's termination test (unscaled residuals) at refine_eps */
-            csc_mv(n, m, Ap0, Ai0, Ax, x, Axv);
-            sym_mv(n, Pp0, Pi0, Px, x, Pxv);
-            csc_mtv(n, Ap0, Ai0, Ax, y, Aty);
-            for (int i = 0; i < m; ++i) tm[i] = Axv[i] - z[i];
-            for (int i = 0; i < n; ++i) tn[i] = Pxv[i] + q[i] + Aty[i];
-            pri_res = vnorm_inf_scaled(Einv, tm, m);
-            dua_res = cinv * vnorm_inf_scaled(Dinv, tn, n);
-            {
-                const double nz = vnorm_inf_scaled(Einv, z, m), nAx = vnorm_inf_scaled(Einv, Axv, m);
-                const double nAty = vnorm_inf_scaled(Dinv, Aty, n), nPx = vnorm_inf_scaled(Dinv, Pxv, n), nq = vnorm_inf_scaled(Dinv, q, n);
-                double dn = nq > nAty ? nq : nAty;
-                dn = dn > nPx ? dn : nPx;
-                stop = pri_res < prm->refine_eps + prm->refine_eps * (nz > nAx ? nz : nAx) && dua_res < prm->refine_eps + prm->refine_eps * cinv * dn;
-            }
-            if (g_refine_trace) fprintf(stderr, "  refine round %d it %d nfac %d changed %d rb %.3g  r_prim %.3e r_dual %.3e%s\n", round, it2, nfac, changed, rb, pri_res, dua_res, stop ? "  CERTIFIED" : "");
-            if (stop || it2 >= cap_it) break;
-            if (prm->refine_adapt && !changed) {
-                /* refine_adapt: OSQP's rho estimate (compute_rho_estimate's balance of the relative residuals; here on the unscaled ones this test has just
-                 * evaluated) applied to the phase's own rho, after a block that kept its step vector.  With the activity set settled the iteration is dual
-                 * ascent on the active rows: a multiplier that has to grow to O(1) at refine_rho = 10 x (a violation of 1e-4) per iteration takes thousands
-                 * of iterations (primal residual stuck at 1e-4, dual at 1e-10: BASELINE config 3, path 1857 — 6 425 iterations without this, 285 with) */
-                const double nz_ = vnorm_inf_scaled(Einv, z, m), nAx_ = vnorm_inf_scaled(Einv, Axv, m);
-                const double nAty_ = vnorm_inf_scaled(Dinv, Aty, n), nPx_ = vnorm_inf_scaled(Dinv, Pxv, n);
-                const double pr = pri_res / ((nz_ > nAx_ ? nz_ : nAx_) + 1e-10), dr = dua_res / (cinv * (nAty_ > nPx_ ? nAty_ : nPx_) + 1e-10);
-                double rn = rb * sqrt(pr / (dr + 1e-10));
-                rn = rn < OSQP_RHO_MIN ? OSQP_RHO_MIN : (rn > OSQP_RHO_MAX ? OSQP_RHO_MAX : rn);
-                if (rn > prm->adapt_tol * rb || rn < rb / prm->adapt_tol) rb_next = rn;
-            }
         }
         if (g_refine_trace) fprintf(stderr, "round %d: type-based iterations so far %d, refinement %d its %d refactorisations -> %s (r_prim %.3e r_dual %.3e; entered at %.3e %.3e)\n", round, iter, it2, nfac, stop ? "certified" : "not certified", pri_res, dua_res, pri0, dua0);
         refine_its += it2;
@@ -1452,11 +1373,10 @@ resume_main:
         }
     }
     /* ---- polish (OSQP polish.c, on the scaled problem like OSQP): reduced KKT system on the active set with the regularisation
-     * +-delta, polish_refine_iter steps of iterative refinement, normal-cone projection, OSQP's acceptance rule.  polish_passes > 1
-     * (extension, not OSQP): the active set is re-derived from the polished point and the solve repeated until it reproduces itself. ---- */
+     * +-delta, polish_refine_iter steps of iterative refinement, normal-cone projection, OSQP's acceptance rule. ---- */
     if (prm->polish && info->status == PO_STATUS_SOLVED) {
         const double delta = prm->polish_delta;
-        const int passes = prm->polish_passes > 1 ? prm->polish_passes : 1;
+        const int passes = 1;
         int *act = (int *)malloc(sizeof(int) * (size_t)(m + 1)), *act_new = (int *)malloc(sizeof(int) * (size_t)(m + 1));
         int *ridx = (int *)malloc(sizeof(int) * (size_t)(m + 1));
         int *Rp = (int *)malloc(sizeof(int) * (size_t)(n + 1)), *Ri = (int *)malloc(sizeof(int) * (size_t)(anz + 1));

@@ -1,4 +1,5 @@
 """ctypes mirror of include/po_hip.h (struct layouts and enums only; no behaviour)."""
+PO_ABI_VERSION = 5  # include/po_hip.h
 import ctypes as C
 
 PO_KP, PO_KPC, PO_K = 0, 1, 2
@@ -27,8 +28,8 @@ class PoParams(C.Structure):
         ("cart_w_curv", C.c_double), ("cart_w_curv_rate", C.c_double), ("cart_w_dev", C.c_double),
         ("mu", C.c_double), ("max_curvature_rate", C.c_double), ("search_lateral_range", C.c_double),
         ("search_long_spacing", C.c_double), ("search_lat_spacing", C.c_double), ("enable_dynamic_segmentation", C.c_int), ("enable_raw_output", C.c_int), ("output_spacing", C.c_double), ("smoothing_method", C.c_int), ("optimization_method", C.c_int), ("enable_exact_position", C.c_int), ("polish", C.c_int),
-        ("polish_delta", C.c_double), ("polish_refine_iter", C.c_int), ("polish_passes", C.c_int),
-        ("refine", C.c_int), ("refine_every", C.c_int), ("refine_max_iter", C.c_int), ("refine_max_refactor", C.c_int), ("refine_rho", C.c_double), ("refine_eps", C.c_double), ("refine_rounds", C.c_int), ("probe_iters", C.c_int), ("refine_chain", C.c_int), ("refine_extra_rounds", C.c_int), ("refine_adapt", C.c_int), ("refine_speculate", C.c_int),
+        ("polish_delta", C.c_double), ("polish_refine_iter", C.c_int),
+        ("refine", C.c_int), ("refine_eps", C.c_double), ("refine_rounds", C.c_int), ("refine_chain", C.c_int), ("refine_extra_rounds", C.c_int),
         ("refine_newton_rho", C.c_double), ("refine_newton_rho_eq", C.c_double), ("refine_newton_rho_max", C.c_double), ("refine_ls_tol", C.c_double), ("refine_ls_max", C.c_int), ("refine_newton_max", C.c_int), ("refine_newton_final", C.c_int), ("refine_newton_escalate", C.c_int), ("refine_newton_rho_eq_max", C.c_double),
     ]
 

@@ -18,8 +18,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PO_LIB") or os.path.join(_HERE, "libpo_hip.so")  # PO_LIB: dev builds (make dev), A/B experiments
 _LIB = None
 
-EXPORTS = ["po_default_params", "po_problem_dims", "po_keep_control_steps", "po_create", "po_destroy", "po_set_stream", "po_debug_set", "po_debug_trace_read", "po_device_count",
-           "po_solve_batch", "po_solve_batch_device", "po_assemble_batch", "po_scaling_batch", "po_last_kernel_ms", "po_last_phase_ms", "po_solve_status", "po_debug_get", "po_strerror",
+EXPORTS = ["po_default_params", "po_problem_dims", "po_keep_control_steps", "po_create", "po_destroy", "po_set_stream", "po_debug_set", "po_device_count",
+           "po_solve_batch", "po_solve_batch_device", "po_assemble_batch", "po_scaling_batch", "po_last_kernel_ms", "po_last_phase_ms", "po_debug_get", "po_strerror",
            "po_last_hip_error", "po_version", "po_set_map", "po_postcheck_batch", "po_postcheck_batch_device", "po_bounds_batch",
            "po_bounds_batch_device", "po_map_sample", "po_smooth_dims", "po_smooth_batch", "po_smooth_batch_device",
            "po_resample_batch", "po_resample_batch_device", "po_limits_batch", "po_limits_batch_device", "po_dp_search_batch",
@@ -31,8 +31,8 @@ class PoError(RuntimeError):
     pass
 
 
-_ENV_DEBUG = {"PO_IDENTITY_ORDER": "identity_order", "PO_DEBUG_CYCLES": "debug_cycles", "PO_SPLIT": "split", "PO_SMOOTH_SEQ": "smooth_seq",
-              "PO_SMOOTH_WAVES": "smooth_waves", "PO_SMOOTH_NOPAD": "smooth_nopad", "PO_SMOOTH_DEBUG": "smooth_debug", "PO_DP_ONE_WAVE": "dp_one_wave", "PO_QUEUE_POLICY": "queue_policy"}
+_ENV_DEBUG = {"PO_IDENTITY_ORDER": "identity_order", "PO_DEBUG_CYCLES": "debug_cycles", "PO_SMOOTH_SEQ": "smooth_seq",
+              "PO_SMOOTH_WAVES": "smooth_waves", "PO_SMOOTH_NOPAD": "smooth_nopad", "PO_SMOOTH_DEBUG": "smooth_debug", "PO_DP_ONE_WAVE": "dp_one_wave"}
 
 
 def lib():
@@ -58,7 +58,6 @@ def lib():
         L.po_scaling_batch.argtypes = [C.c_void_p, C.POINTER(PoBatchIn), C.c_void_p]
         L.po_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.po_last_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
-        L.po_solve_status.argtypes = [C.c_void_p]
         L.po_debug_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_longlong)]
         _LIB = L
     return _LIB
@@ -139,25 +138,13 @@ class Engine:
             raise
 
     def debug_set(self, key: str, value: int):
-        """po_debug_set: developer A/B switches (identity_order, debug_cycles, split, smooth_seq, smooth_waves, smooth_nopad, smooth_debug, dp_one_wave)."""
+        """po_debug_set: developer A/B switches (identity_order, debug_cycles, host_threads, smooth_seq, smooth_waves, smooth_nopad, smooth_debug, dp_one_wave)."""
         _check(lib().po_debug_set(self._h, key.encode(), int(value)))
-
-    def solve_status(self):
-        """po_solve_status: 0 = the last solve's device-side work queue drained normally; PO_ERR_HIP = a waiter timed out (synchronises the handle's stream)."""
-        return int(lib().po_solve_status(self._h))
 
     def debug_get(self, key: str) -> int:
         v = C.c_longlong()
         _check(lib().po_debug_get(self._h, key.encode(), C.byref(v)))
         return int(v.value)
-
-    def debug_trace_read(self, max_records: int = 65000):
-        """po_debug_trace_read: [n, 4] int64 records of the last chained-rounds solve (after debug_set("queue_trace", 1))."""
-        out = np.zeros((max_records, 4), dtype=np.int64)
-        n = lib().po_debug_trace_read(self._h, out.ctypes.data_as(C.c_void_p), max_records)
-        if n < 0:
-            _check(n)
-        return out[:n]
 
     def close(self):
         if self._h:

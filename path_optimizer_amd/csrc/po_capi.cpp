@@ -21,12 +21,12 @@
 #include "po_smooth.hpp"
 
 extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out);
-extern "C" hipError_t po_launch_solve_round(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
 extern "C" hipError_t po_launch_finalize_status(po_info *info, int B, hipStream_t st);
 extern "C" hipError_t po_launch_polish(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
 extern "C" hipError_t po_launch_newton(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
 extern "C" hipError_t po_launch_newton_fallback(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
 extern "C" int po_polish_state_doubles(int form, int N, int C, int keep);
+extern "C" int po_has_polish_kernel(int form, int N, int C, int keep);
 extern "C" hipError_t po_launch_scale(int form, const po::DevBatch *in, const po::DevParams *P, int passes, double *sc, hipStream_t st);
 extern "C" hipError_t po_launch_assemble(int form, const po::DevBatch *in, const po::DevParams *P, double *l, double *u, double *dyn, hipStream_t st);
 extern "C" size_t po_lds_bytes(int form, int N, int C, int keep);
@@ -122,22 +122,16 @@ struct po_handle_s {
     hipEvent_t evh[4] = {nullptr, nullptr, nullptr, nullptr};  // host-pointer entry: start, H2D done, (ev0 .. ev1 = the solve), D2H done; evh[3]: solve phase mark (po_last_phase_ms)
     hipEvent_t evp[2] = {nullptr, nullptr};                    // split scheduling (refine = 2): end of the warm-start launches, end of the Newton launch
     bool timed = false, timed_host = false, timed_phases = false;
-    size_t rq_qints = 0;
-    bool rq_used = false;      // the last solve ran the chained rounds: its queues' error flags are worth a look (po_solve_status)
     double host_pack_ms = 0.0, host_unpack_ms = 0.0;
     HostBuf pin_in, pin_out;   // pinned staging of the host-pointer entry
     int host_threads = 0;      // pack / unpack threads (0: min(8, hardware threads); po_debug_set "host_threads")
-    DevBuf pol_buf;  // per-lane ADMM state handed from the solve kernels to the polish kernel (po_params.polish)
-    DevBuf ord_buf;  // po_params.probe_iters: the launch order of the second round
-    DevBuf rq_buf;   // po_params.refine_chain: the two device-side queues of a chained-rounds solve
-    DevBuf fb_buf;   // split scheduling of refine = 2: the work list of newton_fallback_kernel
+    DevBuf pol_buf;  // per-lane ADMM state handed from the solve kernels to newton_kernel / polish_kernel (po_params.refine / polish)
+    DevBuf fb_buf;   // refine = 2: the work list of newton_fallback_kernel
     HostBuf fb_host; // ... and the pinned word its count is read back into (refine_chain = 2)
     // developer switches (po_debug_set; the library reads no environment variable): identity_order (block i solves path i), debug_cycles (per-phase shader
-    // clocks of path 0 on stderr; synchronises), split (experimental stage-split mapping, only in builds made with `make SPLIT=1`), smoothing / DP-search A/B switches
-    bool env_identity = false, env_cycles = false, env_split = false, env_smooth_seq = false, env_smooth_nopad = false, env_smooth_debug = false, env_dp_one_wave = false;
-    int env_smooth_waves = 0, env_queue_policy = -1;  // queue_policy -1: automatic (fresh paths first; hand-backs first when the caller supplies an order)
-    bool env_queue_trace = false;
-    DevBuf trace_buf;
+    // clocks of path 0 on stderr; synchronises), smoothing / DP-search A/B switches
+    bool env_identity = false, env_cycles = false, env_smooth_seq = false, env_smooth_nopad = false, env_smooth_debug = false, env_dp_one_wave = false;
+    int env_smooth_waves = 0;
     DevBuf in_buf, out_buf, asm_buf, scale_buf, dbg_buf, map_buf, post_buf, coef_buf, bnd_buf, smooth_buf, smooth_io, plan_coef, plan_io, plan_arena, plan_host;
     po::DevMap map{};  // obstacle-distance layer (po_set_map); map.d == nullptr until set
     std::mutex mu;
@@ -175,9 +169,8 @@ void po_default_params(po_params *p) {
     p->mu = 0.4; p->max_curvature_rate = 0.1; p->search_lateral_range = 10.0; p->search_long_spacing = 1.5; p->search_lat_spacing = 0.6;
     p->enable_dynamic_segmentation = 1;
     p->enable_raw_output = 1; p->output_spacing = 0.3; /* planning_flags.cpp:127-129 */
-    p->polish = 0; p->polish_delta = 1e-6; p->polish_refine_iter = 3; p->polish_passes = 1;  /* OSQP defaults (polish off) */
-    p->refine = 0; p->refine_every = 10; p->refine_max_iter = 400; p->refine_max_refactor = 40; p->refine_rho = 10.0; p->refine_eps = 1e-7; p->refine_rounds = 1; p->probe_iters = 0;
-    p->refine_chain = 1; p->refine_extra_rounds = 0; p->refine_adapt = 1; p->refine_speculate = 1;
+    p->polish = 0; p->polish_delta = 1e-6; p->polish_refine_iter = 3;  /* OSQP defaults (polish off) */
+    p->refine = 0; p->refine_eps = 1e-7; p->refine_rounds = 1; p->refine_chain = 2; p->refine_extra_rounds = 0;
     p->refine_newton_rho = 100.0; p->refine_newton_rho_eq = 1e4; p->refine_newton_rho_max = 1e5; p->refine_ls_tol = 0.3; p->refine_ls_max = 30; p->refine_newton_max = 300; p->refine_newton_final = 3; p->refine_newton_escalate = 12; p->refine_newton_rho_eq_max = 1e6; /* refine = 2 */
 }
 
@@ -221,6 +214,7 @@ int po_device_count(void) {
 int po_create(int device, const po_params *params, po_handle *out) {
     if (!params || !out) return PO_ERR_INVALID;
     if (params->scaling < 0 || params->scaling > 100) return PO_ERR_INVALID;
+    if (params->refine != 0 && params->refine != 2) return PO_ERR_INVALID;  // (refine = 1 was removed with ABI 5, include/po_hip.h)
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return PO_ERR_INVALID;
@@ -246,10 +240,7 @@ int po_destroy(po_handle h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     h->pol_buf.release();
-    h->ord_buf.release();
-    h->rq_buf.release();
     h->fb_buf.release();
-    h->trace_buf.release();
     h->in_buf.release(); h->out_buf.release(); h->asm_buf.release(); h->scale_buf.release(); h->dbg_buf.release(); h->map_buf.release(); h->post_buf.release(); h->coef_buf.release(); h->bnd_buf.release(); h->smooth_buf.release(); h->smooth_io.release(); h->plan_coef.release(); h->plan_io.release(); h->plan_arena.release(); h->plan_host.release();
     h->pin_in.release(); h->pin_out.release(); h->fb_host.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -268,20 +259,11 @@ int po_debug_set(po_handle h, const char *key, int value) {
     if (k == "identity_order") h->env_identity = value != 0;
     else if (k == "host_threads") h->host_threads = value < 0 ? 0 : value;
     else if (k == "debug_cycles") h->env_cycles = value != 0;
-    else if (k == "split") {
-#ifdef PO_WITH_SPLIT
-        h->env_split = value != 0;
-#else
-        if (value != 0) return PO_ERR_UNSUPPORTED;  // built without `make SPLIT=1`
-#endif
-    }
     else if (k == "smooth_seq") h->env_smooth_seq = value != 0;
     else if (k == "smooth_waves") h->env_smooth_waves = value;
     else if (k == "smooth_nopad") h->env_smooth_nopad = value != 0;
     else if (k == "smooth_debug") h->env_smooth_debug = value != 0;
     else if (k == "dp_one_wave") h->env_dp_one_wave = value != 0;
-    else if (k == "queue_trace") h->env_queue_trace = value != 0;
-    else if (k == "queue_policy") h->env_queue_policy = value < 0 ? -1 : (value > 31 ? 31 : value);
     else return PO_ERR_INVALID;
     return PO_OK;
 }
@@ -301,19 +283,6 @@ int po_debug_get(po_handle h, const char *key, long long *value) {
         return PO_OK;
     }
     return PO_ERR_INVALID;
-}
-
-int po_debug_trace_read(po_handle h, long long *out, int max_records) {
-    if (!h || !out || max_records < 0) return PO_ERR_INVALID;
-    std::lock_guard<std::mutex> g(h->mu);
-    if (!h->trace_buf.p) return 0;
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    long long hdr[4];
-    HIP_TRY(hipMemcpy(hdr, h->trace_buf.p, sizeof(hdr), hipMemcpyDeviceToHost));
-    int n = (int)std::min<long long>(std::min<long long>(hdr[0], 65000), max_records);
-    HIP_TRY(hipMemcpy(out, static_cast<long long *>(h->trace_buf.p) + 4, sizeof(long long) * 4 * (size_t)n, hipMemcpyDeviceToHost));
-    return n;
 }
 
 int po_set_stream(po_handle h, void *hip_stream) {
@@ -343,21 +312,16 @@ static int make_dev_params(const po_handle_s *h, int form, int keep, po::DevPara
     D->max_iter = p.max_iter; D->check_every = p.check_every; D->adapt_every = p.adapt_every;
     D->end_heading = p.constraint_end_heading;
     D->polish = p.polish; D->pol_delta = p.polish_delta > 0 ? p.polish_delta : 1e-6; D->pol_refine = p.polish_refine_iter < 0 ? 0 : p.polish_refine_iter;
-    D->pol_passes = p.polish_passes;
-    D->refine = p.refine; D->ref_every = p.refine_every > 0 ? p.refine_every : 10; D->ref_max_iter = p.refine_max_iter; D->ref_max_refactor = p.refine_max_refactor;
-    D->ref_rho = p.refine_rho; D->ref_eps = p.refine_eps; D->ref_rounds = p.refine_rounds;
-    D->ref_extra = (p.refine && p.refine_extra_rounds > 0) ? p.refine_extra_rounds : 0; D->ref_adapt = p.refine_adapt; D->ref_spec = p.refine_speculate;
-    D->slice = (!p.refine && p.probe_iters > 0) ? p.probe_iters : 0;
-    // every refine_newton_* field is defaulted when it is not positive (a zero-initialised po_params must not silently disable the penalty growth) and the caps are
-    // held inside what the rest of the engine allows: with refine_newton_escalate the caps stand up to 100 x higher, so rho_max <= kRhoMax / 100 keeps the escalated
-    // inequality penalty <= kRhoMax, and rho_eq <= 1e8 / 100 keeps rho_eq (a.x - b) above its rounding at the dual tolerance (po_hip.h)
+    D->refine = p.refine; D->ref_eps = p.refine_eps; D->ref_rounds = p.refine_rounds;
+    D->ref_extra = (p.refine && p.refine_extra_rounds > 0) ? p.refine_extra_rounds : 0;
+    // every refine_newton_* field is defaulted when it is not positive (a zero-initialised po_params must not silently disable the penalty growth) and held inside what
+    // the rest of the engine allows; the ESCALATED caps (refine_newton_escalate: up to 100 x) are clamped inside the phase to kRhoMax / 1e8 (po_fast.inc, oracle alike)
     D->ref_nw_rho = p.refine_newton_rho > 0 ? std::min(p.refine_newton_rho, po::kRhoMax) : 100.0;
     D->ref_nw_rho_eq = p.refine_newton_rho_eq > 0 ? std::min(p.refine_newton_rho_eq, 1e8) : 1e4;
-    D->ref_nw_rho_max = p.refine_newton_rho_max > 0 ? std::min(p.refine_newton_rho_max, po::kRhoMax / 100.0) : 1e5;
-    D->ref_nw_rho_eq_max = p.refine_newton_rho_eq_max > 0 ? std::min(p.refine_newton_rho_eq_max, 1e6) : (p.refine_newton_rho_eq_max < 0 ? 1e6 : 0.0);  // 0: the equality penalty never grows (documented switch)
+    D->ref_nw_rho_max = p.refine_newton_rho_max > 0 ? std::min(p.refine_newton_rho_max, po::kRhoMax) : 1e5;
+    D->ref_nw_rho_eq_max = p.refine_newton_rho_eq_max > 0 ? std::min(p.refine_newton_rho_eq_max, 1e8) : (p.refine_newton_rho_eq_max < 0 ? 1e6 : 0.0);  // 0: the equality penalty never grows (documented switch)
     D->ref_ls_tol = p.refine_ls_tol > 0 ? p.refine_ls_tol : 1e-4;
     D->ref_nw_final = p.refine_newton_final; D->ref_nw_esc = p.refine_newton_escalate; D->ref_ls_max = p.refine_ls_max > 0 ? p.refine_ls_max : 30; D->ref_nw_max = p.refine_newton_max > 0 ? p.refine_newton_max : 300;
-    D->ref_split_warm = 0;
     return PO_OK;
 }
 
@@ -388,10 +352,8 @@ static void fill_dev_batch(const po_handle_s *h, po::DevBatch *D, const po_batch
         while ((1 << D->perm_bits) < in->B) ++D->perm_bits;
     D->scale = nullptr;
     D->pol_state = nullptr; D->pol_stride = 0;
-    D->use_split = 0;
     D->round = 0;
-    D->rq = nullptr; D->rq_cap = 0; D->spec_words = nullptr; D->rq_timeout = 0; D->fb_list = nullptr; D->rq_policy = h->env_queue_policy >= 0 ? h->env_queue_policy : (in->order != nullptr ? 1 : 0);  // auto: with the caller's longest-first order, hand-backs first
-    D->dbg_trace = nullptr;
+    D->fb_list = nullptr;
     D->n = n; D->m = m;
 }
 
@@ -417,75 +379,26 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     if ((rc = h->scale_buf.ensure(sizeof(double) * 64 * (size_t)in->B))) return rc;
     D.scale = static_cast<double *>(h->scale_buf.p);
     bool polish = false;
-    if (h->params.polish || h->params.refine || h->params.probe_iters > 0) {  // OSQP's polish, opt-in (the refinement and the sliced solve use the same block): the solve kernels leave their ADMM state in pol_buf, polish_kernel picks it up
+    if (h->params.polish || h->params.refine) {  // OSQP's polish (opt-in) and the Newton refinement pick the ADMM state up from pol_buf, where the solve kernels leave it
         const int sd = po_polish_state_doubles(in->formulation, in->N, C, in->keep);
-        if (sd > 0) {  // (shapes on the single-level mapping have no polish kernel: status_polish stays 0 = not attempted)
-            if ((rc = h->pol_buf.ensure(sizeof(double) * (size_t)sd * (size_t)in->B * 2))) return rc;  // (two state blocks per path: speculative continuations)
+        if (sd > 0) {  // (shapes on the single-level mapping have neither kernel: status_polish / status_refine stay 0 = not attempted)
+            if ((rc = h->pol_buf.ensure(sizeof(double) * (size_t)sd * (size_t)in->B))) return rc;
             D.pol_state = static_cast<double *>(h->pol_buf.p);
             D.pol_stride = sd;
-            polish = true;
+            polish = h->params.polish && po_has_polish_kernel(in->formulation, in->N, C, in->keep);  // (role-split shapes, keep 5 .. 8: no polish kernel)
         }
     }
-    {   // EXPERIMENTAL, off by default: the stage-split two-wave mapping of the keep-4 kernel (two waves per SIMD; DESIGN.md §9: correct, but measured 30 % slower
-        // than the one-wave mapping — seven LDS hand-offs per iteration).  po_debug_set "split" selects it (A/B runs, tests); never together with the polish (state layout).
-        D.use_split = (h->env_split && !polish) ? 1 : 0;
-    }
-    po::DevBatch DS = D;  // what the solve launches see (the polish launch keeps D: B workgroups, no queue)
     const int rounds_total = (h->params.refine_rounds > 1 ? h->params.refine_rounds : 1) + P.ref_extra;
-    // refine = 2, refine_chain = 2: "split" scheduling — plain warm-start launch, the Newton refinement as its own launch, then the (nearly always empty) per-round launches
-    const bool split = h->params.refine == 2 && (h->params.refine_chain == 2 || h->params.refine_chain == 3) && D.pol_state != nullptr && rounds_total < 32;
+    // refine = 2: plain warm-start launches, the Newton refinement as its own launch, then the (nearly always empty) fallback launch for the later rounds
+    const bool split = h->params.refine == 2 && D.pol_state != nullptr && rounds_total < 32;
     if (split && ((rc = h->fb_buf.ensure(sizeof(int) * ((size_t)in->B + 1))) || (rc = h->fb_host.ensure(64)))) return rc;
-    if (!split && h->params.refine && rounds_total > 1 && rounds_total < 32 && h->params.refine_chain && D.pol_state != nullptr && in->B < (1 << 24)) {
-        // chained rounds: hand-backs and speculative continuations, at most one of each per path and round
-        const size_t cap = 2 * (size_t)(rounds_total - 1) * (size_t)in->B, qints = 8 + cap;  // (po_fast.inc: kRqHdr)
-        h->rq_qints = qints;
-        if ((rc = h->rq_buf.ensure(sizeof(int) * (2 * qints + 3 * (size_t)in->B)))) return rc;
-        DS.rq = static_cast<int *>(h->rq_buf.p);
-        DS.rq_cap = (int)cap;
-        // time-out of a waiter: 5 s, or what the slowest legitimate producer could take — every round's iteration budget at a generous 50 us per iteration, x 4 for a shared / preempted GPU
-        const double per_round_it = (double)h->params.max_iter + (double)(h->params.refine == 2 ? 20 * h->params.refine_newton_max : h->params.refine_max_iter);
-        DS.rq_timeout = (long long)std::max(5.0e8, 4.0 * 50e-6 * 1e8 * per_round_it * (double)rounds_total);
-    }
-    if (h->env_queue_trace && DS.rq != nullptr) {  // dev: item timeline (po_debug_trace_read)
-        if ((rc = h->trace_buf.ensure(sizeof(long long) * (4 + 4 * 65000)))) return rc;
-        HIP_TRY(hipMemsetAsync(h->trace_buf.p, 0, sizeof(long long) * 4, h->stream));
-        DS.dbg_trace = static_cast<long long *>(h->trace_buf.p);
-    }
-    if (P.slice > 0 && D.pol_state != nullptr && D.order == nullptr)  // (before anything is enqueued: a failed allocation leaves no half-run batch behind)
-        if ((rc = h->ord_buf.ensure(sizeof(int) * (size_t)in->B))) return rc;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     h->timed_phases = false;
-    h->rq_used = DS.rq != nullptr;
     // per-path equilibration (h->params.scaling class-level Ruiz passes; 0 -> identity), then the fused solve
     HIP_TRY(po_launch_scale(in->formulation, &D, &P, h->params.scaling, static_cast<double *>(h->scale_buf.p), h->stream));
-    if (P.slice > 0 && D.pol_state != nullptr) {
-        // po_params.probe_iters: probe launch pair, then the unfinished paths longest-first by the dual residual they were handed back with (the caller's own
-        // order hint, when there is one, is kept for both rounds)
-        po::DevBatch rb = D;
-        rb.round = 0;
-        HIP_TRY(po_launch_solve_round(in->formulation, &rb, &P, h->stream));
-        if (D.order == nullptr) {
-            std::vector<po_info> hi((size_t)in->B);
-            HIP_TRY(hipMemcpyAsync(hi.data(), D.out_info, sizeof(po_info) * hi.size(), hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));
-            std::vector<int> ord((size_t)in->B);
-            for (int b = 0; b < in->B; ++b) ord[(size_t)b] = b;
-            std::vector<double> key((size_t)in->B);  // handed-back paths: their dual residual (>= 0; a NaN counts as 0); the others: -1, i.e. last
-            for (int b = 0; b < in->B; ++b) {
-                const po_info &o = hi[(size_t)b];
-                key[(size_t)b] = o.status == po::kStatusDeferred - 1 ? ((o.r_dual == o.r_dual && o.r_dual > 0) ? o.r_dual : 0.0) : -1.0;
-            }
-            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return key[(size_t)a] > key[(size_t)b]; });  // largest dual residual first
-            HIP_TRY(hipMemcpyAsync(h->ord_buf.p, ord.data(), sizeof(int) * ord.size(), hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));  // (ord is a local)
-            rb.order = static_cast<const int *>(h->ord_buf.p);
-        }
-        rb.round = 1;
-        HIP_TRY(po_launch_solve_round(in->formulation, &rb, &P, h->stream));
-    } else if (split) {
+    if (split) {
         po::DevParams P1 = P;  // the warm start: the plain solve kernels, stopped where round 0 of the rounds stops (10^(R-1) x eps)
         for (int r = 1; r < (h->params.refine_rounds > 1 ? h->params.refine_rounds : 1); ++r) { P1.eps_abs *= 10.0; P1.eps_rel *= 10.0; }
-        P1.ref_split_warm = 1;
         HIP_TRY(po_launch_solve(in->formulation, &D, &P1, h->stream, nullptr));
         HIP_TRY(hipEventRecord(h->evp[0], h->stream));
         D.fb_list = static_cast<int *>(h->fb_buf.p);
@@ -496,12 +409,12 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
         // The paths newton_kernel did not certify (rare) are on a device-side work list; newton_fallback_kernel takes them through the later rounds.  Its launch alone
         // costs 0.5 ms whatever its grid (1.2 KB of private segment per lane: the runtime re-provisions scratch for it; 7 % of a BASELINE config-3 solve), so
         // refine_chain = 2 reads the 4-byte count back and launches it only when there is something on the list — the call then returns when the Newton launch has
-        // finished (it blocks, like probe_iters).  refine_chain = 3: always launched, the call stays asynchronous.
+        // finished (it blocks).  refine_chain = 3: always launched, the call stays asynchronous.
         bool need_fb = true;
         // a stream that is being captured cannot be waited on (the copy below would never run and a synchronise invalidates the capture): always issue the launch then
         hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
         const bool capturing = hipStreamIsCapturing(h->stream, &cap_st) == hipSuccess && cap_st != hipStreamCaptureStatusNone;
-        if (h->params.refine_chain == 2 && !capturing) {
+        if (h->params.refine_chain != 3 && !capturing) {
             // the count lands in a pinned word the host SPINS on: a blocking hipStreamSynchronize wakes up through an interrupt — measured 0.5 ms, what the launch it
             // is meant to save costs; falls back to the blocking wait after 20 ms of spinning (a long solve: the wake-up latency no longer matters)
             volatile int *cnt = static_cast<volatile int *>(h->fb_host.p);
@@ -520,12 +433,11 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
             need_fb = *cnt != 0;
         }
         if (need_fb) HIP_TRY(po_launch_newton_fallback(in->formulation, &D, &P, h->stream));
-        // (po_launch_newton = newton_kernel + newton_fallback_kernel: the rare path the first does not certify runs its later rounds in the second)
     } else {
-        HIP_TRY(po_launch_solve(in->formulation, &DS, &P, h->stream, nullptr));
+        HIP_TRY(po_launch_solve(in->formulation, &D, &P, h->stream, nullptr));
     }
-    if (D.pol_state != nullptr && (h->params.refine || P.slice > 0)) HIP_TRY(po_launch_finalize_status(D.out_info, in->B, h->stream));
-    if (polish && h->params.polish) HIP_TRY(po_launch_polish(in->formulation, &D, &P, h->stream));
+    if (split) HIP_TRY(po_launch_finalize_status(D.out_info, in->B, h->stream));
+    if (polish) HIP_TRY(po_launch_polish(in->formulation, &D, &P, h->stream));
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     if (dbg) {
@@ -635,7 +547,6 @@ int po_solve_batch(po_handle h, const po_batch_in *in, const po_batch_out *out) 
     HIP_TRY(hipMemcpyAsync(pout, ob, out_bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipEventRecord(h->evh[2], h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if ((rc = po_solve_status(h))) return rc;
     {
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<CopySeg> us;
@@ -646,21 +557,6 @@ int po_solve_batch(po_handle h, const po_batch_in *in, const po_batch_out *out) 
         h->host_unpack_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     h->timed_host = true;
-    return PO_OK;
-}
-
-// Did the last solve on this handle run to its end?  Synchronises the stream.  PO_OK, or PO_ERR_HIP when a workgroup of a chained-rounds launch (refine_chain = 1) gave up
-// waiting for a hand-back (a protocol time-out: the affected paths are reported PO_STATUS_UNSOLVED).  The host-pointer entry checks this itself.
-int po_solve_status(po_handle h) {
-    if (!h) return PO_ERR_INVALID;
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (!h->rq_used || !h->rq_buf.p) return PO_OK;
-    int hdr[2][8];
-    const int *rq = static_cast<const int *>(h->rq_buf.p);
-    HIP_TRY(hipMemcpy(hdr[0], rq, sizeof(int) * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(hdr[1], rq + h->rq_qints, sizeof(int) * 8, hipMemcpyDeviceToHost));
-    if (hdr[0][2] != 0 || hdr[1][2] != 0) { g_hip_err = "chained refinement rounds: a workgroup timed out waiting for a hand-back (affected paths are PO_STATUS_UNSOLVED)"; return PO_ERR_HIP; }
     return PO_OK;
 }
 
@@ -1229,6 +1125,6 @@ const char *po_strerror(int code) {
     }
 }
 const char *po_last_hip_error(void) { return g_hip_err.c_str(); }
-const char *po_version(void) { return "po_hip 0.1 (gfx950)"; }
+const char *po_version(void) { return "po_hip 5 (gfx950)"; }
 
 }  // extern "C"

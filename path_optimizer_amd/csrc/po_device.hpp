@@ -34,13 +34,11 @@ struct DevParams {
     double sigma, alpha, rho0, eps_abs, eps_rel, eps_pinf, adapt_tol;
     int max_iter, check_every, adapt_every, end_heading;
     double pol_delta;           // OSQP delta
-    int polish, pol_refine, pol_passes;
-    int refine, ref_every, ref_max_iter, ref_max_refactor, ref_rounds, ref_extra, ref_adapt, ref_spec;  // po_params.refine*
-    int slice;              // po_params.probe_iters (0 with refine): iterations of the first launch pair
-    double ref_rho, ref_eps;
+    int polish, pol_refine;
+    int refine, ref_rounds, ref_extra;  // po_params.refine (0 / 2), refine_rounds, refine_extra_rounds
+    double ref_eps;
     double ref_nw_rho, ref_nw_rho_eq, ref_nw_rho_max, ref_nw_rho_eq_max, ref_ls_tol;  // po_params.refine = 2 (Newton refinement)
     int ref_ls_max, ref_nw_max, ref_nw_final, ref_nw_esc;
-    int ref_split_warm;  // launcher only: this is the warm-start launch of the split scheduling (plain kernels although refine = 2)
 };
 
 struct DevBatch {
@@ -57,17 +55,10 @@ struct DevBatch {
     int perm_bits;          // block -> path permutation: ceil(log2 B) bits of mixing (0 = blockIdx order), see solve_kernel_fast
     int only_deferred;      // set by the launcher for the second (general) launch of the two-level mapping: solve only the paths the first one deferred
     int n, m;
-    int round;              // po_params.refine_rounds: which round this launch is (0: all paths; r > 0: the paths round r - 1 handed back)
-    int use_split;          // launcher hint: take the stage-split two-wave mapping where it exists (keep 4, one-wave shapes; not with polish)
-    double *pol_state;      // polish only: [B][pol_stride] per-lane ADMM state left by the solve kernels for polish_kernel (or nullptr)
+    int round;              // po_params.refine_rounds: which round this launch is (0: all paths; r > 0: the paths round r - 1 handed back; newton_fallback_kernel)
+    double *pol_state;      // [B][pol_stride] per-lane ADMM state left by the solve kernels for newton_kernel / polish_kernel (or nullptr)
     int pol_stride;
-    long long *dbg_trace;   // dev: per-item timeline of the chained rounds (po_debug_set "queue_trace"), or nullptr
-    int rq_policy;          // chained refinement rounds: which item a workgroup prefers (rq_take)
-    int rq_cap;             // chained refinement rounds: entries of the queue; the grid holds B + rq_cap workgroups (see rq_take in po_fast.inc)
-    int *rq;                // ... and this launch's device-side queue [8 + rq_cap] (nullptr: one launch pair per round)
-    int *spec_words;        // ... and the verdict words of the speculative continuations [B][3] (po_fast.inc, spec_post)
-    int *fb_list;           // split scheduling of refine = 2: work list of the paths newton_kernel hands back (count, then path ids; newton_fallback_kernel)
-    long long rq_timeout;   // ... and how long a waiter waits for a hand-back before it flags the launch as failed (100 MHz ticks; 0: the 5 s floor)
+    int *fb_list;           // po_params.refine = 2: work list of the paths newton_kernel hands back (count, then path ids; newton_fallback_kernel)
 };
 
 template <int F> struct FormTraits;

@@ -56,87 +56,30 @@ template <int F> __global__ __launch_bounds__(64) void assemble_kernel(DevBatch 
 PO_DECL(po_launch_solve_kp); PO_DECL(po_launch_solve_kp_uni);
 PO_DECL(po_launch_solve_kpc); PO_DECL(po_launch_solve_kpc_uni);
 PO_DECL(po_launch_solve_k); PO_DECL(po_launch_solve_k_uni);
-PO_DECL(po_launch_solve_kp_uni_ref); PO_DECL(po_launch_solve_kpc_uni_ref); PO_DECL(po_launch_solve_k_uni_ref);
-PO_DECL(po_launch_solve_kp_ref); PO_DECL(po_launch_solve_kpc_ref); PO_DECL(po_launch_solve_k_ref);
-PO_DECL(po_launch_solve_kp_uni_nw); PO_DECL(po_launch_solve_kpc_uni_nw); PO_DECL(po_launch_solve_k_uni_nw);
-PO_DECL(po_launch_solve_kp_nw); PO_DECL(po_launch_solve_kpc_nw); PO_DECL(po_launch_solve_k_nw);
 #undef PO_DECL
-// the launch pair (uniform-row-class variant, general variant) of the kernels with a refinement phase: po_params.refine = 2 -> the Newton phase
-typedef hipError_t (*po_launch_fn)(const po::DevBatch *, const po::DevParams *, hipStream_t, size_t *);
-static void po_ref_pair(int form, int refine, po_launch_fn *uni, po_launch_fn *gen) {
-    const bool nw = refine == 2;
-    if (form == po::F_KP) { *uni = nw ? po_launch_solve_kp_uni_nw : po_launch_solve_kp_uni_ref; *gen = nw ? po_launch_solve_kp_nw : po_launch_solve_kp_ref; }
-    else if (form == po::F_KPC) { *uni = nw ? po_launch_solve_kpc_uni_nw : po_launch_solve_kpc_uni_ref; *gen = nw ? po_launch_solve_kpc_nw : po_launch_solve_kpc_ref; }
-    else { *uni = nw ? po_launch_solve_k_uni_nw : po_launch_solve_k_uni_ref; *gen = nw ? po_launch_solve_k_nw : po_launch_solve_k_ref; }
-}
 
-// Two launches on the same stream for the two-level mapping: the uniform-row-class variant first (solves what it can, defers the rest),
-// then the general variant (po_fast.inc, solve_kernel_fast).
-extern "C" hipError_t po_launch_solve_round(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
 namespace po {
-// the two queues of a chained-rounds solve (po_fast.inc, rq_take): tail = 0, pending = B, error = head = fresh = 0, entries = -1
-__global__ void rq_init_kernel(int *rq, int qints, int B) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 2 * qints + 3 * B) return;
-    if (i >= 2 * qints) { rq[i] = 0; return; }  // the verdict words of the speculative continuations
-    const int k = i % qints;
-    rq[i] = k == 1 ? B : (k < kRqHdr ? 0 : -1);
-}
-// After the launches of a solve that hands paths from launch to launch (refinement rounds, probe): no internal "in flight" status may reach the caller
-// (a path that a malformed caller-side order skipped, a chained follow-up block that gave up waiting): anything at or below kStatusDeferred becomes UNSOLVED.
+// After the launches of a solve that hands paths from launch to launch (the Newton refinement's rounds): no internal "in flight" status may reach the caller
+// (a path that a malformed caller-side order skipped): anything at or below kStatusDeferred becomes UNSOLVED.
 __global__ void finalize_status_kernel(po_info *info, int B) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B && info[b].status <= kStatusDeferred) { info[b].status = PO_STATUS_UNSOLVED; info[b].status_polish = 0; }
 }
 }  // namespace po
+// Two launches on the same stream for the two-level mapping: the uniform-row-class variant first (solves what it can, defers the rest),
+// then the general variant (po_fast.inc, solve_kernel_fast).
 extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out) {
     using namespace po;
     hipError_t e;
-    const bool ref = (P->refine != 0 || P->slice > 0) && in->pol_state != nullptr && !(P->refine == 2 && P->ref_split_warm);  // the kernels that carry the refinement phase / hand paths back (two-level shapes; they need the state block)
-    if (!ref) {
-        if (form == F_KP) { e = po_launch_solve_kp_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kp(in, P, st, lds_out); }
-        if (form == F_KPC) { e = po_launch_solve_kpc_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kpc(in, P, st, lds_out); }
-        e = po_launch_solve_k_uni(in, P, st, lds_out);
-        return e != hipSuccess ? e : po_launch_solve_k(in, P, st, lds_out);
-    }
-    // po_params.refine_rounds: one pair of launches per round; a later round finds only the paths the round before handed back (the others leave after one
-    // 4-byte read).  po_params.probe_iters: two rounds (the engine launches them one by one, po_launch_solve_round, to order the second).
-    const int rounds = P->refine ? (P->ref_rounds > 1 ? P->ref_rounds : 1) + P->ref_extra : 2;  // (with the rounds below eps, po_params.refine_extra_rounds)
-    DevBatch rb = *in;
-    if (P->refine && rounds > 1 && in->rq != nullptr) {
-        // chained rounds (po_params.refine_chain): ONE launch pair, rounds * B workgroups each; in->rq = the two queues ([0]: uniform-variant launch, [1]: general
-        // one) followed by the verdict words, in->rq_cap = entries per queue.  See rq_take in po_fast.inc.
-        const int qints = kRqHdr + in->rq_cap;
-        hipLaunchKernelGGL(rq_init_kernel, dim3((2 * qints + 3 * in->B + 255) / 256), dim3(256), 0, st, in->rq, qints, in->B);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        rb.round = 0; rb.spec_words = in->rq + 2 * qints;
-        po_launch_fn uni, gen;
-        po_ref_pair(form, P->refine, &uni, &gen);
-        e = uni(&rb, P, st, nullptr); rb.rq = in->rq + qints; if (e == hipSuccess) e = gen(&rb, P, st, nullptr);
-        return e;
-    }
-    rb.rq = nullptr;
-    for (int r = 0; r < rounds; ++r) {
-        rb.round = r;
-        e = po_launch_solve_round(form, &rb, P, st);
-        if (e != hipSuccess) return e;
-    }
-    return hipSuccess;
+    if (form == F_KP) { e = po_launch_solve_kp_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kp(in, P, st, lds_out); }
+    if (form == F_KPC) { e = po_launch_solve_kpc_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kpc(in, P, st, lds_out); }
+    e = po_launch_solve_k_uni(in, P, st, lds_out);
+    return e != hipSuccess ? e : po_launch_solve_k(in, P, st, lds_out);
 }
-// no internal "in flight" status reaches the caller (po_fast.inc, finalize_status_kernel)
+// no internal "in flight" status reaches the caller (finalize_status_kernel)
 extern "C" hipError_t po_launch_finalize_status(po_info *info, int B, hipStream_t st) {
     hipLaunchKernelGGL(po::finalize_status_kernel, dim3((B + 255) / 256), dim3(256), 0, st, info, B);
     return hipGetLastError();
-}
-// one round (in->round) of the kernels that hand paths back: the uniform-row-class launch, then the general one
-extern "C" hipError_t po_launch_solve_round(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st) {
-    using namespace po;
-    hipError_t e;
-    po_launch_fn uni, gen;
-    po_ref_pair(form, P->refine, &uni, &gen);
-    e = uni(in, P, st, nullptr); if (e == hipSuccess) e = gen(in, P, st, nullptr);
-    return e;
 }
 
 #define PO_DECLP(name) extern "C" hipError_t name(const po::DevBatch *in, const po::DevParams *P, hipStream_t st)
@@ -146,7 +89,7 @@ PO_DECLP(po_launch_polish_kp); PO_DECLP(po_launch_polish_kpc); PO_DECLP(po_launc
 PO_DECLP(po_launch_newton_kp); PO_DECLP(po_launch_newton_kpc); PO_DECLP(po_launch_newton_k);
 PO_DECLP(po_launch_newton_kp_fb); PO_DECLP(po_launch_newton_kpc_fb); PO_DECLP(po_launch_newton_k_fb);
 #undef PO_DECLP
-// the Newton refinement of round 0 as its own launch (po_params.refine = 2, refine_chain = 2 / 3), and the fallback launch for what it hands back
+// the Newton refinement of round 0 as its own launch (po_params.refine = 2), and the fallback launch for what it hands back
 extern "C" hipError_t po_launch_newton(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st) {
     using namespace po;
     return form == F_KP ? po_launch_newton_kp(in, P, st) : (form == F_KPC ? po_launch_newton_kpc(in, P, st) : po_launch_newton_k(in, P, st));
@@ -166,6 +109,14 @@ extern "C" hipError_t po_launch_polish(int form, const po::DevBatch *in, const p
 extern "C" int po_polish_state_doubles(int form, int N, int C, int keep) {
     using namespace po;
     return form == F_KP ? po_polish_state_doubles_kp(N, C, keep) : (form == F_KPC ? po_polish_state_doubles_kpc(N, C, keep) : po_polish_state_doubles_k(N, form == F_K ? 0 : C, keep));
+}
+extern "C" int po_has_polish_kernel_kp(int N, int C, int keep);
+extern "C" int po_has_polish_kernel_kpc(int N, int C, int keep);
+extern "C" int po_has_polish_kernel_k(int N, int C, int keep);
+// does the shape of this batch have a polish kernel?  (the role-split shapes of keep 5 .. 8 and the single-level mapping do not)
+extern "C" int po_has_polish_kernel(int form, int N, int C, int keep) {
+    using namespace po;
+    return form == F_KP ? po_has_polish_kernel_kp(N, C, keep) : (form == F_KPC ? po_has_polish_kernel_kpc(N, C, keep) : po_has_polish_kernel_k(N, form == F_K ? 0 : C, keep));
 }
 
 extern "C" hipError_t po_launch_scale(int form, const po::DevBatch *in, const po::DevParams *P, int passes, double *sc, hipStream_t st) {

@@ -100,33 +100,40 @@ template <class K> hipError_t launch_grid(K kern, const DevBatch *in, const DevP
 template <class K> hipError_t launch1(K kern, const DevBatch *in, const DevParams *P, int nt, size_t lds, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(in->rq != nullptr ? in->B + in->rq_cap : in->B), dim3(nt), lds, st, *in, *P);
+    hipLaunchKernelGGL(kern, dim3(in->B), dim3(nt), lds, st, *in, *P);
     return hipGetLastError();
 }
 // thread-block shape: NT threads x SPL stages per thread must cover N, and NT >= C (one control per thread).
-// Two-level mode needs chunk == control group (SPL == keep), or no held controls at all (K).
-struct Shape { int nt, spl; bool two; };
+// Two-level mode needs chunk == control group, or no held controls at all (K): one lane per chunk (SPL == keep, keep <= 5), or — round 5, keep 6 .. 8 — the
+// ROLE-SPLIT mapping: two lanes per chunk, SPL = ceil(keep / 2) stages each (nwx = 2; 3 when keep is odd), NT = 64 for up to 32 chunks, 128 for up to 64.
+struct Shape { int nt, spl; bool two; int nwx; };
 inline bool pick_shape(int form, int N, int C, int keep, Shape *s) {
     const bool no_u = (form == F_K);
     if (no_u) C = 0;  // K has no held controls: its N-1 steering variables live inside the nodes
-    // two-level path: one chunk of `spl` stages per thread; with held controls the chunk IS the control group (spl == keep).
-    // keep 1..8 covers what the reference produces (spacing 0.15..1.0 m, path_optimizer.cpp:171-172); KPC is keep == 4 only.
+    // two-level path; keep 1..8 covers what the reference produces (spacing 0.15..1.0 m, path_optimizer.cpp:171-172); KPC is keep == 4 only.
     const int keep_max = form == F_KP ? 8 : 4;
     if (no_u || (keep >= 1 && keep <= keep_max)) {
-        const int spl = no_u ? (N <= 128 ? 2 : 4) : keep;
-        for (int nt : {64, 128, 256}) {
-            if (nt == 256 && spl != 1) break;
-            if (nt == 128 && spl > 4) break;
-            if (N <= nt * spl && C <= nt) { *s = {nt, spl, true}; return true; }
+        if (!no_u && keep >= 6) {
+            const int spl = (keep + 1) / 2, chunks = (N + keep - 1) / keep;
+            if (chunks <= 32) { *s = {64, spl, true, 2 + (keep & 1)}; return true; }
+            if (chunks <= 64) { *s = {128, spl, true, 2 + (keep & 1)}; return true; }
+        } else {
+            // (keep 5 stays on one lane per chunk: measured at N = 200, where the role-split form needs two waves, 616 k against 487 k paths/s at the headline setting)
+            const int spl = no_u ? (N <= 128 ? 2 : 4) : keep;
+            for (int nt : {64, 128, 256}) {
+                if (nt == 256 && spl != 1) break;
+                if (nt == 128 && spl > 4) break;
+                if (N <= nt * spl && C <= nt) { *s = {nt, spl, true, 1}; return true; }
+            }
         }
     }
     const int cand[5][2] = {{64, 2}, {64, 4}, {128, 4}, {256, 2}, {256, 4}};
     for (auto &c : cand)
-        if (N <= c[0] * c[1] && C <= c[0]) { *s = {c[0], c[1], false}; return true; }
+        if (N <= c[0] * c[1] && C <= c[0]) { *s = {c[0], c[1], false, 1}; return true; }
     return false;
 }
 inline size_t lds_of(int form, int N, int C, const Shape &s) {
-    return form == F_KP ? lds_bytes_fast<F_KP>(N, C, s.spl, s.two, s.nt) : (form == F_KPC ? lds_bytes_fast<F_KPC>(N, C, s.spl, s.two, s.nt) : lds_bytes_fast<F_K>(N, C, s.spl, s.two, s.nt));
+    return form == F_KP ? lds_bytes_fast<F_KP>(N, C, s.spl, s.two, s.nt, s.nwx) : (form == F_KPC ? lds_bytes_fast<F_KPC>(N, C, s.spl, s.two, s.nt, s.nwx) : lds_bytes_fast<F_K>(N, C, s.spl, s.two, s.nt, s.nwx));
 }
 // pick_shape, then fall back to the single-level path when the two-level tables of a long, finely chunked path
 // (prefix products: 9 * chunks * log2(chunks) doubles) exceed the 160 KB of LDS
@@ -137,120 +144,98 @@ inline bool resolve_shape(int form, int N, int C, int keep, Shape *s) {
 }
 // UNI = true: the uniform-row-class variant of the two-level kernels (no-op for shapes that use the single-level mapping and for K on multi-wave blocks); UNI = false: the general variant.  po_launch_solve issues them in this order on one stream.
 template <int F> inline bool has_uni_variant(const Shape &s) { return s.two && (F != F_K || s.nt == 64); }  // K: one-wave blocks only (Fast::classify)
-// REF: kernels that carry the refinement phase (po_params.refine) around the loop — every variant exists with and without (the phase costs the hot loop
-// a few % even when it is not taken); those with are launched only when po_params.refine is set.
-template <int F, bool UNI, int REF> hipError_t launch_form(const DevBatch *in_, const DevParams *P, hipStream_t st, size_t *lds_out) {
+// the shapes of the two-level mapping that are instantiated: X(SPL, NT, NWX)
+#ifdef PO_DEV_HEADLINE  // dev builds: only the BASELINE config-3 variant (seconds to compile); -DPO_DEV_SPL=k -DPO_DEV_NWX=x: that one-wave variant instead
+#ifndef PO_DEV_SPL
+#define PO_DEV_SPL 4
+#endif
+#ifndef PO_DEV_NWX
+#define PO_DEV_NWX 1
+#endif
+#define PO_TWO_SHAPES(X) if (s.spl == PO_DEV_SPL && s.nt == 64 && s.nwx == PO_DEV_NWX) X(PO_DEV_SPL, 64, PO_DEV_NWX);
+#else
+#define PO_TWO_SHAPES(X)                                                                                                            \
+    if constexpr (F == F_KP) {                                                                                                      \
+        if (s.nwx == 1 && s.spl == 1 && s.nt == 64) X(1, 64, 1); if (s.nwx == 1 && s.spl == 1 && s.nt == 128) X(1, 128, 1); if (s.nwx == 1 && s.spl == 1) X(1, 256, 1); \
+        if (s.nwx == 1 && s.spl == 5) X(5, 64, 1);                                                                                  \
+        if (s.nwx == 2 && s.spl == 3 && s.nt == 64) X(3, 64, 2); if (s.nwx == 2 && s.spl == 3) X(3, 128, 2);                        \
+        if (s.nwx == 2 && s.spl == 4 && s.nt == 64) X(4, 64, 2); if (s.nwx == 2 && s.spl == 4) X(4, 128, 2);                        \
+        if (s.nwx == 3 && s.spl == 4 && s.nt == 64) X(4, 64, 3); if (s.nwx == 3 && s.spl == 4) X(4, 128, 3);                        \
+    }                                                                                                                               \
+    if (s.nwx == 1) {                                                                                                               \
+        if (s.spl == 2 && s.nt == 64) X(2, 64, 1); if (s.spl == 2) X(2, 128, 1);                                                    \
+        if (s.spl == 3 && s.nt == 64) X(3, 64, 1); if (s.spl == 3) X(3, 128, 1);                                                    \
+        if (s.spl == 4 && s.nt == 64) X(4, 64, 1); if (s.spl == 4) X(4, 128, 1);                                                    \
+    }
+#endif
+template <int F, bool UNI> hipError_t launch_form(const DevBatch *in_, const DevParams *P, hipStream_t st, size_t *lds_out) {
     Shape s;
     if (!resolve_shape(F, in_->N, in_->C, in_->keep, &s)) return hipErrorInvalidValue;
-    const size_t lds = lds_bytes_fast<F>(in_->N, in_->C, s.spl, s.two, s.nt);
+    const size_t lds = lds_of(F, in_->N, in_->C, s);
     if (lds_out) *lds_out = lds;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     DevBatch copy = *in_;
     copy.only_deferred = (!UNI && has_uni_variant<F>(s)) ? 1 : 0;
     const DevBatch *in = &copy;
-#define PO_L(SPL_, NT_, TWO_) return launch1(&solve_kernel_fast<F, SPL_, NT_, TWO_, UNI && TWO_, REF>, in, P, NT_, lds, st)
     if constexpr (UNI) {
         if (!has_uni_variant<F>(s)) return hipSuccess;
     }
-#ifdef PO_WITH_SPLIT
-    if constexpr (UNI && F != F_K) {
-        // keep == 4 on one-wave blocks (BASELINE configs 1-3): the stage-split two-wave mapping (Fast<..., NW = 2>): 2 stages per lane, <= 256 registers, two waves per SIMD
-        if (in->use_split && s.two && s.spl == 4 && s.nt == 64 && in->keep == 4) {
-            const size_t lds2 = lds_bytes_fast<F>(in->N, in->C, 2, true, 128, 2);
-            if (lds_out) *lds_out = lds2;
-            if (lds2 <= 160 * 1024) return launch1(&solve_kernel_split<F>, in, P, 128, lds2, st);
-        }
-    }
-#endif
-#ifdef PO_DEV_HEADLINE  // dev builds: only the BASELINE config-3 variant (seconds to compile); -DPO_DEV_SPL=k: the one-wave variant of keep k instead
-#ifndef PO_DEV_SPL
-#define PO_DEV_SPL 4
-#endif
-    if (s.two && s.spl == PO_DEV_SPL && s.nt == 64) PO_L(PO_DEV_SPL, 64, true);
-    return hipErrorInvalidValue;
-#else
     if (s.two) {
-        if constexpr (F == F_KP) {
-            if (s.spl == 1 && s.nt == 64) PO_L(1, 64, true);
-            if (s.spl == 1 && s.nt == 128) PO_L(1, 128, true);
-            if (s.spl == 1) PO_L(1, 256, true);
-            if (s.spl == 5) PO_L(5, 64, true);
-            if (s.spl == 6) PO_L(6, 64, true);
-            if (s.spl == 7) PO_L(7, 64, true);
-            if (s.spl == 8) PO_L(8, 64, true);
-        }
-        if (s.spl == 2 && s.nt == 64) PO_L(2, 64, true);
-        if (s.spl == 2) PO_L(2, 128, true);
-        if (s.spl == 3 && s.nt == 64) PO_L(3, 64, true);
-        if (s.spl == 3) PO_L(3, 128, true);
-        if (s.nt == 64) PO_L(4, 64, true);
-        PO_L(4, 128, true);
-    }
-    if constexpr (!UNI) {
-        if (s.nt == 64 && s.spl == 2) PO_L(2, 64, false);
-        if (s.nt == 64) PO_L(4, 64, false);
-        if (s.nt == 128) PO_L(4, 128, false);
-        if (s.spl == 2) PO_L(2, 256, false);
-        PO_L(4, 256, false);
-    }
-    return hipErrorInvalidValue;
-#endif
+#define PO_L(SPL_, NT_, NWX_) return launch1(&solve_kernel_fast<F, SPL_, NT_, true, UNI, NWX_>, in, P, NT_, lds, st)
+        PO_TWO_SHAPES(PO_L)
 #undef PO_L
+        return hipErrorInvalidValue;
+    }
+#ifndef PO_DEV_HEADLINE
+    if constexpr (!UNI) {
+#define PO_L1(SPL_, NT_) return launch1(&solve_kernel_fast<F, SPL_, NT_, false, false, 1>, in, P, NT_, lds, st)
+        if (s.nt == 64 && s.spl == 2) PO_L1(2, 64);
+        if (s.nt == 64) PO_L1(4, 64);
+        if (s.nt == 128) PO_L1(4, 128);
+        if (s.spl == 2) PO_L1(2, 256);
+        PO_L1(4, 256);
+#undef PO_L1
+    }
+#endif
+    return hipErrorInvalidValue;
 }
-// ---- polish (po_params.polish): same shape as the solve launch; two-level shapes only (every case the reference produces) ----
-template <int F, int SPL_, int NT_> inline int state_doubles_of() { return Fast<F, SPL_, NT_, true>::kStateDoubles * NT_; }
-#define PO_POLISH_SHAPES(X)                                                                          \
-    if constexpr (F == F_KP) {                                                                       \
-        if (s.spl == 1 && s.nt == 64) X(1, 64); if (s.spl == 1 && s.nt == 128) X(1, 128); if (s.spl == 1) X(1, 256); \
-        if (s.spl == 5) X(5, 64); if (s.spl == 6) X(6, 64); if (s.spl == 7) X(7, 64); if (s.spl == 8) X(8, 64);       \
-    }                                                                                                \
-    if (s.spl == 2 && s.nt == 64) X(2, 64); if (s.spl == 2) X(2, 128);                               \
-    if (s.spl == 3 && s.nt == 64) X(3, 64); if (s.spl == 3) X(3, 128);                               \
-    if (s.nt == 64) X(4, 64); X(4, 128);
-// doubles per path of the state block the solve kernels leave for the polish (0: shape without a polish kernel)
+// ---- state block / polish (po_params.polish): same shape as the solve launch; two-level shapes only (every case the reference produces) ----
+template <int F, int SPL_, int NT_, int NWX_> inline int state_doubles_of() { return Fast<F, SPL_, NT_, true, NWX_>::kStateDoubles * NT_; }
+// doubles per path of the state block the solve kernels leave for the Newton refinement and the polish (0: shape without either: the single-level mapping)
 template <int F> inline int polish_state_doubles(int N, int C, int keep) {
     Shape s;
     if (!resolve_shape(F, N, C, keep, &s) || !s.two) return 0;
-#ifdef PO_DEV_HEADLINE
-    return (s.spl == 4 && s.nt == 64) ? state_doubles_of<F, 4, 64>() : 0;
-#else
-#define PO_X(SPL_, NT_) return state_doubles_of<F, SPL_, NT_>()
-    PO_POLISH_SHAPES(PO_X)
+#define PO_X(SPL_, NT_, NWX_) return state_doubles_of<F, SPL_, NT_, NWX_>()
+    PO_TWO_SHAPES(PO_X)
 #undef PO_X
     return 0;
-#endif
 }
-// the Newton refinement of round 0 as its own launch (po_params.refine = 2, refine_chain = 2 / 3): same shapes as the polish.  FB: the fallback launch behind it
+// the Newton refinement of round 0 as its own launch (po_params.refine = 2): same shapes.  FB: the fallback launch behind it
 // (newton_fallback_kernel walks the work list of the paths newton_kernel handed back; a small fixed grid)
 template <int F, bool FB> hipError_t launch_newton(const DevBatch *in, const DevParams *P, hipStream_t st) {
     Shape s;
     if (!resolve_shape(F, in->N, in->C, in->keep, &s) || !s.two) return hipErrorInvalidValue;
-    const size_t lds = lds_bytes_fast<F>(in->N, in->C, s.spl, s.two, s.nt);
+    const size_t lds = lds_of(F, in->N, in->C, s);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-#define PO_X(SPL_, NT_) { if constexpr (FB) return launch_grid(&newton_fallback_kernel<F, SPL_, NT_>, in, P, kFallbackGrid, NT_, lds, st); else return launch1(&newton_kernel<F, SPL_, NT_>, in, P, NT_, lds, st); }
-#ifdef PO_DEV_HEADLINE
-    if (s.spl == 4 && s.nt == 64) PO_X(4, 64)
-    return hipErrorInvalidValue;
-#else
-    PO_POLISH_SHAPES(PO_X)
-    return hipErrorInvalidValue;
-#endif
+#define PO_X(SPL_, NT_, NWX_) { if constexpr (FB) return launch_grid(&newton_fallback_kernel<F, SPL_, NT_, NWX_>, in, P, kFallbackGrid, NT_, lds, st); else return launch1(&newton_kernel<F, SPL_, NT_, NWX_>, in, P, NT_, lds, st); }
+    PO_TWO_SHAPES(PO_X)
 #undef PO_X
+    return hipErrorInvalidValue;
+}
+// OSQP's polish: one-lane-per-chunk shapes (the role-split shapes of keep 5 .. 8 have no polish kernel: status_polish stays 0 = not attempted, like the single-level mapping)
+template <int F> inline bool has_polish_kernel(int N, int C, int keep) {
+    Shape s;
+    return resolve_shape(F, N, C, keep, &s) && s.two && s.nwx == 1;
 }
 template <int F> hipError_t launch_polish(const DevBatch *in, const DevParams *P, hipStream_t st) {
     Shape s;
     if (!resolve_shape(F, in->N, in->C, in->keep, &s) || !s.two) return hipErrorInvalidValue;
-    const size_t lds = lds_bytes_fast<F>(in->N, in->C, s.spl, s.two, s.nt);
+    if (s.nwx != 1) return hipSuccess;
+    const size_t lds = lds_of(F, in->N, in->C, s);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-#ifdef PO_DEV_HEADLINE
-    if (s.spl == 4 && s.nt == 64) return launch1(&polish_kernel<F, 4, 64>, in, P, 64, lds, st);
-    return hipErrorInvalidValue;
-#else
-#define PO_X(SPL_, NT_) return launch1(&polish_kernel<F, SPL_, NT_>, in, P, NT_, lds, st)
-    PO_POLISH_SHAPES(PO_X)
+#define PO_X(SPL_, NT_, NWX_) { if constexpr (NWX_ == 1) return launch1(&polish_kernel<F, SPL_, NT_>, in, P, NT_, lds, st); }
+    PO_TWO_SHAPES(PO_X)
 #undef PO_X
     return hipErrorInvalidValue;
-#endif
 }
 }  // namespace po
-

@@ -4,7 +4,7 @@ Yardstick: tests/golden/tight_full_<set>.npz — the exact optimum of EVERY path
 round 4), the K formulation (4096) and of 1024 paths of the keep-3 / N = 231 shape the reference's own pipeline hands the QP (generator make_tight_full.py: oracle
 ADMM to 1e-6, then a primal-dual active-set solve on the full KKT system, KKT residuals <= 3e-14; 4e-7 absolute on KPC).  Setting under test: the one bench.py
 reports as `value` (bench.HEADLINE) — since round 4 the Newton refinement (po_params.refine = 2) entered after the first termination check, refine_eps 1e-8 plus the final Newton correction steps (refine_newton_final), the
-same setting on every shape; the round-3 headline (activity-weighted ADMM continuation, refine = 1) is kept beside it on configs 3 and 2.
+same setting on every shape (the round-3 headline, the activity-weighted ADMM continuation refine = 1, was removed in round 5).
 
 CPU: the oracle's implementation on a sample of every set.  GPU: the device on every path of every set — 0 paths beyond 1e-4 m, every path certified
 (po_info.status_refine == 1), and the OSQP-faithful default measured beside it (it leaves more than half of the paths beyond the bar, which is why it is not `value`)."""
@@ -21,7 +21,6 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 from make_tight_full import SETS, batch_of, e_y_of  # noqa: E402
 
 HEADLINE = dict(refine=2, refine_rounds=5, refine_extra_rounds=2, refine_eps=1e-8, refine_chain=2)
-HEADLINE_R3 = dict(refine=1, refine_rounds=3, refine_extra_rounds=2)  # round 3
 
 
 def _gold(name):
@@ -86,33 +85,19 @@ def test_device_headline_setting_puts_every_path_of_the_batch_within_the_bar(nam
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["c3", "c2"])
-def test_device_round3_headline_setting_still_holds_on_configs_3_and_2(name):
-    from path_optimizer_amd import binding
-
-    b = batch_of(name)
-    p = binding.default_params()
-    for k, v in HEADLINE_R3.items():
-        setattr(p, k, v)
-    st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
-    r = _rms(b, xs, _gold(name))
-    assert (info["status"] == 1).all() and int((r > 1e-4).sum()) == 0 and (info["status_refine"] == 1).all()
-
-
-@pytest.mark.gpu
 def test_device_certified_flag_is_what_a_caller_can_rely_on():
     """Whatever the setting, a path flagged status_refine == 1 is within the bar; what is beyond it is flagged -1 (or 0 without the refinement).  Settings that leave
-    paths uncertified on config 3: one round without the rounds below eps, and a refinement starved of iterations."""
+    paths uncertified on config 3: Newton attempts starved of steps, with and without rounds below eps."""
     from path_optimizer_amd import binding
 
     b = batch_of("c3", 1024)
     gold = _gold("c3")
-    for kw in (dict(refine=1), dict(refine=1, refine_rounds=3), dict(refine=1, refine_rounds=3, refine_max_iter=40), dict(refine=1, refine_rounds=3, refine_extra_rounds=1)):
+    for kw in (dict(HEADLINE), dict(HEADLINE, refine_rounds=1, refine_extra_rounds=0), dict(HEADLINE, refine_rounds=2, refine_extra_rounds=0, refine_newton_max=6), dict(HEADLINE, refine_chain=3, refine_rounds=2, refine_extra_rounds=1, refine_newton_max=5)):
         p = binding.default_params()
         for k, v in kw.items():
             setattr(p, k, v)
         st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
         r = _rms(b, xs, gold)
         cert = info["status_refine"] == 1
-        assert cert.mean() > 0.9 and r[cert].max() < 1e-4, (kw, r[cert].max())
+        assert cert.mean() > 0.25 and r[cert].max() < 1e-4, (kw, cert.mean(), r[cert].max())
         assert (info["status_refine"][r > 1e-4] == -1).all(), kw

@@ -76,35 +76,6 @@ def test_random_case_matches_oracle(oracle, seed):
     _compare_every_path(info, oinfo, xs, oxs, st, ost, 0.6, eps=1e-4, check_every=ce)
 
 
-@pytest.mark.parametrize("seed", range(24))
-def test_random_case_refinement_matches_oracle(oracle, seed):
-    """The same random cases through the refinement (po_params.refine, rounds 1 or 3): device and oracle take the same decisions (activity sets, refactorisations,
-    hand-backs) except where one is decided by the last bits — then the counts differ by whole blocks of 10 and the points agree at the termination tolerance."""
-    from path_optimizer_amd import binding
-
-    rng, form, b = _case(seed)
-    if form == T.PO_KP:
-        b.keep = binding.keep_control_steps(form, b.ref_s[0])
-    st0 = rng.bit_generator.state
-    p = _params(rng, binding.default_params)
-    rng.bit_generator.state = st0
-    po = oracle.device_equivalent_params(_params(rng, binding.default_params))
-    rounds = int(rng.choice([1, 1, 3]))
-    for q in (p, po):
-        q.refine, q.refine_rounds = 1, rounds
-    st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
-    ost, oinfo, oxs = oracle.solve_batch(b, po)
-    assert np.array_equal(info["status"], oinfo["status"]), (seed, info["status"], oinfo["status"])
-    ok = info["status"] == 1
-    same = ok & (info["iters"] == oinfo["iters"])  # (refactorisation counts may differ where a row sits on its bound with a multiplier at noise level)
-    assert same.sum() >= 0.98 * ok.sum() - 1, (seed, form, b.N, b.keep, info["iters"], oinfo["iters"])
-    if same.any():
-        assert np.abs(xs - oxs)[same].max() < 1e-5, (seed, np.abs(xs - oxs)[same].max())
-    conv = ok & (info["r_prim"] < 2e-6) & (info["r_dual"] < 2e-6) & (oinfo["r_prim"] < 2e-6) & (oinfo["r_dual"] < 2e-6)
-    if conv.any():
-        assert np.abs(st - ost)[conv][..., :3].max() < 1e-3, (seed, np.abs(st - ost)[conv][..., :3].max())
-
-
 HEADLINE = dict(refine=2, refine_rounds=5, refine_extra_rounds=2, refine_eps=1e-8)
 
 

@@ -490,45 +490,3 @@ def test_order_hint_changes_scheduling_only(binding):
     st2, info2, x2 = binding.Engine(0, p).solve_batch(b, want_x=True, order=order[::-1].copy())
     st3, info3, x3 = binding.Engine(0, p).solve_batch(b, want_x=True)
     assert np.array_equal(x2, x3) and np.array_equal(info2["status_polish"], info3["status_polish"])
-
-
-def test_stage_split_two_wave_mapping_matches_oracle(binding):
-    """The experimental stage-split mapping of the keep-4 kernel (`make SPLIT=1` builds only; po_debug_set "split" / PO_SPLIT=1 through the binding: chunk stages 0-1 on wave A, 2-3 + the control on wave B, two waves per SIMD;
-    csrc/po_fast.inc Fast<..., NW = 2>) computes the same iteration: same counts as the oracle, same solution, for path lengths on every residue of the chunk
-    structure (N - 1 = 1 mod 4 is handed to the one-wave general kernel), one and several DPP rows of chunks, and fewer chunks than a hand-off slot has words."""
-    import os
-    import subprocess
-    import sys
-
-    probe = binding.Engine(0)
-    try:
-        probe.debug_set("split", 1)
-    except binding.PoError:
-        pytest.skip("libpo_hip.so was built without `make SPLIT=1` (the experimental mapping is not part of the default build)")
-    finally:
-        probe.close()
-    code = r"""
-import sys, numpy as np
-sys.path.insert(0, '.')
-from oracle import oracle_py
-from path_optimizer_amd import binding, synth
-for cfg, N, B in ((3, 200, 24), (3, 41, 6), (3, 42, 6), (3, 43, 6), (3, 44, 6), (2, 120, 8), (3, 68, 6), (3, 256, 4)):
-    b = synth.make_batch(cfg, B=B, N=N)
-    st, info, xs = binding.Engine(0).solve_batch(b, want_x=True)
-    ost, oinfo, oxs = oracle_py.solve_batch(b, oracle_py.device_equivalent_params())
-    assert np.array_equal(info["status"], oinfo["status"]) and (info["status"] == 1).all(), (N, info["status"])
-    same = info["iters"] == oinfo["iters"]
-    assert same.mean() >= 0.8 and np.abs(xs - oxs)[same].max() < 1e-6 and np.abs(st - ost)[same].max() < 1e-6, (N, info["iters"], oinfo["iters"])
-    if (~same).any():
-        assert np.abs(xs - oxs)[~same].max() < 1e-3
-p = binding.default_params(); p.max_iter, p.check_every, p.adapt_every = 120, 0, 50
-po = oracle_py.device_equivalent_params(p)
-b = synth.make_batch(3, B=8)
-st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
-ost, oinfo, oxs = oracle_py.solve_batch(b, po)
-assert np.array_equal(info["n_refactor"], oinfo["n_refactor"]) and np.abs(xs - oxs).max() < 1e-8, np.abs(xs - oxs).max()
-print("SPLIT_OK")
-"""
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PO_SPLIT="1"), cwd=root, capture_output=True, text=True, timeout=600)
-    assert "SPLIT_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

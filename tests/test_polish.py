@@ -24,9 +24,9 @@ def test_oracle_polish_reaches_the_exact_optimum(oracle):
     _, i0, x0 = oracle.solve_batch(b, base)
     r0 = _rms(x0, gold, b.N)
     res = {}
-    for passes in (1, 6):
+    for passes in (1,):
         p = oracle.device_equivalent_params()
-        p.polish, p.polish_passes = 1, passes
+        p.polish = 1
         _, info, xs = oracle.solve_batch(b, p)
         assert np.array_equal(info["iters"], i0["iters"]) and (info["status"] == 1).all()
         ok = info["status_polish"] == 1
@@ -37,20 +37,20 @@ def test_oracle_polish_reaches_the_exact_optimum(oracle):
         assert (info["r_prim"][ok] < i0["r_prim"][ok]).all() and (info["r_dual"][ok] <= i0["r_dual"][ok]).all()
         res[passes] = (ok.mean(), (r <= 1e-4).mean(), np.median(r[ok]))
     assert (r0 <= 1e-4).mean() < 0.6           # ADMM at eps 1e-4 alone: about half of the paths within 1e-4 m of the optimum
-    assert res[1][1] >= 0.8 and res[6][1] >= res[1][1] and res[6][1] >= 0.88
-    assert res[1][2] < 1e-9 and res[6][2] < 1e-9  # where the active set was identified the polished point IS the optimum
+    assert res[1][1] >= 0.8
+    assert res[1][2] < 1e-9  # where the active set was identified the polished point IS the optimum
 
 
 def test_oracle_polish_off_is_the_default(oracle):
     p = oracle.default_params()
-    assert p.polish == 0 and p.polish_delta == 1e-6 and p.polish_refine_iter == 3 and p.polish_passes == 1  # OSQP defaults
+    assert p.polish == 0 and p.polish_delta == 1e-6 and p.polish_refine_iter == 3  # OSQP defaults
     b = synth.make_batch(2, B=2)
     _, info, _ = oracle.solve_batch(b, oracle.device_equivalent_params())
     assert (info["status_polish"] == 0).all()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("passes", [1, 6])
+@pytest.mark.parametrize("passes", [1])
 def test_device_polish_matches_oracle_and_optimum(oracle, passes):
     from path_optimizer_amd import binding
 
@@ -58,7 +58,7 @@ def test_device_polish_matches_oracle_and_optimum(oracle, passes):
     gold = np.load(GOLD)["e_y"]
     p = binding.default_params()
     assert p.polish == 0 and p.polish_delta == 1e-6 and p.polish_refine_iter == 3
-    p.polish, p.polish_passes = 1, passes
+    p.polish = 1
     st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
     st0, info0, xs0 = binding.Engine(0).solve_batch(b, want_x=True)
     po = oracle.device_equivalent_params(p)
@@ -88,7 +88,7 @@ def test_device_polish_other_formulations(oracle, form, cfg, B):
 
     b = synth.make_batch(cfg, B=B, formulation=form)
     p = binding.default_params()
-    p.polish, p.polish_passes = 1, 6
+    p.polish = 1
     st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
     po = oracle.device_equivalent_params(p)
     ost, oinfo, oxs = oracle.solve_batch(b, po)
@@ -114,7 +114,7 @@ def test_device_polish_on_ragged_batches_and_other_keep_values(oracle):
         assert binding.keep_control_steps(0, b.ref_s[0]) == keep
         b.n_points = np.array([N, N - 1, N - 5, N // 2, N, 7, N - 2, N, 31, N], dtype=np.int32)
         p = binding.default_params()
-        p.polish, p.polish_passes = 1, 4
+        p.polish = 1
         st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
         ost, oinfo, oxs = oracle.solve_batch(b, oracle.device_equivalent_params(p))
         assert np.array_equal(info["status"], oinfo["status"])
