@@ -227,6 +227,67 @@ def run_setting(torch, binding, stream, db_x, kw, steps=3):
     return row, x, info
 
 
+def scaling_preview(torch, binding, synth, dev, stream, B):
+    """What a second GPU will see (no multi-GPU node has been available in any round).  Two things can cost a batch split its linearity:
+    (1) the tail of a launch — does it amortise on a bigger shard?  BASELINE config 4's WHOLE batch (32 768 paths) as ONE launch sequence on this device, beside the
+        4 096-path shard `value` is measured on: paths/s per GPU at both shard sizes;
+    (2) the host side of E concurrent engines — E handles on E host threads pinned to distinct cores, each solving its own small batch (64 paths: the GPU work is
+        ~0.1 ms, what is timed is the launch path: 1 scale + 2 warm-start + 1 Newton launch, the 4-byte read-back, the status sweep) — per-call wall time for E = 1, 2, 4, 8.
+        (Python threads: ctypes releases the GIL for the call; ~50 us of interpreter time per call are included.)"""
+    import threading
+
+    out = {}
+    eng = binding.Engine(torch.cuda.current_device(), make_params(binding, HEADLINE["params"]))
+    eng.set_stream(stream.cuda_stream)
+    big = synth.make_batch(4, B=32768)
+    db = binding.DeviceBatch(big, device=dev)
+    time_serial(torch, eng, stream, db, 1, torch.cuda.synchronize)
+    _, ms = time_serial(torch, eng, stream, db, 3, torch.cuda.synchronize)
+    info = db.info_numpy()
+    med = float(np.median(ms))
+    out["b32768_single_launch"] = {"workload": "BASELINE config 4 (KP, N=200), all 32768 paths on ONE device, one launch sequence", "ms": med, "paths_per_s": 32768 / (med * 1e-3),
+                                   "iters_mean": float(info["iters"].mean()), "iters_max": int(info["iters"].max()), "certified": int((info["status_refine"] == 1).sum()),
+                                   "unsolved": int((info["status"] != 1).sum())}
+    del db
+    small = synth.make_batch(3, B=64)
+    per_e = {}
+    for E in (1, 2, 4, 8):
+        cores = sorted(os.sched_getaffinity(0))[:E]
+        if len(cores) < E:
+            break
+        engs, strs, dbs = [], [], []
+        for _ in range(E):
+            e_ = binding.Engine(torch.cuda.current_device(), make_params(binding, HEADLINE["params"]))
+            st_ = torch.cuda.Stream(device=dev)
+            e_.set_stream(st_.cuda_stream)
+            engs.append(e_); strs.append(st_); dbs.append(binding.DeviceBatch(small, device=dev))
+        res = [None] * E
+        gate = threading.Barrier(E)
+
+        def work(k):
+            try:
+                os.sched_setaffinity(threading.get_native_id(), {cores[k]})
+            except OSError:
+                pass
+            for _ in range(5):
+                engs[k].solve_batch_device(dbs[k]); strs[k].synchronize()
+            gate.wait()
+            ts = []
+            for _ in range(40):
+                t0 = time.perf_counter(); engs[k].solve_batch_device(dbs[k]); strs[k].synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+            res[k] = float(np.median(ts))
+
+        th = [threading.Thread(target=work, args=(k,)) for k in range(E)]
+        [t.start() for t in th]; [t.join() for t in th]
+        per_e[str(E)] = {"per_call_ms_median_over_engines": float(np.median(res)), "per_call_ms_max": float(np.max(res))}
+        [e_.close() for e_ in engs]
+    out["engines_on_pinned_threads"] = {"batch_per_engine": 64, "calls": 40, "per_call_ms": per_e,
+                                        "note": "one handle + stream + host thread per engine, threads pinned to distinct cores, all on device 0; flat in E = the launch paths of "
+                                                "concurrent engines do not serialise on the host"}
+    eng.close()
+    return out
+
+
 def settings_table(torch, binding, batch, dev, stream, gold):
     """The table of settings on the full batch (details file): time, iterations and the accuracy counts of each."""
     db = binding.DeviceBatch(batch, device=dev, want_x=True)
@@ -628,6 +689,7 @@ def main():
     ap.add_argument("--no-stages", action="store_true", help="skip the legs for the stages around the QP (SURVEY.md §8f)")
     ap.add_argument("--no-configs", action="store_true", help="skip the quick legs for BASELINE configs 1, 2, 5 and the K formulation")
     ap.add_argument("--no-parity", action="store_true", help="skip the accuracy / parity legs")
+    ap.add_argument("--no-scaling-preview", action="store_true", help="skip the B = 32768 single-launch leg and the engines-on-pinned-threads leg (SURVEY §8e stand-ins)")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="paths timed on the CPU oracle (rank 0, N=1 only; 0 = no CPU legs)")
     ap.add_argument("--gather", action="store_true", help="N>1: gather every rank's states and info on rank 0 (SURVEY §8e collective 1) and report its time")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 PMC child passes that measure `roofline.traffic` in this run")
@@ -903,6 +965,15 @@ def main():
                      "compliant_n_gt_1e-4_m", "compliant_max_m", "qp_iters", "max_abs_diff_vs_reference")
             out["configs"] = {k: {kk: v[kk] for kk in keep_ if kk in v} for k, v in details["configs"].items()}
             out["configs"]["note"] = "ms / paths_per_s: OSQP-faithful default at eps 1e-4; compliant_*: the headline setting (same as `value`) on the whole batch, against the exact optima"
+        if not args.no_scaling_preview:
+            try:
+                details["scaling_preview"] = scaling_preview(torch, binding, synth, dev, streams[0], B)
+                sp = details["scaling_preview"]
+                out["scaling_preview"] = {"shard_4096_paths_per_s": out["single_batch"]["paths_per_s"], "shard_32768_paths_per_s": sp["b32768_single_launch"]["paths_per_s"],
+                                          "engine_call_ms_by_E": {k: v["per_call_ms_median_over_engines"] for k, v in sp["engines_on_pinned_threads"]["per_call_ms"].items()},
+                                          "note": "no multi-GPU node was available: one device at both shard sizes of a 1 -> 8 GPU split of config 4, and the host launch path of E concurrent engines (details file)"}
+            except Exception as e_:
+                out["scaling_preview"] = {"error": repr(e_)}
         if not args.no_parity:
             details["settings"] = settings_table(torch, binding, batch, dev, streams[0], gold)
             ok_all = [r for r in details["settings"] if r.get("e_y_rms_vs_exact_optimum", {}).get("n_gt_1e-4_m", 1) == 0 and r["unsolved"] == 0]

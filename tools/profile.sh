@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --cpu-sample 0 --no-stages --no-configs --no-parity --streams 0 --no-live-traffic --details ''"  # the timed pattern of the default command only: 3 warm-ups + 10 single-batch solves on one stream (+ the 11 solves of the order-hint leg: same kernel)
+BENCH="python $R/bench.py --cpu-sample 0 --no-stages --no-configs --no-parity --no-scaling-preview --streams 0 --no-live-traffic --details ''"  # the timed pattern of the default command only: 3 warm-ups + 10 single-batch solves on one stream (+ the 11 solves of the order-hint leg: same kernel)
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.log
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- $BENCH > /dev/null 2> $OUT/pmc_fetch.log
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o write -- $BENCH > /dev/null 2> $OUT/pmc_write.log
