@@ -118,10 +118,15 @@ inline bool pick_shape(int form, int N, int C, int keep, Shape *s) {
             if (chunks <= 32) { *s = {64, spl, true, 2 + (keep & 1)}; return true; }
             if (chunks <= 64) { *s = {128, spl, true, 2 + (keep & 1)}; return true; }
         } else {
+            // keep 1 / 2 (KP): MULTI-GROUP mapping — four stages per lane holding 4 / 2 whole control groups (nwx 4 / 5): keep 1 at N = 200 on 50 lanes instead of 200
+            if (form == F_KP && (keep == 1 || keep == 2)) {
+                const int chunks = (N + 3) / 4;
+                if (chunks <= 64) { *s = {64, 4, true, keep == 1 ? 4 : 5}; return true; }
+                if (chunks <= 128) { *s = {128, 4, true, keep == 1 ? 4 : 5}; return true; }
+            }
             // (keep 5 stays on one lane per chunk: measured at N = 200, where the role-split form needs two waves, 616 k against 487 k paths/s at the headline setting)
             const int spl = no_u ? (N <= 128 ? 2 : 4) : keep;
-            for (int nt : {64, 128, 256}) {
-                if (nt == 256 && spl != 1) break;
+            for (int nt : {64, 128}) {
                 if (nt == 128 && spl > 4) break;
                 if (N <= nt * spl && C <= nt) { *s = {nt, spl, true, 1}; return true; }
             }
@@ -154,17 +159,21 @@ template <int F> inline bool has_uni_variant(const Shape &s) { return s.two && (
 #endif
 #define PO_TWO_SHAPES(X) if (s.spl == PO_DEV_SPL && s.nt == 64 && s.nwx == PO_DEV_NWX) X(PO_DEV_SPL, 64, PO_DEV_NWX);
 #else
+// (KP: keep 1 / 2 multi-group (4, ., 4 / 5), keep 3 / 4 / 5 one lane per chunk, keep 6 / 7 / 8 role-split; KPC: keep 4; K: 2 or 4 stages per lane)
 #define PO_TWO_SHAPES(X)                                                                                                            \
     if constexpr (F == F_KP) {                                                                                                      \
-        if (s.nwx == 1 && s.spl == 1 && s.nt == 64) X(1, 64, 1); if (s.nwx == 1 && s.spl == 1 && s.nt == 128) X(1, 128, 1); if (s.nwx == 1 && s.spl == 1) X(1, 256, 1); \
         if (s.nwx == 1 && s.spl == 5) X(5, 64, 1);                                                                                  \
+        if (s.nwx == 1 && s.spl == 3 && s.nt == 64) X(3, 64, 1); if (s.nwx == 1 && s.spl == 3) X(3, 128, 1);                        \
+        if (s.nwx == 4 && s.nt == 64) X(4, 64, 4); if (s.nwx == 4) X(4, 128, 4);                                                    \
+        if (s.nwx == 5 && s.nt == 64) X(4, 64, 5); if (s.nwx == 5) X(4, 128, 5);                                                    \
         if (s.nwx == 2 && s.spl == 3 && s.nt == 64) X(3, 64, 2); if (s.nwx == 2 && s.spl == 3) X(3, 128, 2);                        \
         if (s.nwx == 2 && s.spl == 4 && s.nt == 64) X(4, 64, 2); if (s.nwx == 2 && s.spl == 4) X(4, 128, 2);                        \
         if (s.nwx == 3 && s.spl == 4 && s.nt == 64) X(4, 64, 3); if (s.nwx == 3 && s.spl == 4) X(4, 128, 3);                        \
     }                                                                                                                               \
+    if constexpr (F == F_K) {                                                                                                       \
+        if (s.nwx == 1 && s.spl == 2 && s.nt == 64) X(2, 64, 1); if (s.nwx == 1 && s.spl == 2) X(2, 128, 1);                        \
+    }                                                                                                                               \
     if (s.nwx == 1) {                                                                                                               \
-        if (s.spl == 2 && s.nt == 64) X(2, 64, 1); if (s.spl == 2) X(2, 128, 1);                                                    \
-        if (s.spl == 3 && s.nt == 64) X(3, 64, 1); if (s.spl == 3) X(3, 128, 1);                                                    \
         if (s.spl == 4 && s.nt == 64) X(4, 64, 1); if (s.spl == 4) X(4, 128, 1);                                                    \
     }
 #endif
@@ -222,18 +231,18 @@ template <int F, bool FB> hipError_t launch_newton(const DevBatch *in, const Dev
 #undef PO_X
     return hipErrorInvalidValue;
 }
-// OSQP's polish: one-lane-per-chunk shapes (the role-split shapes of keep 5 .. 8 have no polish kernel: status_polish stays 0 = not attempted, like the single-level mapping)
+// OSQP's polish: one-lane-per-chunk shapes (the role-split shapes of keep 6 .. 8 have no polish kernel: status_polish stays 0 = not attempted, like the single-level mapping)
 template <int F> inline bool has_polish_kernel(int N, int C, int keep) {
     Shape s;
-    return resolve_shape(F, N, C, keep, &s) && s.two && s.nwx == 1;
+    return resolve_shape(F, N, C, keep, &s) && s.two && s.nwx != 2 && s.nwx != 3;
 }
 template <int F> hipError_t launch_polish(const DevBatch *in, const DevParams *P, hipStream_t st) {
     Shape s;
     if (!resolve_shape(F, in->N, in->C, in->keep, &s) || !s.two) return hipErrorInvalidValue;
-    if (s.nwx != 1) return hipSuccess;
+    if (s.nwx == 2 || s.nwx == 3) return hipSuccess;
     const size_t lds = lds_of(F, in->N, in->C, s);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-#define PO_X(SPL_, NT_, NWX_) { if constexpr (NWX_ == 1) return launch1(&polish_kernel<F, SPL_, NT_>, in, P, NT_, lds, st); }
+#define PO_X(SPL_, NT_, NWX_) { if constexpr (NWX_ != 2 && NWX_ != 3) return launch1(&polish_kernel<F, SPL_, NT_, NWX_>, in, P, NT_, lds, st); }
     PO_TWO_SHAPES(PO_X)
 #undef PO_X
     return hipErrorInvalidValue;

@@ -13,7 +13,7 @@ from path_optimizer_amd.abi import INFO_DTYPE  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 scn = synth.make_planning_scenes(2, 64)
 par = binding.default_params()
-for kv in sys.argv[3:]:  # e.g. refine=1 eps_abs=3e-4 eps_rel=3e-4
+for kv in sys.argv[3:]:  # e.g. refine=2 eps_abs=3e-4 eps_rel=3e-4
     k_, v_ = kv.split("=")
     setattr(par, k_, type(getattr(par, k_))(float(v_)))
 eng = binding.Engine(0, par)
