@@ -147,9 +147,12 @@ typedef struct po_params {
     double refine_newton_rho_max;       /* 1e5: a multiplier update that does not cut the primal residual by 4 raises the penalty 10 x, up to this (the slow
                                            case: active rows that are nearly dependent through the heavily weighted curvature-rate variables).  <= 0: the default;
                                            at most OSQP's RHO_MAX = 1e6, which also bounds what refine_newton_escalate raises it to */
-    double refine_ls_tol;               /* 0.3: the line search stops at |psi'(t)| <= tol |psi'(0)| (the search is a safeguarded Newton iteration on the piecewise-linear psi', so
-                                           what it accepts is close to the root anyway; measured on the whole BASELINE batches against 1e-4: 3 - 7 % fewer Newton steps AND 14 %
-                                           fewer evaluations per step, every path certified at the same distance from the optimum).  The final correction steps always search to 1e-4. */
+    double refine_ls_tol;               /* 0.6: the line search stops at |psi'(t)| <= tol |psi'(0)| (the search is a safeguarded Newton iteration on the piecewise-linear psi', so
+                                           what it accepts is close to the root anyway).  Measured on the whole BASELINE batches, every path certified at every setting: 1e-4 -> 0.3
+                                           3 - 7 % fewer Newton steps and 14 % fewer evaluations per step (round 4); 0.3 -> 0.6 another 1 % fewer steps, the first trial step
+                                           accepted more often (config 3 5.19 -> 4.98 ms, config 5 21.3 -> 19.6 ms) and the SAME largest distance from the exact optimum on every
+                                           golden batch (2.1e-5 m); 0.9 is 3 % faster again but lands 3 paths of config 5 (KPC, flat directions) at 5 - 6.5e-5 m, half the margin
+                                           to the 1e-4 m bar (round 5).  The final correction steps always search to 1e-4. */
     int    refine_ls_max;               /* 30: evaluations of psi' per line search at most */
     int    refine_newton_max;           /* 300: Newton steps per attempt (every round).  BASELINE config 3: mean 16, max 60; config 5 (KPC): mean 28, max ~210 */
     int    refine_newton_final;         /* 3: once the point is certified at refine_eps, Newton steps go on (tight line search, no multiplier update) until the dual residual — the

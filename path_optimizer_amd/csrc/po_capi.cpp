@@ -171,7 +171,7 @@ void po_default_params(po_params *p) {
     p->enable_raw_output = 1; p->output_spacing = 0.3; /* planning_flags.cpp:127-129 */
     p->polish = 0; p->polish_delta = 1e-6; p->polish_refine_iter = 3;  /* OSQP defaults (polish off) */
     p->refine = 0; p->refine_eps = 1e-7; p->refine_rounds = 1; p->refine_chain = 2; p->refine_extra_rounds = 0;
-    p->refine_newton_rho = 100.0; p->refine_newton_rho_eq = 1e4; p->refine_newton_rho_max = 1e5; p->refine_ls_tol = 0.3; p->refine_ls_max = 30; p->refine_newton_max = 300; p->refine_newton_final = 3; p->refine_newton_escalate = 12; p->refine_newton_rho_eq_max = 1e6; /* refine = 2 */
+    p->refine_newton_rho = 100.0; p->refine_newton_rho_eq = 1e4; p->refine_newton_rho_max = 1e5; p->refine_ls_tol = 0.6; p->refine_ls_max = 30; p->refine_newton_max = 300; p->refine_newton_final = 3; p->refine_newton_escalate = 12; p->refine_newton_rho_eq_max = 1e6; /* refine = 2 */
 }
 
 int po_problem_dims(int form, int N, int keep, int *n, int *m, int *C) {

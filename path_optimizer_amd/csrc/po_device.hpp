@@ -481,9 +481,6 @@ template <int MODE> struct NwDirFn {
                 c0 += rw * dl * s;
                 c1 += rw * s * s;
             }
-#ifdef PO_NW_F0_MERGE
-            else if (k == 0u) f0 += W[r] * rho * dl * s;  // the inequality rows' part of psi'(0): saves the line search one evaluation
-#endif
         } else v[r] += t * s;
     }
 };
@@ -505,6 +502,29 @@ struct NwLsFn {
         const double rw = W[r] * rho;
         f += rw * dl * s;
         fp += dl != 0.0 ? rw * s * s : 0.0;
+    }
+};
+// the first pass of the line search: psi'(0) AND psi'(1) with the slope at 1 in one walk over the rows (the first trial step is always t = 1; same numbers as two
+// single evaluations — the row's s = a.d, its class test and its penalty are shared)
+struct NwLs01Fn {
+    double xt[5];
+    const double *v;
+    double rho, f0, f1, fp1;
+    unsigned cls_type;
+    const double *W;
+    template <int MASK, class TL, class TU> __device__ __forceinline__ void row(int r, double k0, double k1, double k2, double k3, double k4, TL l, TU u) {
+        if (((cls_type >> (2 * r)) & 3u) != 0u) return;
+        const double c[5] = {k0, k1, k2, k3, k4};
+        double s = 0;
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+            if (MASK >> a & 1) s += c[a] * xt[a];
+        const double w0 = v[r], d0 = w0 - clipd(w0, l, u);
+        const double w1 = w0 + 1.0 * s, d1 = w1 - clipd(w1, l, u);
+        const double rw = W[r] * rho;
+        f0 += rw * d0 * s;
+        f1 += rw * d1 * s;
+        fp1 += d1 != 0.0 ? rw * s * s : 0.0;
     }
 };
 template <bool FIRST> struct UpdFnX {

@@ -37,7 +37,7 @@ def _rms(batch, xs, gold):
 
 def test_oracle_newton_defaults(oracle):
     p = oracle.default_params()
-    assert (p.refine_newton_rho, p.refine_newton_rho_eq, p.refine_newton_rho_max, p.refine_ls_tol, p.refine_ls_max, p.refine_newton_max, p.refine_newton_final, p.refine_newton_rho_eq_max, p.refine_newton_escalate) == (100.0, 1e4, 1e5, 0.3, 30, 300, 3, 1e6, 12)
+    assert (p.refine_newton_rho, p.refine_newton_rho_eq, p.refine_newton_rho_max, p.refine_ls_tol, p.refine_ls_max, p.refine_newton_max, p.refine_newton_final, p.refine_newton_rho_eq_max, p.refine_newton_escalate) == (100.0, 1e4, 1e5, 0.6, 30, 300, 3, 1e6, 12)
 
 
 @pytest.mark.parametrize("name,B", [("c3", 512), ("c2", 256), ("c5", 96), ("k", 128), ("keep3", 128)])
