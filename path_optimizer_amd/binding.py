@@ -32,7 +32,7 @@ class PoError(RuntimeError):
 
 
 _ENV_DEBUG = {"PO_IDENTITY_ORDER": "identity_order", "PO_DEBUG_CYCLES": "debug_cycles", "PO_SMOOTH_SEQ": "smooth_seq",
-              "PO_SMOOTH_WAVES": "smooth_waves", "PO_SMOOTH_NOPAD": "smooth_nopad", "PO_SMOOTH_DEBUG": "smooth_debug", "PO_DP_ONE_WAVE": "dp_one_wave"}
+              "PO_SMOOTH_WAVES": "smooth_waves", "PO_SMOOTH_NOPAD": "smooth_nopad", "PO_SMOOTH_DEBUG": "smooth_debug", "PO_DP_ONE_WAVE": "dp_one_wave", "PO_NEWTON_SLICE": "newton_slice"}
 
 
 def lib():
@@ -138,7 +138,7 @@ class Engine:
             raise
 
     def debug_set(self, key: str, value: int):
-        """po_debug_set: developer A/B switches (identity_order, debug_cycles, host_threads, smooth_seq, smooth_waves, smooth_nopad, smooth_debug, dp_one_wave)."""
+        """po_debug_set: developer A/B switches (identity_order, debug_cycles, host_threads, smooth_seq, smooth_waves, smooth_nopad, smooth_debug, dp_one_wave, newton_slice)."""
         _check(lib().po_debug_set(self._h, key.encode(), int(value)))
 
     def debug_get(self, key: str) -> int:

@@ -26,6 +26,8 @@ extern "C" hipError_t po_launch_polish(int form, const po::DevBatch *in, const p
 extern "C" hipError_t po_launch_newton(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
 extern "C" hipError_t po_launch_newton_fallback(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
 extern "C" int po_polish_state_doubles(int form, int N, int C, int keep);
+extern "C" int po_newton_park_doubles(int form, int N, int C, int keep);
+extern "C" hipError_t po_launch_nw_sort(const int *keys, int B, int *list, hipStream_t st);
 extern "C" int po_has_polish_kernel(int form, int N, int C, int keep);
 extern "C" hipError_t po_launch_scale(int form, const po::DevBatch *in, const po::DevParams *P, int passes, double *sc, hipStream_t st);
 extern "C" hipError_t po_launch_assemble(int form, const po::DevBatch *in, const po::DevParams *P, double *l, double *u, double *dyn, hipStream_t st);
@@ -127,6 +129,9 @@ struct po_handle_s {
     int host_threads = 0;      // pack / unpack threads (0: min(8, hardware threads); po_debug_set "host_threads")
     DevBuf pol_buf;  // per-lane ADMM state handed from the solve kernels to newton_kernel / polish_kernel (po_params.refine / polish)
     DevBuf fb_buf;   // refine = 2: the work list of newton_fallback_kernel
+    DevBuf nw_state_buf, nw_idx_buf;  // sliced Newton launches: the parked paths' blocks; keys [B] + list [B + 1]
+    int nw_last_B = 0;  // ... and the batch size of the last sliced solve (po_debug_get "newton_parked")
+    int nw_slice = 8;  // steps of the first of the two Newton launches (po_debug_set "newton_slice"; 0: one launch).  Scheduling only.
     HostBuf fb_host; // ... and the pinned word its count is read back into (refine_chain = 2)
     // developer switches (po_debug_set; the library reads no environment variable): identity_order (block i solves path i), debug_cycles (per-phase shader
     // clocks of path 0 on stderr; synchronises), smoothing / DP-search A/B switches
@@ -241,6 +246,7 @@ int po_destroy(po_handle h) {
     (void)hipStreamSynchronize(h->stream);
     h->pol_buf.release();
     h->fb_buf.release();
+    h->nw_state_buf.release(); h->nw_idx_buf.release();
     h->in_buf.release(); h->out_buf.release(); h->asm_buf.release(); h->scale_buf.release(); h->dbg_buf.release(); h->map_buf.release(); h->post_buf.release(); h->coef_buf.release(); h->bnd_buf.release(); h->smooth_buf.release(); h->smooth_io.release(); h->plan_coef.release(); h->plan_io.release(); h->plan_arena.release(); h->plan_host.release();
     h->pin_in.release(); h->pin_out.release(); h->fb_host.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -259,6 +265,7 @@ int po_debug_set(po_handle h, const char *key, int value) {
     if (k == "identity_order") h->env_identity = value != 0;
     else if (k == "host_threads") h->host_threads = value < 0 ? 0 : value;
     else if (k == "debug_cycles") h->env_cycles = value != 0;
+    else if (k == "newton_slice") h->nw_slice = value > 0 ? (int)value : 0;
     else if (k == "smooth_seq") h->env_smooth_seq = value != 0;
     else if (k == "smooth_waves") h->env_smooth_waves = value;
     else if (k == "smooth_nopad") h->env_smooth_nopad = value != 0;
@@ -279,6 +286,16 @@ int po_debug_get(po_handle h, const char *key, long long *value) {
         HIP_TRY(hipStreamSynchronize(h->stream));
         int c = 0;
         HIP_TRY(hipMemcpy(&c, h->fb_buf.p, sizeof(int), hipMemcpyDeviceToHost));
+        *value = c;
+        return PO_OK;
+    }
+    if (k == "newton_parked") {  // sliced Newton launches: how many paths of the last solve went on into the second launch (-1: the last solve was not sliced)
+        *value = -1;
+        if (!h->nw_idx_buf.p || h->nw_last_B <= 0) return PO_OK;
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        int c = 0;
+        HIP_TRY(hipMemcpy(&c, static_cast<int *>(h->nw_idx_buf.p) + h->nw_last_B, sizeof(int), hipMemcpyDeviceToHost));
         *value = c;
         return PO_OK;
     }
@@ -321,7 +338,7 @@ static int make_dev_params(const po_handle_s *h, int form, int keep, po::DevPara
     D->ref_nw_rho_max = p.refine_newton_rho_max > 0 ? std::min(p.refine_newton_rho_max, po::kRhoMax) : 1e5;
     D->ref_nw_rho_eq_max = p.refine_newton_rho_eq_max > 0 ? std::min(p.refine_newton_rho_eq_max, 1e8) : (p.refine_newton_rho_eq_max < 0 ? 1e6 : 0.0);  // 0: the equality penalty never grows (documented switch)
     D->ref_ls_tol = p.refine_ls_tol > 0 ? p.refine_ls_tol : 1e-4;
-    D->ref_nw_final = p.refine_newton_final; D->ref_nw_esc = p.refine_newton_escalate; D->ref_ls_max = p.refine_ls_max > 0 ? p.refine_ls_max : 30; D->ref_nw_max = p.refine_newton_max > 0 ? p.refine_newton_max : 300;
+    D->ref_nw_final = p.refine_newton_final; D->ref_nw_esc = p.refine_newton_escalate; D->ref_nw_slice = 0; D->ref_ls_max = p.refine_ls_max > 0 ? p.refine_ls_max : 30; D->ref_nw_max = p.refine_newton_max > 0 ? p.refine_newton_max : 300;
     return PO_OK;
 }
 
@@ -354,6 +371,7 @@ static void fill_dev_batch(const po_handle_s *h, po::DevBatch *D, const po_batch
     D->pol_state = nullptr; D->pol_stride = 0;
     D->round = 0;
     D->fb_list = nullptr;
+    D->nw_phase = 0; D->nw_state = nullptr; D->nw_stride = 0; D->nw_keys = nullptr; D->nw_list = nullptr;
     D->n = n; D->m = m;
 }
 
@@ -403,7 +421,26 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
         HIP_TRY(hipEventRecord(h->evp[0], h->stream));
         D.fb_list = static_cast<int *>(h->fb_buf.p);
         HIP_TRY(hipMemsetAsync(D.fb_list, 0, sizeof(int), h->stream));
-        HIP_TRY(po_launch_newton(in->formulation, &D, &P, h->stream));
+        // SLICED LAUNCHES (engine-internal scheduling): the Newton launch is two — every path for nw_slice steps, the unfinished ones parked with a
+        // priority key; a one-workgroup sort; the parked paths in order of expected remaining work, longest first.  One launch in engine order ends on a tail of a few
+        // long paths (30 % of it on BASELINE config 3).  The operations and their order are unchanged: statuses and certificates do not depend on the slicing, solutions agree to round-off.
+        const int pd = h->nw_slice > 0 ? po_newton_park_doubles(in->formulation, in->N, C, in->keep) : 0;
+        h->nw_last_B = pd > 0 ? in->B : 0;
+        if (pd > 0) {
+            if ((rc = h->nw_state_buf.ensure(sizeof(double) * (size_t)pd * (size_t)in->B)) || (rc = h->nw_idx_buf.ensure(sizeof(int) * (2 * (size_t)in->B + 1)))) return rc;
+            D.nw_state = static_cast<double *>(h->nw_state_buf.p); D.nw_stride = pd;
+            D.nw_keys = static_cast<int *>(h->nw_idx_buf.p); D.nw_list = D.nw_keys + in->B;
+            P.ref_nw_slice = h->nw_slice;
+            HIP_TRY(hipMemsetAsync(D.nw_keys, 0xFF, sizeof(int) * (size_t)in->B, h->stream));  // (a path no workgroup of the first launch reaches — a malformed caller-side order — is not parked)
+            D.nw_phase = 1;
+            HIP_TRY(po_launch_newton(in->formulation, &D, &P, h->stream));
+            HIP_TRY(po_launch_nw_sort(D.nw_keys, in->B, D.nw_list, h->stream));
+            D.nw_phase = 2;
+            HIP_TRY(po_launch_newton(in->formulation, &D, &P, h->stream));
+            D.nw_phase = 0;
+        } else {
+            HIP_TRY(po_launch_newton(in->formulation, &D, &P, h->stream));
+        }
         HIP_TRY(hipEventRecord(h->evp[1], h->stream));
         h->timed_phases = true;
         // The paths newton_kernel did not certify (rare) are on a device-side work list; newton_fallback_kernel takes them through the later rounds.  Its launch alone

@@ -39,6 +39,7 @@ struct DevParams {
     double ref_eps;
     double ref_nw_rho, ref_nw_rho_eq, ref_nw_rho_max, ref_nw_rho_eq_max, ref_ls_tol;  // po_params.refine = 2 (Newton refinement)
     int ref_ls_max, ref_nw_max, ref_nw_final, ref_nw_esc;
+    int ref_nw_slice;  // sliced Newton launches: steps of the first launch (engine-internal scheduling, po_debug_set("newton_slice"); results do not depend on it)
 };
 
 struct DevBatch {
@@ -59,6 +60,12 @@ struct DevBatch {
     double *pol_state;      // [B][pol_stride] per-lane ADMM state left by the solve kernels for newton_kernel / polish_kernel (or nullptr)
     int pol_stride;
     int *fb_list;           // po_params.refine = 2: work list of the paths newton_kernel hands back (count, then path ids; newton_fallback_kernel)
+    // sliced Newton launches (newton_kernel): 0 one launch; 1 first launch (parks after DevParams::ref_nw_slice steps); 2 second launch (resumes the parked paths in list order)
+    int nw_phase;
+    double *nw_state;       // [B][nw_stride]: a parked path's lane state, factor classes and phase scalars (Fast::park_io)
+    int nw_stride;
+    int *nw_keys;           // [B]: -1 finished in the first launch, else the priority key (larger = longer expected)
+    int *nw_list;           // count, then the parked path ids in launch order (nw_sort_kernel)
 };
 
 template <int F> struct FormTraits;

@@ -106,6 +106,65 @@ extern "C" hipError_t po_launch_polish(int form, const po::DevBatch *in, const p
     using namespace po;
     return form == F_KP ? po_launch_polish_kp(in, P, st) : (form == F_KPC ? po_launch_polish_kpc(in, P, st) : po_launch_polish_k(in, P, st));
 }
+extern "C" int po_polish_state_doubles_kp_park(int N, int C, int keep);
+extern "C" int po_polish_state_doubles_kpc_park(int N, int C, int keep);
+extern "C" int po_polish_state_doubles_k_park(int N, int C, int keep);
+extern "C" int po_newton_park_doubles(int form, int N, int C, int keep) {
+    using namespace po;
+    return form == F_KP ? po_polish_state_doubles_kp_park(N, C, keep) : (form == F_KPC ? po_polish_state_doubles_kpc_park(N, C, keep) : po_polish_state_doubles_k_park(N, form == F_K ? 0 : C, keep));
+}
+namespace po {
+// the parked paths (keys[b] >= 0) in descending key order, ties in path order (a stable counting sort: deterministic): list[0] = count, list[1 ..] = path ids.
+// One workgroup of kNwSortThreads threads, thread t owns the contiguous range of paths [t * per, (t + 1) * per).
+constexpr int kNwKeys = 16, kNwSortThreads = 512;
+__global__ __launch_bounds__(kNwSortThreads) void nw_sort_kernel(const int *keys, int B, int *list) {
+    __shared__ int cnt[kNwKeys][kNwSortThreads + 1];
+    const int t = threadIdx.x, per = (B + kNwSortThreads - 1) / kNwSortThreads, lo = t * per, hi = min(B, lo + per);
+    int mine[kNwKeys];
+#pragma unroll
+    for (int k = 0; k < kNwKeys; ++k) mine[k] = 0;
+    for (int b = lo; b < hi; ++b) {
+        const int k = keys[b];
+        if (k >= 0) {
+#pragma unroll
+            for (int j = 0; j < kNwKeys; ++j) mine[j] += (j == (k < kNwKeys ? k : kNwKeys - 1));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kNwKeys; ++k) cnt[k][t] = mine[k];
+    __syncthreads();
+    // exclusive prefix over (key descending, thread ascending): one thread per key scans its row, then the rows are offset by the totals of the higher keys
+    if (t < kNwKeys) {
+        int run = 0;
+        for (int i = 0; i < kNwSortThreads; ++i) { const int c = cnt[t][i]; cnt[t][i] = run; run += c; }
+        cnt[t][kNwSortThreads] = run;
+    }
+    __syncthreads();
+    int base[kNwKeys];
+    {
+        int run = 0;
+#pragma unroll
+        for (int k = kNwKeys - 1; k >= 0; --k) { base[k] = run + cnt[k][t]; run += cnt[k][kNwSortThreads]; }
+        if (t == 0) list[0] = run;
+    }
+    for (int b = lo; b < hi; ++b) {
+        const int k = keys[b];
+        if (k >= 0) {
+            const int kk = k < kNwKeys ? k : kNwKeys - 1;
+            int pos = 0;
+#pragma unroll
+            for (int j = 0; j < kNwKeys; ++j) if (j == kk) { pos = base[j]; base[j] += 1; }
+            list[1 + pos] = b;
+        }
+    }
+}
+
+}  // namespace po
+// sliced Newton launches: the parked paths ordered by expected remaining work (one small workgroup; ~10 us)
+extern "C" hipError_t po_launch_nw_sort(const int *keys, int B, int *list, hipStream_t st) {
+    hipLaunchKernelGGL(po::nw_sort_kernel, dim3(1), dim3(po::kNwSortThreads), 0, st, keys, B, list);
+    return hipGetLastError();
+}
 extern "C" int po_polish_state_doubles(int form, int N, int C, int keep) {
     using namespace po;
     return form == F_KP ? po_polish_state_doubles_kp(N, C, keep) : (form == F_KPC ? po_polish_state_doubles_kpc(N, C, keep) : po_polish_state_doubles_k(N, form == F_K ? 0 : C, keep));

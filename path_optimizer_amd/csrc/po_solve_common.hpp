@@ -219,6 +219,15 @@ template <int F> inline int polish_state_doubles(int N, int C, int keep) {
 #undef PO_X
     return 0;
 }
+// doubles per path of the block a PARKED Newton path lives in between the two sliced launches (Fast::park_io + kNwParkScalars)
+template <int F> inline int newton_park_doubles(int N, int C, int keep) {
+    Shape s;
+    if (!resolve_shape(F, N, C, keep, &s) || !s.two) return 0;
+#define PO_X(SPL_, NT_, NWX_) return Fast<F, SPL_, NT_, true, NWX_>::kParkDoubles * NT_ + kNwParkScalars
+    PO_TWO_SHAPES(PO_X)
+#undef PO_X
+    return 0;
+}
 // the Newton refinement of round 0 as its own launch (po_params.refine = 2): same shapes.  FB: the fallback launch behind it
 // (newton_fallback_kernel walks the work list of the paths newton_kernel handed back; a small fixed grid)
 template <int F, bool FB> hipError_t launch_newton(const DevBatch *in, const DevParams *P, hipStream_t st) {
@@ -226,7 +235,7 @@ template <int F, bool FB> hipError_t launch_newton(const DevBatch *in, const Dev
     if (!resolve_shape(F, in->N, in->C, in->keep, &s) || !s.two) return hipErrorInvalidValue;
     const size_t lds = lds_of(F, in->N, in->C, s);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-#define PO_X(SPL_, NT_, NWX_) { if constexpr (FB) return launch_grid(&newton_fallback_kernel<F, SPL_, NT_, NWX_>, in, P, kFallbackGrid, NT_, lds, st); else return launch1(&newton_kernel<F, SPL_, NT_, NWX_>, in, P, NT_, lds, st); }
+#define PO_X(SPL_, NT_, NWX_) { if constexpr (FB) return launch_grid(&newton_fallback_kernel<F, SPL_, NT_, NWX_>, in, P, kFallbackGrid, NT_, lds, st); else if (in->nw_phase == 2) return launch1(&newton_kernel<F, SPL_, NT_, NWX_, 2>, in, P, NT_, lds, st); else return launch1(&newton_kernel<F, SPL_, NT_, NWX_, 1>, in, P, NT_, lds, st); }
     PO_TWO_SHAPES(PO_X)
 #undef PO_X
     return hipErrorInvalidValue;

@@ -46,5 +46,6 @@ extern "C" hipError_t PO_ENTRY_BASE(const po::DevBatch *in, const po::DevParams 
 // the polish kernels of this formulation build with the general-variant object
 extern "C" hipError_t PO_POLISH_ENTRY(const po::DevBatch *in, const po::DevParams *P, hipStream_t st) { return po::launch_polish<PO_FORM>(in, P, st); }
 extern "C" int PO_POLISH_SIZE(int N, int C, int keep) { return po::polish_state_doubles<PO_FORM>(N, C, keep); }
+extern "C" int PO_CAT(PO_POLISH_SIZE, _park)(int N, int C, int keep) { return po::newton_park_doubles<PO_FORM>(N, C, keep); }
 extern "C" int PO_POLISH_HAS(int N, int C, int keep) { return po::has_polish_kernel<PO_FORM>(N, C, keep) ? 1 : 0; }
 #endif
