@@ -232,7 +232,7 @@ def scaling_preview(torch, binding, synth, dev, stream, B):
     (1) the tail of a launch — does it amortise on a bigger shard?  BASELINE config 4's WHOLE batch (32 768 paths) as ONE launch sequence on this device, beside the
         4 096-path shard `value` is measured on: paths/s per GPU at both shard sizes;
     (2) the host side of E concurrent engines — E handles on E host threads pinned to distinct cores, each solving its own small batch (64 paths: the GPU work is
-        ~0.1 ms, what is timed is the launch path: 1 scale + 2 warm-start + 1 Newton launch, the 4-byte read-back, the status sweep) — per-call wall time for E = 1, 2, 4, 8.
+        ~0.1 ms, what is timed is the launch path: 1 scale + 2 warm-start + the Newton launch (a pair with a sort between them on batches of >= 2048 paths), the 4-byte read-back, the status sweep) — per-call wall time for E = 1, 2, 4, 8.
         (Python threads: ctypes releases the GIL for the call; ~50 us of interpreter time per call are included.)"""
     import threading
 
@@ -854,7 +854,7 @@ def main():
                        "batch_per_gpu": B, "points": N, "formulation": "KP", "parallelism": f"batch-split x{world}",
                        "rank_time_max_over_mean": rank_time_max_over_mean},
             "single_batch": {"median_ms": med_ms, "min_ms": float(np.min(step_ms)), "max_ms": float(np.max(step_ms)), "paths_per_s": B / (med_ms * 1e-3),
-                             "note": "hipEvents on the engine's stream around each step (equilibration + warm-start launches + Newton launch + fallback launch + status sweep), rank 0"},
+                             "note": "hipEvents on the engine's stream around each step (equilibration + warm-start launches + the two sliced Newton launches and the sort between them + fallback launch + status sweep), rank 0"},
             "admm": {"iters_mean": iters_sum_all / (world * B), "iters_max": iters_max, "unsolved": int(unsolved_all),
                      "refactorisations": int(refac_all), "path_iters_per_s": iters_sum_all * args.steps / elapsed_max,
                      "iters_min": int(info["iters"].min()), "iters_median": float(np.median(info["iters"])), "iters_p95": float(np.percentile(info["iters"], 95)),
@@ -1002,7 +1002,7 @@ def main():
                 rf["frac_of_measured_issue_ceiling"] = {k: rf["achieved"] / v for k, v in FP64_VALU_MEASURED_CEILING.items()} if rf.get("achieved") else None
                 nk_ms = (out["single_batch"].get("phases_ms_last_step") or {}).get("newton")
                 if lt.get("newton_kernel_fp64_flop_per_launch") and nk_ms:
-                    rf["dominant_kernel"] = {"kernel": "po::newton_kernel<KP,4,64> (+ the fallback launch behind it, empty here)", "launch_ms": nk_ms,
+                    rf["dominant_kernel"] = {"kernel": "po::newton_kernel<KP,4,64>: the sliced pair of launches (8 steps of every path; the parked rest, longest expected first) with the 13 us sort between them (+ the fallback launch behind, empty here)", "launch_ms": nk_ms,
                                              "fp64_flop_per_launch": lt["newton_kernel_fp64_flop_per_launch"], "achieved": lt["newton_kernel_fp64_flop_per_launch"] / (nk_ms * 1e-3) / 1e12,
                                              "frac": lt["newton_kernel_fp64_flop_per_launch"] / (nk_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                                              "launch_ms_source": "hipEvents on the engine's stream around the launch (po_last_phase_ms), last timed step"}

@@ -130,7 +130,9 @@ struct po_handle_s {
     DevBuf pol_buf;  // per-lane ADMM state handed from the solve kernels to newton_kernel / polish_kernel (po_params.refine / polish)
     DevBuf fb_buf;   // refine = 2: the work list of newton_fallback_kernel
     DevBuf nw_state_buf, nw_idx_buf;  // sliced Newton launches: the parked paths' blocks; keys [B] + list [B + 1]
+    bool nw_slice_forced = false;
     int nw_last_B = 0;  // ... and the batch size of the last sliced solve (po_debug_get "newton_parked")
+    int wave_slots = 1024;  // paths the device runs at a time (one wave per SIMD: 4 per CU); batches below two rounds of that are not sliced (no queueing tail to remove)
     int nw_slice = 8;  // steps of the first of the two Newton launches (po_debug_set "newton_slice"; 0: one launch).  Scheduling only.
     HostBuf fb_host; // ... and the pinned word its count is read back into (refine_chain = 2)
     // developer switches (po_debug_set; the library reads no environment variable): identity_order (block i solves path i), debug_cycles (per-phase shader
@@ -227,6 +229,7 @@ int po_create(int device, const po_params *params, po_handle *out) {
     po_handle_s *h = new (std::nothrow) po_handle_s;
     if (!h) return PO_ERR_NOMEM;
     h->device = device;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->wave_slots = 4 * cus; }
     h->params = *params;
     if (!hip_ok(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking), "hipStreamCreate") ||
         !hip_ok(hipEventCreate(&h->ev0), "hipEventCreate") || !hip_ok(hipEventCreate(&h->ev1), "hipEventCreate")) {
@@ -265,7 +268,7 @@ int po_debug_set(po_handle h, const char *key, int value) {
     if (k == "identity_order") h->env_identity = value != 0;
     else if (k == "host_threads") h->host_threads = value < 0 ? 0 : value;
     else if (k == "debug_cycles") h->env_cycles = value != 0;
-    else if (k == "newton_slice") h->nw_slice = value > 0 ? (int)value : 0;
+    else if (k == "newton_slice") { h->nw_slice = value > 0 ? (int)value : 0; h->nw_slice_forced = value > 0; }  // (set explicitly: also on batches the engine would not slice)
     else if (k == "smooth_seq") h->env_smooth_seq = value != 0;
     else if (k == "smooth_waves") h->env_smooth_waves = value;
     else if (k == "smooth_nopad") h->env_smooth_nopad = value != 0;
@@ -424,7 +427,7 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
         // SLICED LAUNCHES (engine-internal scheduling): the Newton launch is two — every path for nw_slice steps, the unfinished ones parked with a
         // priority key; a one-workgroup sort; the parked paths in order of expected remaining work, longest first.  One launch in engine order ends on a tail of a few
         // long paths (30 % of it on BASELINE config 3).  The operations and their order are unchanged: statuses and certificates do not depend on the slicing, solutions agree to round-off.
-        const int pd = h->nw_slice > 0 ? po_newton_park_doubles(in->formulation, in->N, C, in->keep) : 0;
+        const int pd = (h->nw_slice > 0 && (in->B >= 2 * h->wave_slots || h->nw_slice_forced)) ? po_newton_park_doubles(in->formulation, in->N, C, in->keep) : 0;
         h->nw_last_B = pd > 0 ? in->B : 0;
         if (pd > 0) {
             if ((rc = h->nw_state_buf.ensure(sizeof(double) * (size_t)pd * (size_t)in->B)) || (rc = h->nw_idx_buf.ensure(sizeof(int) * (2 * (size_t)in->B + 1)))) return rc;

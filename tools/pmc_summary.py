@@ -75,12 +75,18 @@ def main(src, dst):
                "solves_per_pass": n_solves, **out}, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
     top = os.path.dirname(dst.rstrip("/"))
     H = "headline"
-    nk = next((v for k, v in out[H].items() if "newton_kernel" in k), None)
+    # the Newton refinement of one solve = its newton_kernel launches together (round 5: two, the sliced pair <..., 1> and <..., 2>): per-launch figures summed over the variants
+    nk = None
+    for k, v in out[H].items():
+        if "newton_kernel" in k:
+            nk = nk or collections.defaultdict(lambda: {"per_dispatch": 0.0})
+            for c, d in v.items():
+                nk[c]["per_dispatch"] += d["per_dispatch"]
     if n_solves[H].get("pmc_fetch") and n_solves[H].get("pmc_write"):
         fetch, write = per_solve(out, n_solves, H, "FETCH_SIZE", "pmc_fetch") * 1024.0, per_solve(out, n_solves, H, "WRITE_SIZE", "pmc_write") * 1024.0
         t = {"hbm_bytes_per_launch": 2 * fetch + write, "fetch_bytes_raw": fetch,
              "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM section)",
-             "write_bytes": write, "write_note": "32.8 MB of outputs + the state block handed from the warm-start launch to newton_kernel + register-spill scratch write-backs",
+             "write_bytes": write, "write_note": "32.8 MB of outputs + the state block handed from the warm-start launch to newton_kernel (147 MB) + the parked paths' blocks between the two Newton launches (~250 MB) + register-spill scratch write-backs",
              "per": "one solve of BASELINE config 3 at the headline setting = every kernel of that solve summed (scale + warm-start launches + newton_kernel + fallback + status sweep); launches of the osqp_default leg excluded",
              "headline_solves_averaged": n_solves[H]["pmc_fetch"],
              "source": f"{dst}/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)",
@@ -94,7 +100,7 @@ def main(src, dst):
              "valu_wave_instr_per_solve": gsq("SQ_INSTS_VALU"),
              "fp64_wave_instr_per_solve": sum(g64(c) for c in F64),
              "headline_solves_averaged": n_solves[H]["pmc_f64"],
-             "newton_kernel": {"fp64_flop_per_launch": flop_of(lambda c: nk[c]["per_dispatch"]), "valu_wave_instr_per_launch": nk.get("SQ_INSTS_VALU", {}).get("per_dispatch", 0),
+             "newton_kernel": {"launches_per_solve": sum(1 for k in out[H] if "newton_kernel" in k), "fp64_flop_per_launch": flop_of(lambda c: nk[c]["per_dispatch"]), "valu_wave_instr_per_launch": nk.get("SQ_INSTS_VALU", {}).get("per_dispatch", 0),
                                "sq_wave_cycles_per_launch_x4": nk.get("SQ_WAVE_CYCLES", {}).get("per_dispatch", 0) * 4,
                                "lds_bank_conflict_over_busy": (nk["SQ_LDS_BANK_CONFLICT"]["per_dispatch"] / nk["SQ_BUSY_CYCLES"]["per_dispatch"]) if "SQ_LDS_BANK_CONFLICT" in nk and nk.get("SQ_BUSY_CYCLES", {}).get("per_dispatch") else None},
              "osqp_default_solve": {"fp64_flop_per_solve": flop_of(lambda c: per_solve(out, n_solves, "other", c, "pmc_f64")), "solves_averaged": n_solves["other"].get("pmc_f64", 0)},
