@@ -122,7 +122,7 @@ class Engine:
         self._h = C.c_void_p()
         _check(lib().po_create(device, C.byref(self.params), C.byref(self._h)))
         # developer conveniences of THIS Python plumbing (tools/*.py, A/B runs): PO_* environment variables are translated into po_debug_set calls
-        # here; the C library itself reads no environment variable.  A switch this build does not have (PO_SPLIT on a build without `make SPLIT=1`) is
+        # here; the C library itself reads no environment variable.  A switch this build does not have is
         # reported and ignored; any other failure destroys the handle before it propagates.
         try:
             for env, key in _ENV_DEBUG.items():
