@@ -165,7 +165,7 @@ def config_legs(torch, binding, synth, dev, stream, steps=3):
 
 # The setting `value` is quoted at — ONE setting for every shape (round 4): a short OSQP-faithful ADMM run (to the first termination check) as the warm start, then
 # the Newton refinement (po_params.refine = 2: semismooth Newton on the augmented Lagrangian with a line search on the merit (safeguarded Newton on its piecewise-linear derivative)) until OSQP's termination test holds at refine_eps.
-HEADLINE = {"label": "ADMM warm start (25 it) + Newton refinement (refine = 2, refine_eps 1e-8 + final correction steps), split launches",
+HEADLINE = {"label": "ADMM warm start (25 it) + Newton refinement (refine = 2, refine_eps 1e-8 + final correction steps), split launches; the Newton launch sliced in two by the engine (8 steps of every path, the rest longest-expected first)",
             "params": dict(refine=2, refine_rounds=5, refine_extra_rounds=2, refine_eps=1e-8, refine_chain=2),
             "algorithm": "EXTENSION (closer to the QP's optimum than the reference's OSQP run): certified per path, po_info.status_refine"}
 OSQP_DEFAULT = {"label": "eps 1e-4, OSQP defaults only (no extension)", "params": {},

@@ -262,7 +262,7 @@ int po_set_stream(po_handle h, void *hip_stream);
  * "smooth_seq", "smooth_waves", "smooth_nopad", "smooth_debug" (smoothing-QP engine variants), "dp_one_wave" (DP lattice search on one wave per instance whatever
  * the batch size), "newton_slice" (refine = 2: Newton steps of the FIRST of the two Newton launches, default 8 — every path runs that many, what is unfinished is parked
  * and the second launch takes the parked paths in order of expected remaining work, longest first; 0: one launch; left alone the engine slices batches of
- * at least two rounds of the device's wave slots (2 x 4 x CUs = 2048 paths), a value set here applies to every batch.  Scheduling only: the same operations in the same
+ * at least two rounds of the device's wave slots (2 x 4 x CUs = 2048 paths) on shapes that run one wave per path, a value set here applies to every batch.  Scheduling only: the same operations in the same
  * order — statuses and certificates do not depend on it, the solutions agree to round-off (the kernels of the two launches are compiled separately; identical bit for bit on the
  * BASELINE KP / K shapes, <= 1e-10 elsewhere); BASELINE config 3: 4.76 -> 4.06 ms).  Unknown key: PO_ERR_INVALID. */
 int po_debug_set(po_handle h, const char *key, int value);

@@ -27,6 +27,7 @@ extern "C" hipError_t po_launch_newton(int form, const po::DevBatch *in, const p
 extern "C" hipError_t po_launch_newton_fallback(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
 extern "C" int po_polish_state_doubles(int form, int N, int C, int keep);
 extern "C" int po_newton_park_doubles(int form, int N, int C, int keep);
+extern "C" int po_shape_threads(int form, int N, int C, int keep);
 extern "C" hipError_t po_launch_nw_sort(const int *keys, int B, int *list, hipStream_t st);
 extern "C" int po_has_polish_kernel(int form, int N, int C, int keep);
 extern "C" hipError_t po_launch_scale(int form, const po::DevBatch *in, const po::DevParams *P, int passes, double *sc, hipStream_t st);
@@ -427,7 +428,11 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
         // SLICED LAUNCHES (engine-internal scheduling): the Newton launch is two — every path for nw_slice steps, the unfinished ones parked with a
         // priority key; a one-workgroup sort; the parked paths in order of expected remaining work, longest first.  One launch in engine order ends on a tail of a few
         // long paths (30 % of it on BASELINE config 3).  The operations and their order are unchanged: statuses and certificates do not depend on the slicing, solutions agree to round-off.
-        const int pd = (h->nw_slice > 0 && (in->B >= 2 * h->wave_slots || h->nw_slice_forced)) ? po_newton_park_doubles(in->formulation, in->N, C, in->keep) : 0;
+        // Left alone the engine slices where it was measured to pay: one wave per path (NT = 64: 4 x CUs paths at a time) and at least two rounds of them — BASELINE config 3
+        // 4.76 -> 4.06 ms, K 5.41 -> 4.85, keep 8 6.15 -> 5.75, 2 048 paths of config 3 2.62 -> 2.53; two-wave shapes gain or lose 1 % (keep 2 / 3) or lose 10 % (KPC at N = 400:
+        // eight rounds, the re-entry of a 2 x 36 KB state per path), a batch of one round has no queueing tail to remove (config 2: + 10 % for the re-entry).
+        const bool slice_auto = in->B >= 2 * h->wave_slots && po_shape_threads(in->formulation, in->N, C, in->keep) == 64;
+        const int pd = (h->nw_slice > 0 && (slice_auto || h->nw_slice_forced)) ? po_newton_park_doubles(in->formulation, in->N, C, in->keep) : 0;
         h->nw_last_B = pd > 0 ? in->B : 0;
         if (pd > 0) {
             if ((rc = h->nw_state_buf.ensure(sizeof(double) * (size_t)pd * (size_t)in->B)) || (rc = h->nw_idx_buf.ensure(sizeof(int) * (2 * (size_t)in->B + 1)))) return rc;

@@ -169,6 +169,11 @@ extern "C" int po_polish_state_doubles(int form, int N, int C, int keep) {
     using namespace po;
     return form == F_KP ? po_polish_state_doubles_kp(N, C, keep) : (form == F_KPC ? po_polish_state_doubles_kpc(N, C, keep) : po_polish_state_doubles_k(N, form == F_K ? 0 : C, keep));
 }
+// threads per path of the shape this batch runs in (0: unsupported)
+extern "C" int po_shape_threads(int form, int N, int C, int keep) {
+    po::Shape s;
+    return po::resolve_shape(form, N, form == po::F_K ? 0 : C, keep, &s) ? s.nt : 0;
+}
 extern "C" int po_has_polish_kernel_kp(int N, int C, int keep);
 extern "C" int po_has_polish_kernel_kpc(int N, int C, int keep);
 extern "C" int po_has_polish_kernel_k(int N, int C, int keep);
