@@ -22,6 +22,7 @@
 static int g_portable_math = 0;
 void po_oracle_set_portable_math(int on) { g_portable_math = on != 0; }
 int po_oracle_get_portable_math(void) { return g_portable_math; }
+#define PO_NW_STAGNATION 8 /* full Newton steps on an unchanged factorisation that do not halve the dual residual, in a row, before the refinement gives a path up (see `nstag`) */
 static int g_refine_trace = 0; /* developer aid: one stderr line per refinement block and round (tools/refine_trace.py) */
 void po_oracle_set_refine_trace(int on) { g_refine_trace = on != 0; }
 static long long g_ls_evals = 0, g_nw_steps = 0; /* developer aid (tools/newton_eval.py): line-search evaluations and Newton steps since the last read; not thread-safe */
@@ -1221,6 +1222,13 @@ resume_main:
             double *w = (double *)malloc(sizeof(double) * (size_t)(m + 1)), *sv = (double *)malloc(sizeof(double) * (size_t)(m + 1));
             double *dv = (double *)malloc(sizeof(double) * (size_t)n), *Pd = (double *)malloc(sizeof(double) * (size_t)n);
             int first_fac = 1, nouter = 0, fail = 0, certified = 0, nfinal = 0;
+            /* STAGNATION (round 5): `quiet` = the last step took the full step on an unchanged factorisation — the situation in which Newton's method converges quadratically; a dual
+             * residual that does not even halve over PO_NW_STAGNATION such steps in a row sits on a floor the method cannot get under (the rounding of rho_eq (a.x - b) under extreme
+             * weights, or a flat valley damped by the proximal terms): the ATTEMPT ends, uncertified, like one that ran out of steps — and the rounds go on as they do then (the
+             * type-based iteration at a tighter eps, another attempt).  Without it such an attempt burns its whole budget (refine_newton_max = 300 steps) in every round: one such
+             * path held its batch for ~80 ms. */
+            int nstag = 0, quiet = 0;
+            double rd_prev = -1.0;
             csc_mv(n, m, Ap0, Ai0, Ax, x, Axv);
             for (int i = 0; i < m; ++i) w[i] = Axv[i] + (ctype[i] == 0 ? y[i] / rb_in : (ctype[i] == 1 ? y[i] / rb_eq : 0.0));
             for (;;) {
@@ -1249,12 +1257,15 @@ resume_main:
                 /* (round 5) the test is re-evaluated on EVERY point, the ones the correction steps produce included: `stop` is only ever true for a point that passes
                  * it, so status_refine = 1 always describes the point that is returned.  A correction step that leaves the test's region (a step that changes the
                  * active set can land with a larger dual residual) takes the path back to the regular iteration — multiplier updates and all — until it is certified again */
+                if (quiet && rd_prev >= 0.0 && dua_res > 0.5 * rd_prev) ++nstag; else nstag = 0;
+                rd_prev = dua_res;
                 if (stop) {
                     if (prm->refine_newton_final <= 0 || dua_res < 1e-3 * tol_d || nfinal >= prm->refine_newton_final) break;
                     certified = 1;
                 } else {
                     certified = 0;
                     if (it2 >= cap_nw) break;
+                    if (nstag >= PO_NW_STAGNATION) break;
                 }
                 if (!certified && dual_ok) { /* the inner problem is solved: multiplier update, w <- A x + (w - clip(w)) */
                     if (++nouter > 50) break;
@@ -1272,6 +1283,7 @@ resume_main:
                     }
                     pri_outer = pri_res;
                     for (int i = 0; i < m; ++i) w[i] = Axv[i] + (ctype[i] == 1 ? ratio_eq : ratio) * (w[i] - z[i]);
+                    quiet = 0;
                     continue;
                 }
                 /* Newton step: rows outside their bounds at rho_i, the others at RHO_MIN (the matrix of refine = 1) */
@@ -1282,6 +1294,7 @@ resume_main:
                     const double r = ctype[i] == -1 ? OSQP_RHO_MIN : (ctype[i] == 1 ? rb_eq : (fabs(w[i] - z[i]) > 1e-15 * (1.0 + fabs(z[i])) ? rb_in : OSQP_RHO_MIN));
                     if (r != rho_vec[i]) { rho_vec[i] = r; changed = 1; }
                 }
+                quiet = !changed;
                 if (changed) {
                     for (int i = 0; i < m; ++i) { rho_inv[i] = 1.0 / rho_vec[i]; K.Kx[K.rho_pos[i]] = -rho_inv[i]; }
                     if (ldl_numeric(&F, K.Kp, K.Ki, K.Kx)) { free(w); free(sv); free(dv); free(Pd); free(snap); rc = PO_ERR_INVALID; goto done; }
@@ -1331,6 +1344,7 @@ resume_main:
                 for (int i = 0; i < m; ++i) w[i] += t * sv[i];
                 ++it2;
                 if (certified) ++nfinal;
+                quiet = quiet && t == 1.0;
             }
             free(w); free(sv); free(dv); free(Pd);
         }

@@ -372,3 +372,54 @@ def test_sliced_newton_launches_change_nothing_but_the_schedule(case):
         assert np.abs(out[sl][1]["iters"] - out[0][1]["iters"]).max() <= 3 and (out[sl][1]["iters"] != out[0][1]["iters"]).mean() <= 0.05
     if case != "c3_ragged":  # (config-3 paths cut short at a random point: 14 of 333 go through the fallback rounds — the parked / resumed state feeds those as well)
         assert (out[0][1]["status_refine"] == 1).all()
+
+
+def _fuzz_case_at_headline(make_params, seed):
+    """The random case `seed` of tests/test_gpu_fuzz.py at the headline setting (same draws as test_random_case_newton_matches_oracle)."""
+    import np_twin as T
+    import test_gpu_fuzz as F
+    from path_optimizer_amd import binding
+
+    rng, form, b = F._case(seed)
+    if form == T.PO_KP:
+        b.keep = binding.keep_control_steps(form, b.ref_s[0])
+    p = F._params(rng, make_params)
+    if seed % 3 == 0:
+        b.bounds = b.bounds * float(rng.choice([0.5, 0.7]))
+    chain = int(rng.choice([2, 3]))
+    for k, v in NEWTON.items():
+        setattr(p, k, v)
+    p.refine_chain = chain
+    return b, p
+
+
+def test_oracle_a_stagnating_attempt_gives_up_after_a_few_steps(oracle):
+    """Cases 250 (KPC) and 214 (KP, keep 1) of the wider fuzz sweep (tools/fuzz_more.py): one path's dual residual sits on a floor above refine_eps (slack weights of 1e5 put the
+    rounding of rho_eq (a.x - b) there; a flat valley damped by the proximal terms) while every step is a full step on an unchanged factorisation.  Such an attempt used to burn its
+    300 steps in each of six rounds (2 275 / 5 800 iterations, ~80 ms of a device batch); now it ends after 8 stagnant steps: the path stays SOLVED and flagged -1, the others certified."""
+    b, p = _fuzz_case_at_headline(oracle.default_params, 250)
+    _, info, _ = oracle.solve_batch(b, oracle.device_equivalent_params(p), want_x=True)
+    assert (info["status"] == 1).all() and list(info["status_refine"]) == [1, 1, -1, 1, 1]
+    assert info["iters"][2] < 700 and info["iters"][[0, 1, 3, 4]].max() < 80
+    b, p = _fuzz_case_at_headline(oracle.default_params, 214)
+    _, info, _ = oracle.solve_batch(b, oracle.device_equivalent_params(p), want_x=True)
+    assert (info["status"] == 1).all() and list(info["status_refine"]) == [-1, -1, 1, -1, 1]
+    assert info["iters"][1] < 400 and info["iters"][3] < 400  # (2 275 each before; path 0's 4 096 are type-based iterations of the rounds)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [250, 214])
+def test_device_stagnating_attempt_matches_the_oracle(oracle, seed):
+    from path_optimizer_amd import binding
+
+    b, p = _fuzz_case_at_headline(binding.default_params, seed)
+    bo, po = _fuzz_case_at_headline(oracle.default_params, seed)
+    st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
+    _, oinfo, oxs = oracle.solve_batch(bo, oracle.device_equivalent_params(po), want_x=True)
+    assert np.array_equal(info["status"], oinfo["status"]) and np.array_equal(info["status_refine"], oinfo["status_refine"])
+    cert = info["status_refine"] == 1
+    assert (np.abs(info["iters"].astype(int) - oinfo["iters"])[cert] <= 3).all(), (info["iters"], oinfo["iters"])
+    # a path on a rounding floor: which round's attempt stagnates when is decided by noise — the outcome (SOLVED, flagged -1) is the same, the iteration count of the same order,
+    # and far below what the unguarded attempts burned (2 275 / 5 800)
+    assert (info["iters"][~cert] <= 2 * oinfo["iters"][~cert] + 100).all() and info["iters"].max() < 4500, (info["iters"], oinfo["iters"])
+    assert np.abs(xs - oxs)[cert].max() < 1e-5
