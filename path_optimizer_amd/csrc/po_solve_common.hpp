@@ -157,7 +157,10 @@ template <int F> inline bool has_uni_variant(const Shape &s) { return s.two && (
 #ifndef PO_DEV_NWX
 #define PO_DEV_NWX 1
 #endif
-#define PO_TWO_SHAPES(X) if (s.spl == PO_DEV_SPL && s.nt == 64 && s.nwx == PO_DEV_NWX) X(PO_DEV_SPL, 64, PO_DEV_NWX);
+#ifndef PO_DEV_NT
+#define PO_DEV_NT 64
+#endif
+#define PO_TWO_SHAPES(X) if (s.spl == PO_DEV_SPL && s.nt == PO_DEV_NT && s.nwx == PO_DEV_NWX) X(PO_DEV_SPL, PO_DEV_NT, PO_DEV_NWX);
 #else
 // (KP: keep 1 / 2 multi-group (4, ., 4 / 5), keep 3 / 4 / 5 one lane per chunk, keep 6 / 7 / 8 role-split; KPC: keep 4; K: 2 or 4 stages per lane)
 #define PO_TWO_SHAPES(X)                                                                                                            \
