@@ -83,3 +83,4 @@ def test_inline_dpp_fmacs_of_the_tension_solve_have_their_wait_states():
 
     total, findings = check()
     assert total >= 100 and not findings, (total, findings[:3])
+    assert check.led * 9 == total, (check.led, total)  # one wait-state-carrying FMAC per product of nine (bandwidth W = 9)

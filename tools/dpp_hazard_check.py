@@ -30,12 +30,17 @@ def check(hipcc="/opt/rocm/bin/hipcc"):
                 w = (int(mm.group(1)), int(mm.group(2))) if mm.group(1) else (int(mm.group(3)), int(mm.group(3)))
                 if not (w[1] < src[0] or w[0] > src[1]):
                     findings.append((l, p))
+    #  every PRODUCT — W = 9 DPP FMACs into one accumulator — starts with the FMAC that carries the wait states: as many `s_nop 4`-led FMACs as products
+    led = sum(1 for k, l in enumerate(ins) if l.startswith("v_fmac_f64_dpp") and ins[k - 1].startswith("s_nop 4"))
+    check.led = led
     return total, findings
 
 
 if __name__ == "__main__":
     total, findings = check()
-    print("v_fmac_f64_dpp:", total, "unprotected:", len(findings))
+    print("v_fmac_f64_dpp:", total, "unprotected:", len(findings), "products led by s_nop 4:", check.led, "of", total // 9)
+    if check.led * 9 != total:
+        sys.exit(1)
     for f in findings:
         print("  ", f)
     sys.exit(1 if findings or total == 0 else 0)
