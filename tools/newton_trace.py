@@ -1,5 +1,5 @@
 """Dev tool (GPU box): one path of a golden set through a PO_NW_TRACE build of the Newton kernel (csrc: `make dev DEVFLAGS=-DPO_NW_TRACE TAG=_tr`,
-then PO_LIB=path_optimizer_amd/libpo_hip_dev_tr.so python tools/_tr_dev.py c3 <path> <batch>): prints the per-step trace and the cycle counters of path 0; compare with the oracle's
+then PO_LIB=path_optimizer_amd/libpo_hip_dev_tr.so python tools/newton_trace.py c3 <path> <batch>): prints the per-step trace and the cycle counters of path 0; compare with the oracle's
 po_oracle_set_refine_trace(1)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
