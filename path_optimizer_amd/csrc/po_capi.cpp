@@ -425,7 +425,7 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
         HIP_TRY(hipEventRecord(h->evp[0], h->stream));
         D.fb_list = static_cast<int *>(h->fb_buf.p);
         HIP_TRY(hipMemsetAsync(D.fb_list, 0, sizeof(int), h->stream));
-        // SLICED LAUNCHES (engine-internal scheduling; DESIGN.md section 10): the Newton launch is two — every path for nw_slice steps, the unfinished ones parked with a
+        // SLICED LAUNCHES (engine-internal scheduling; DESIGN.md section 11): the Newton launch is two — every path for nw_slice steps, the unfinished ones parked with a
         // priority key; a one-workgroup sort; the parked paths in order of expected remaining work, longest first.  One launch in engine order ends on a tail of a few
         // long paths (30 % of it on BASELINE config 3).  The operations and their order are unchanged: statuses and certificates do not depend on the slicing, solutions agree to round-off.
         // Left alone the engine slices where it was measured to pay: one wave per path (NT = 64: 4 x CUs paths at a time) and at least two rounds of them — BASELINE config 3
