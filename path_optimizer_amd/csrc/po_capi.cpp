@@ -432,10 +432,15 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
         // 4.76 -> 4.06 ms, K 5.41 -> 4.85, keep 8 6.15 -> 5.75, 2 048 paths of config 3 2.62 -> 2.53; two-wave shapes gain or lose 1 % (keep 2 / 3) or lose 10 % (KPC at N = 400:
         // eight rounds, the re-entry of a 2 x 36 KB state per path), a batch of one round has no queueing tail to remove (config 2: + 10 % for the re-entry).
         const bool slice_auto = in->B >= 2 * h->wave_slots && po_shape_threads(in->formulation, in->N, C, in->keep) == 64;
-        const int pd = (h->nw_slice > 0 && (slice_auto || h->nw_slice_forced)) ? po_newton_park_doubles(in->formulation, in->N, C, in->keep) : 0;
+        int pd = (h->nw_slice > 0 && (slice_auto || h->nw_slice_forced)) ? po_newton_park_doubles(in->formulation, in->N, C, in->keep) : 0;
+        // (the parking blocks are 39 KB per path on top of the state block: a batch they do not fit beside is solved unsliced — scheduling is not worth an out-of-memory error)
+        if (pd > 0 && (h->nw_state_buf.ensure(sizeof(double) * (size_t)pd * (size_t)in->B) || h->nw_idx_buf.ensure(sizeof(int) * (2 * (size_t)in->B + 1)))) {
+            (void)hipGetLastError();
+            h->nw_state_buf.release();
+            pd = 0;
+        }
         h->nw_last_B = pd > 0 ? in->B : 0;
         if (pd > 0) {
-            if ((rc = h->nw_state_buf.ensure(sizeof(double) * (size_t)pd * (size_t)in->B)) || (rc = h->nw_idx_buf.ensure(sizeof(int) * (2 * (size_t)in->B + 1)))) return rc;
             D.nw_state = static_cast<double *>(h->nw_state_buf.p); D.nw_stride = pd;
             D.nw_keys = static_cast<int *>(h->nw_idx_buf.p); D.nw_list = D.nw_keys + in->B;
             P.ref_nw_slice = h->nw_slice;
