@@ -88,15 +88,27 @@ PO_DECLP(po_launch_polish_kp); PO_DECLP(po_launch_polish_kpc); PO_DECLP(po_launc
 #define PO_DECLP(name) extern "C" hipError_t name(const po::DevBatch *in, const po::DevParams *P, hipStream_t st)
 PO_DECLP(po_launch_newton_kp); PO_DECLP(po_launch_newton_kpc); PO_DECLP(po_launch_newton_k);
 PO_DECLP(po_launch_newton_kp_fb); PO_DECLP(po_launch_newton_kpc_fb); PO_DECLP(po_launch_newton_k_fb);
+PO_DECLP(po_launch_newton_kp_b); PO_DECLP(po_launch_newton_kp_b_fb);  // KP's role-split shapes (second Newton object)
+PO_DECLP(po_launch_newton_kp_c); PO_DECLP(po_launch_newton_kp_c_fb);  // KP's multi-group shapes (third)
 #undef PO_DECLP
 // the Newton refinement of round 0 as its own launch (po_params.refine = 2), and the fallback launch for what it hands back
 extern "C" hipError_t po_launch_newton(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st) {
     using namespace po;
-    return form == F_KP ? po_launch_newton_kp(in, P, st) : (form == F_KPC ? po_launch_newton_kpc(in, P, st) : po_launch_newton_k(in, P, st));
+    if (form == F_KP) {  // (an object answers hipErrorInvalidValue for a shape it does not hold)
+        hipError_t e = po_launch_newton_kp(in, P, st);
+        if (e == hipErrorInvalidValue) e = po_launch_newton_kp_b(in, P, st);
+        return e == hipErrorInvalidValue ? po_launch_newton_kp_c(in, P, st) : e;
+    }
+    return form == F_KPC ? po_launch_newton_kpc(in, P, st) : po_launch_newton_k(in, P, st);
 }
 extern "C" hipError_t po_launch_newton_fallback(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st) {
     using namespace po;
-    return form == F_KP ? po_launch_newton_kp_fb(in, P, st) : (form == F_KPC ? po_launch_newton_kpc_fb(in, P, st) : po_launch_newton_k_fb(in, P, st));
+    if (form == F_KP) {
+        hipError_t e = po_launch_newton_kp_fb(in, P, st);
+        if (e == hipErrorInvalidValue) e = po_launch_newton_kp_b_fb(in, P, st);
+        return e == hipErrorInvalidValue ? po_launch_newton_kp_c_fb(in, P, st) : e;
+    }
+    return form == F_KPC ? po_launch_newton_kpc_fb(in, P, st) : po_launch_newton_k_fb(in, P, st);
 }
 extern "C" int po_polish_state_doubles_kp(int N, int C, int keep);
 extern "C" int po_polish_state_doubles_kpc(int N, int C, int keep);

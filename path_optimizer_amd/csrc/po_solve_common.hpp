@@ -163,21 +163,45 @@ template <int F> inline bool has_uni_variant(const Shape &s) { return s.two && (
 #define PO_TWO_SHAPES(X) if (s.spl == PO_DEV_SPL && s.nt == PO_DEV_NT && s.nwx == PO_DEV_NWX) X(PO_DEV_SPL, PO_DEV_NT, PO_DEV_NWX);
 #else
 // (KP: keep 1 / 2 multi-group (4, ., 4 / 5), keep 3 / 4 / 5 one lane per chunk, keep 6 / 7 / 8 role-split; KPC: keep 4; K: 2 or 4 stages per lane)
-#define PO_TWO_SHAPES(X)                                                                                                            \
-    if constexpr (F == F_KP) {                                                                                                      \
+// -DPO_SHAPE_GROUP=1 / 2 / 3 (the Newton objects of KP, whose 15 shapes x 3 kernels were the 5-minute pole of the build): only the one-lane-per-chunk shapes / only the role-split
+// shapes / only the multi-group shapes; the dispatcher (po_kernels.hip) asks the objects in turn.  0: all of them (the solve objects).
+#ifndef PO_SHAPE_GROUP
+#define PO_SHAPE_GROUP 0
+#endif
+#if PO_SHAPE_GROUP == 0 || PO_SHAPE_GROUP == 1
+#define PO_KP_SHAPES_A(X)                                                                                                           \
         if (s.nwx == 1 && s.spl == 5) X(5, 64, 1);                                                                                  \
         if (s.nwx == 1 && s.spl == 3 && s.nt == 64) X(3, 64, 1); if (s.nwx == 1 && s.spl == 3) X(3, 128, 1);                        \
+        if (s.nwx == 1 && s.spl == 4 && s.nt == 64) X(4, 64, 1); if (s.nwx == 1 && s.spl == 4) X(4, 128, 1);
+#else
+#define PO_KP_SHAPES_A(X)
+#endif
+#if PO_SHAPE_GROUP == 0 || PO_SHAPE_GROUP == 3
+#define PO_KP_SHAPES_C(X)                                                                                                           \
         if (s.nwx == 4 && s.nt == 64) X(4, 64, 4); if (s.nwx == 4) X(4, 128, 4);                                                    \
-        if (s.nwx == 5 && s.nt == 64) X(4, 64, 5); if (s.nwx == 5) X(4, 128, 5);                                                    \
+        if (s.nwx == 5 && s.nt == 64) X(4, 64, 5); if (s.nwx == 5) X(4, 128, 5);
+#else
+#define PO_KP_SHAPES_C(X)
+#endif
+#if PO_SHAPE_GROUP == 0 || PO_SHAPE_GROUP == 2
+#define PO_KP_SHAPES_B(X)                                                                                                           \
         if (s.nwx == 2 && s.spl == 3 && s.nt == 64) X(3, 64, 2); if (s.nwx == 2 && s.spl == 3) X(3, 128, 2);                        \
         if (s.nwx == 2 && s.spl == 4 && s.nt == 64) X(4, 64, 2); if (s.nwx == 2 && s.spl == 4) X(4, 128, 2);                        \
-        if (s.nwx == 3 && s.spl == 4 && s.nt == 64) X(4, 64, 3); if (s.nwx == 3 && s.spl == 4) X(4, 128, 3);                        \
+        if (s.nwx == 3 && s.spl == 4 && s.nt == 64) X(4, 64, 3); if (s.nwx == 3 && s.spl == 4) X(4, 128, 3);
+#else
+#define PO_KP_SHAPES_B(X)
+#endif
+#define PO_TWO_SHAPES(X)                                                                                                            \
+    if constexpr (F == F_KP) {                                                                                                      \
+        PO_KP_SHAPES_A(X)                                                                                                           \
+        PO_KP_SHAPES_C(X)                                                                                                           \
+        PO_KP_SHAPES_B(X)                                                                                                           \
     }                                                                                                                               \
     if constexpr (F == F_K) {                                                                                                       \
         if (s.nwx == 1 && s.spl == 2 && s.nt == 64) X(2, 64, 1); if (s.nwx == 1 && s.spl == 2) X(2, 128, 1);                        \
     }                                                                                                                               \
-    if (s.nwx == 1) {                                                                                                               \
-        if (s.spl == 4 && s.nt == 64) X(4, 64, 1); if (s.spl == 4) X(4, 128, 1);                                                    \
+    if constexpr (F != F_KP) {                                                                                                      \
+        if (s.nwx == 1 && s.spl == 4 && s.nt == 64) X(4, 64, 1); if (s.nwx == 1 && s.spl == 4) X(4, 128, 1);                        \
     }
 #endif
 template <int F, bool UNI> hipError_t launch_form(const DevBatch *in_, const DevParams *P, hipStream_t st, size_t *lds_out) {
@@ -233,7 +257,8 @@ template <int F> inline int newton_park_doubles(int N, int C, int keep) {
 }
 // the Newton refinement of round 0 as its own launch (po_params.refine = 2): same shapes.  FB: the fallback launch behind it
 // (newton_fallback_kernel walks the work list of the paths newton_kernel handed back; a small fixed grid)
-template <int F, bool FB> hipError_t launch_newton(const DevBatch *in, const DevParams *P, hipStream_t st) {
+// (G: the object's shape group is part of the function's identity — three objects instantiate this template with three different bodies, and the linker would fold them into one)
+template <int F, bool FB, int G = PO_SHAPE_GROUP> hipError_t launch_newton(const DevBatch *in, const DevParams *P, hipStream_t st) {
     Shape s;
     if (!resolve_shape(F, in->N, in->C, in->keep, &s) || !s.two) return hipErrorInvalidValue;
     const size_t lds = lds_of(F, in->N, in->C, s);
