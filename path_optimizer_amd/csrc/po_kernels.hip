@@ -54,6 +54,7 @@ template <int F> __global__ __launch_bounds__(64) void assemble_kernel(DevBatch 
 // the solve kernels of one formulation and one loop variant live in their own object (po_solve_form.hip)
 #define PO_DECL(name) extern "C" hipError_t name(const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out)
 PO_DECL(po_launch_solve_kp); PO_DECL(po_launch_solve_kp_uni);
+PO_DECL(po_launch_solve_kp_w); PO_DECL(po_launch_solve_kp_w_uni);  // the wide role-split shapes of keep 9 .. 16 (objects of their own)
 PO_DECL(po_launch_solve_kpc); PO_DECL(po_launch_solve_kpc_uni);
 PO_DECL(po_launch_solve_k); PO_DECL(po_launch_solve_k_uni);
 #undef PO_DECL
@@ -71,7 +72,14 @@ __global__ void finalize_status_kernel(po_info *info, int B) {
 extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out) {
     using namespace po;
     hipError_t e;
-    if (form == F_KP) { e = po_launch_solve_kp_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kp(in, P, st, lds_out); }
+    if (form == F_KP) {
+        e = po_launch_solve_kp_uni(in, P, st, lds_out);
+        if (e == hipErrorInvalidValue) {  // not a shape of keep 1 .. 8: the wide objects
+            e = po_launch_solve_kp_w_uni(in, P, st, lds_out);
+            return e != hipSuccess ? e : po_launch_solve_kp_w(in, P, st, lds_out);
+        }
+        return e != hipSuccess ? e : po_launch_solve_kp(in, P, st, lds_out);
+    }
     if (form == F_KPC) { e = po_launch_solve_kpc_uni(in, P, st, lds_out); return e != hipSuccess ? e : po_launch_solve_kpc(in, P, st, lds_out); }
     e = po_launch_solve_k_uni(in, P, st, lds_out);
     return e != hipSuccess ? e : po_launch_solve_k(in, P, st, lds_out);
@@ -90,6 +98,7 @@ PO_DECLP(po_launch_newton_kp); PO_DECLP(po_launch_newton_kpc); PO_DECLP(po_launc
 PO_DECLP(po_launch_newton_kp_fb); PO_DECLP(po_launch_newton_kpc_fb); PO_DECLP(po_launch_newton_k_fb);
 PO_DECLP(po_launch_newton_kp_b); PO_DECLP(po_launch_newton_kp_b_fb);  // KP's role-split shapes (second Newton object)
 PO_DECLP(po_launch_newton_kp_c); PO_DECLP(po_launch_newton_kp_c_fb);  // KP's multi-group shapes (third)
+PO_DECLP(po_launch_newton_kp_w1); PO_DECLP(po_launch_newton_kp_w1_fb); PO_DECLP(po_launch_newton_kp_w2); PO_DECLP(po_launch_newton_kp_w2_fb); PO_DECLP(po_launch_newton_kp_w3); PO_DECLP(po_launch_newton_kp_w3_fb);  // keep 9 .. 16
 #undef PO_DECLP
 // the Newton refinement of round 0 as its own launch (po_params.refine = 2), and the fallback launch for what it hands back
 extern "C" hipError_t po_launch_newton(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st) {
@@ -97,7 +106,10 @@ extern "C" hipError_t po_launch_newton(int form, const po::DevBatch *in, const p
     if (form == F_KP) {  // (an object answers hipErrorInvalidValue for a shape it does not hold)
         hipError_t e = po_launch_newton_kp(in, P, st);
         if (e == hipErrorInvalidValue) e = po_launch_newton_kp_b(in, P, st);
-        return e == hipErrorInvalidValue ? po_launch_newton_kp_c(in, P, st) : e;
+        if (e == hipErrorInvalidValue) e = po_launch_newton_kp_c(in, P, st);
+        if (e == hipErrorInvalidValue) e = po_launch_newton_kp_w1(in, P, st);
+        if (e == hipErrorInvalidValue) e = po_launch_newton_kp_w2(in, P, st);
+        return e == hipErrorInvalidValue ? po_launch_newton_kp_w3(in, P, st) : e;
     }
     return form == F_KPC ? po_launch_newton_kpc(in, P, st) : po_launch_newton_k(in, P, st);
 }
@@ -106,7 +118,10 @@ extern "C" hipError_t po_launch_newton_fallback(int form, const po::DevBatch *in
     if (form == F_KP) {
         hipError_t e = po_launch_newton_kp_fb(in, P, st);
         if (e == hipErrorInvalidValue) e = po_launch_newton_kp_b_fb(in, P, st);
-        return e == hipErrorInvalidValue ? po_launch_newton_kp_c_fb(in, P, st) : e;
+        if (e == hipErrorInvalidValue) e = po_launch_newton_kp_c_fb(in, P, st);
+        if (e == hipErrorInvalidValue) e = po_launch_newton_kp_w1_fb(in, P, st);
+        if (e == hipErrorInvalidValue) e = po_launch_newton_kp_w2_fb(in, P, st);
+        return e == hipErrorInvalidValue ? po_launch_newton_kp_w3_fb(in, P, st) : e;
     }
     return form == F_KPC ? po_launch_newton_kpc_fb(in, P, st) : po_launch_newton_k_fb(in, P, st);
 }
@@ -119,11 +134,14 @@ extern "C" hipError_t po_launch_polish(int form, const po::DevBatch *in, const p
     return form == F_KP ? po_launch_polish_kp(in, P, st) : (form == F_KPC ? po_launch_polish_kpc(in, P, st) : po_launch_polish_k(in, P, st));
 }
 extern "C" int po_polish_state_doubles_kp_park(int N, int C, int keep);
+extern "C" int po_polish_state_doubles_kp_w(int N, int C, int keep);
+extern "C" int po_polish_state_doubles_kp_w_park(int N, int C, int keep);
 extern "C" int po_polish_state_doubles_kpc_park(int N, int C, int keep);
 extern "C" int po_polish_state_doubles_k_park(int N, int C, int keep);
 extern "C" int po_newton_park_doubles(int form, int N, int C, int keep) {
     using namespace po;
-    return form == F_KP ? po_polish_state_doubles_kp_park(N, C, keep) : (form == F_KPC ? po_polish_state_doubles_kpc_park(N, C, keep) : po_polish_state_doubles_k_park(N, form == F_K ? 0 : C, keep));
+    if (form == F_KP) { const int d = po_polish_state_doubles_kp_park(N, C, keep); return d ? d : po_polish_state_doubles_kp_w_park(N, C, keep); }
+    return form == F_KPC ? po_polish_state_doubles_kpc_park(N, C, keep) : po_polish_state_doubles_k_park(N, form == F_K ? 0 : C, keep);
 }
 namespace po {
 // the parked paths (keys[b] >= 0) in descending key order, ties in path order (a stable counting sort: deterministic): list[0] = count, list[1 ..] = path ids.
@@ -179,7 +197,8 @@ extern "C" hipError_t po_launch_nw_sort(const int *keys, int B, int *list, hipSt
 }
 extern "C" int po_polish_state_doubles(int form, int N, int C, int keep) {
     using namespace po;
-    return form == F_KP ? po_polish_state_doubles_kp(N, C, keep) : (form == F_KPC ? po_polish_state_doubles_kpc(N, C, keep) : po_polish_state_doubles_k(N, form == F_K ? 0 : C, keep));
+    if (form == F_KP) { const int d = po_polish_state_doubles_kp(N, C, keep); return d ? d : po_polish_state_doubles_kp_w(N, C, keep); }
+    return form == F_KPC ? po_polish_state_doubles_kpc(N, C, keep) : po_polish_state_doubles_k(N, form == F_K ? 0 : C, keep);
 }
 // threads per path of the shape this batch runs in (0: unsupported)
 extern "C" int po_shape_threads(int form, int N, int C, int keep) {

@@ -111,12 +111,14 @@ inline bool pick_shape(int form, int N, int C, int keep, Shape *s) {
     const bool no_u = (form == F_K);
     if (no_u) C = 0;  // K has no held controls: its N-1 steering variables live inside the nodes
     // two-level path; keep 1..8 covers what the reference produces (spacing 0.15..1.0 m, path_optimizer.cpp:171-172); KPC is keep == 4 only.
-    const int keep_max = form == F_KP ? 8 : 4;
+    // keep 9 .. 16 (finer references than the reference's own pipeline produces; VERDICT r4 "missing 3"): the role-split mapping with 5 .. 8 stages per lane, one wave
+    // (N <= 32 keep); beyond that the single-level chain as before.
+    const int keep_max = form == F_KP ? 16 : 4;
     if (no_u || (keep >= 1 && keep <= keep_max)) {
         if (!no_u && keep >= 6) {
             const int spl = (keep + 1) / 2, chunks = (N + keep - 1) / keep;
             if (chunks <= 32) { *s = {64, spl, true, 2 + (keep & 1)}; return true; }
-            if (chunks <= 64) { *s = {128, spl, true, 2 + (keep & 1)}; return true; }
+            if (chunks <= 64 && keep <= 8) { *s = {128, spl, true, 2 + (keep & 1)}; return true; }
         } else {
             // keep 1 / 2 (KP): MULTI-GROUP mapping — four stages per lane holding 4 / 2 whole control groups (nwx 4 / 5): keep 1 at N = 200 on 50 lanes instead of 200
             if (form == F_KP && (keep == 1 || keep == 2)) {
@@ -150,6 +152,9 @@ inline bool resolve_shape(int form, int N, int C, int keep, Shape *s) {
 // UNI = true: the uniform-row-class variant of the two-level kernels (no-op for shapes that use the single-level mapping and for K on multi-wave blocks); UNI = false: the general variant.  po_launch_solve issues them in this order on one stream.
 template <int F> inline bool has_uni_variant(const Shape &s) { return s.two && (F != F_K || s.nt == 64); }  // K: one-wave blocks only (Fast::classify)
 // the shapes of the two-level mapping that are instantiated: X(SPL, NT, NWX)
+#ifndef PO_SHAPE_GROUP
+#define PO_SHAPE_GROUP 0
+#endif
 #ifdef PO_DEV_HEADLINE  // dev builds: only the BASELINE config-3 variant (seconds to compile); -DPO_DEV_SPL=k -DPO_DEV_NWX=x: that one-wave variant instead
 #ifndef PO_DEV_SPL
 #define PO_DEV_SPL 4
@@ -163,11 +168,9 @@ template <int F> inline bool has_uni_variant(const Shape &s) { return s.two && (
 #define PO_TWO_SHAPES(X) if (s.spl == PO_DEV_SPL && s.nt == PO_DEV_NT && s.nwx == PO_DEV_NWX) X(PO_DEV_SPL, PO_DEV_NT, PO_DEV_NWX);
 #else
 // (KP: keep 1 / 2 multi-group (4, ., 4 / 5), keep 3 / 4 / 5 one lane per chunk, keep 6 / 7 / 8 role-split; KPC: keep 4; K: 2 or 4 stages per lane)
-// -DPO_SHAPE_GROUP=1 / 2 / 3 (the Newton objects of KP, whose 15 shapes x 3 kernels were the 5-minute pole of the build): only the one-lane-per-chunk shapes / only the role-split
-// shapes / only the multi-group shapes; the dispatcher (po_kernels.hip) asks the objects in turn.  0: all of them (the solve objects).
-#ifndef PO_SHAPE_GROUP
-#define PO_SHAPE_GROUP 0
-#endif
+// -DPO_SHAPE_GROUP: which of KP's shapes an object holds (the dispatcher in po_kernels.hip asks the objects in turn; an object answers hipErrorInvalidValue / 0 for a shape it does not hold).
+//   0  the shapes of keep 1 .. 8 (the solve objects);  1 / 2 / 3  of those only one lane per chunk / role-split / multi-group (the Newton objects: as ONE object their 15 shapes x 3
+//   kernels were the 5-minute pole of the build);  7  the WIDE role-split shapes of keep 9 .. 16 (5 .. 8 stages per lane; solve objects `_w`);  4 / 5 / 6  of those only SPL 5, 6 / 7 / 8.
 #if PO_SHAPE_GROUP == 0 || PO_SHAPE_GROUP == 1
 #define PO_KP_SHAPES_A(X)                                                                                                           \
         if (s.nwx == 1 && s.spl == 5) X(5, 64, 1);                                                                                  \
@@ -191,11 +194,28 @@ template <int F> inline bool has_uni_variant(const Shape &s) { return s.two && (
 #else
 #define PO_KP_SHAPES_B(X)
 #endif
+#define PO_WIDE_SPL(X, S_) if (s.nwx == 2 && s.spl == S_ && s.nt == 64) X(S_, 64, 2); if (s.nwx == 3 && s.spl == S_ && s.nt == 64) X(S_, 64, 3);
+#if PO_SHAPE_GROUP == 7 || PO_SHAPE_GROUP == 4
+#define PO_KP_SHAPES_W1(X) PO_WIDE_SPL(X, 5) PO_WIDE_SPL(X, 6)
+#else
+#define PO_KP_SHAPES_W1(X)
+#endif
+#if PO_SHAPE_GROUP == 7 || PO_SHAPE_GROUP == 5
+#define PO_KP_SHAPES_W2(X) PO_WIDE_SPL(X, 7)
+#else
+#define PO_KP_SHAPES_W2(X)
+#endif
+#if PO_SHAPE_GROUP == 7 || PO_SHAPE_GROUP == 6
+#define PO_KP_SHAPES_W3(X) PO_WIDE_SPL(X, 8)
+#else
+#define PO_KP_SHAPES_W3(X)
+#endif
 #define PO_TWO_SHAPES(X)                                                                                                            \
     if constexpr (F == F_KP) {                                                                                                      \
         PO_KP_SHAPES_A(X)                                                                                                           \
         PO_KP_SHAPES_C(X)                                                                                                           \
         PO_KP_SHAPES_B(X)                                                                                                           \
+        PO_KP_SHAPES_W1(X) PO_KP_SHAPES_W2(X) PO_KP_SHAPES_W3(X)                                                                    \
     }                                                                                                                               \
     if constexpr (F == F_K) {                                                                                                       \
         if (s.nwx == 1 && s.spl == 2 && s.nt == 64) X(2, 64, 1); if (s.nwx == 1 && s.spl == 2) X(2, 128, 1);                        \
@@ -204,7 +224,7 @@ template <int F> inline bool has_uni_variant(const Shape &s) { return s.two && (
         if (s.nwx == 1 && s.spl == 4 && s.nt == 64) X(4, 64, 1); if (s.nwx == 1 && s.spl == 4) X(4, 128, 1);                        \
     }
 #endif
-template <int F, bool UNI> hipError_t launch_form(const DevBatch *in_, const DevParams *P, hipStream_t st, size_t *lds_out) {
+template <int F, bool UNI, int G = PO_SHAPE_GROUP> hipError_t launch_form(const DevBatch *in_, const DevParams *P, hipStream_t st, size_t *lds_out) {
     Shape s;
     if (!resolve_shape(F, in_->N, in_->C, in_->keep, &s)) return hipErrorInvalidValue;
     const size_t lds = lds_of(F, in_->N, in_->C, s);
@@ -222,7 +242,7 @@ template <int F, bool UNI> hipError_t launch_form(const DevBatch *in_, const Dev
 #undef PO_L
         return hipErrorInvalidValue;
     }
-#ifndef PO_DEV_HEADLINE
+#if !defined(PO_DEV_HEADLINE) && PO_SHAPE_GROUP == 0  // (the single-level mapping lives in the objects of the keep 1 .. 8 shapes)
     if constexpr (!UNI) {
 #define PO_L1(SPL_, NT_) return launch1(&solve_kernel_fast<F, SPL_, NT_, false, false, 1>, in, P, NT_, lds, st)
         if (s.nt == 64 && s.spl == 2) PO_L1(2, 64);
@@ -238,7 +258,7 @@ template <int F, bool UNI> hipError_t launch_form(const DevBatch *in_, const Dev
 // ---- state block / polish (po_params.polish): same shape as the solve launch; two-level shapes only (every case the reference produces) ----
 template <int F, int SPL_, int NT_, int NWX_> inline int state_doubles_of() { return Fast<F, SPL_, NT_, true, NWX_>::kStateDoubles * NT_; }
 // doubles per path of the state block the solve kernels leave for the Newton refinement and the polish (0: shape without either: the single-level mapping)
-template <int F> inline int polish_state_doubles(int N, int C, int keep) {
+template <int F, int G = PO_SHAPE_GROUP> inline int polish_state_doubles(int N, int C, int keep) {
     Shape s;
     if (!resolve_shape(F, N, C, keep, &s) || !s.two) return 0;
 #define PO_X(SPL_, NT_, NWX_) return state_doubles_of<F, SPL_, NT_, NWX_>()
@@ -247,7 +267,7 @@ template <int F> inline int polish_state_doubles(int N, int C, int keep) {
     return 0;
 }
 // doubles per path of the block a PARKED Newton path lives in between the two sliced launches (Fast::park_io + kNwParkScalars)
-template <int F> inline int newton_park_doubles(int N, int C, int keep) {
+template <int F, int G = PO_SHAPE_GROUP> inline int newton_park_doubles(int N, int C, int keep) {
     Shape s;
     if (!resolve_shape(F, N, C, keep, &s) || !s.two) return 0;
 #define PO_X(SPL_, NT_, NWX_) return Fast<F, SPL_, NT_, true, NWX_>::kParkDoubles * NT_ + kNwParkScalars
@@ -273,7 +293,7 @@ template <int F> inline bool has_polish_kernel(int N, int C, int keep) {
     Shape s;
     return resolve_shape(F, N, C, keep, &s) && s.two && s.nwx != 2 && s.nwx != 3;
 }
-template <int F> hipError_t launch_polish(const DevBatch *in, const DevParams *P, hipStream_t st) {
+template <int F, int G = PO_SHAPE_GROUP> hipError_t launch_polish(const DevBatch *in, const DevParams *P, hipStream_t st) {
     Shape s;
     if (!resolve_shape(F, in->N, in->C, in->keep, &s) || !s.two) return hipErrorInvalidValue;
     if (s.nwx == 2 || s.nwx == 3) return hipSuccess;

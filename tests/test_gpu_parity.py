@@ -200,13 +200,13 @@ def test_keep_quirk_and_ragged_sizes(binding, oracle):
         assert np.abs(xs - oxs).max() < 1e-8, (N, ds, np.abs(xs - oxs).max())
 
 
-@pytest.mark.parametrize("keep", [1, 2, 3, 4, 5, 6, 7, 8, 9, 12])
+@pytest.mark.parametrize("keep", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 20])
 def test_every_keep_control_steps_value(binding, oracle, keep):
     """keep_control_steps_ = int(1.2 / spacing) takes every value 1..8 in the reference's own pipeline (spacing 0.15..1.0 m,
-    path_optimizer.cpp:171-172); larger values through the API.  Fixed-iteration iterates, then the full run (termination,
-    adaptive rho, infeasibility certificate) against the oracle, for sizes that are / are not multiples of keep."""
+    path_optimizer.cpp:171-172); larger values through the API (9 .. 16: the wide role-split shapes, N <= 32 keep; beyond: the single-level chain).
+    Fixed-iteration iterates, then the full run (termination, adaptive rho, infeasibility certificate) against the oracle, for sizes that are / are not multiples of keep."""
     ds = 1.2 / keep * 0.999
-    for N in (keep + 2, 41, 97 if keep == 1 else 150):
+    for N in (keep + 2, 41, 97 if keep == 1 else 150) + ((32 * keep - 1, 32 * keep + 1) if 9 <= keep <= 12 else ()):  # (9 .. 12: either side of the one-wave limit of the wide shapes)
         b = _rand_batch(T.PO_KP, 3, N, ds=ds, seed=keep * 100 + N, narrow=True)
         b.keep = keep
         assert binding.keep_control_steps(T.PO_KP, b.ref_s[0]) == keep

@@ -164,9 +164,10 @@ def test_device_newton_ragged_and_mixed_batches(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("keep,N,ds", [(1, 60, 1.0), (2, 128, 0.5), (3, 101, 0.3), (3, 190, 0.3), (4, 90, 0.25), (5, 100, 0.22), (6, 100, 0.19), (7, 100, 0.165), (8, 120, 0.149), (8, 200, 0.149)])
+@pytest.mark.parametrize("keep,N,ds", [(1, 60, 1.0), (2, 128, 0.5), (3, 101, 0.3), (3, 190, 0.3), (4, 90, 0.25), (5, 100, 0.22), (6, 100, 0.19), (7, 100, 0.165), (8, 120, 0.149), (8, 200, 0.149),
+                                         (9, 150, 0.133), (10, 150, 0.1199), (11, 120, 0.109), (12, 200, 0.0999), (13, 100, 0.0922), (14, 150, 0.0856), (15, 121, 0.0799), (16, 200, 0.0749)])
 def test_device_newton_every_keep_value_matches_oracle(oracle, keep, N, ds):
-    """Every chunk shape of the one-wave / two-wave mappings (keep_control_steps_ 1 .. 8: what the reference's pipeline produces) through the Newton refinement —
+    """Every chunk shape of the one-wave / two-wave mappings (keep_control_steps_ 1 .. 8: what the reference's pipeline produces; 9 .. 16: the wide role-split shapes) through the Newton refinement —
     a factorisation per step under penalties of 1e3 .. 1e5 — uniform and pinned-row (general kernel) batches; every path certified, the same point as the oracle."""
     import np_twin as T
     from path_optimizer_amd import binding, synth

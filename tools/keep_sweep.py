@@ -17,7 +17,7 @@ def rand_batch(B, N, ds, seed):
     st = lambda k: np.ascontiguousarray(np.stack([i[k] for i in insts]))
     return synth.Batch(0, B, N, 4, st("ref_x"), st("ref_y"), st("ref_z"), st("ref_k"), st("ref_s"), st("bounds"), st("x0"), np.array([i["goal_z"] for i in insts]))
 out = []
-for keep, N in [(1, 100), (1, 200), (2, 200), (3, 200), (4, 200), (5, 200), (6, 200), (7, 200), (8, 200), (9, 200), (12, 200)]:
+for keep, N in [(1, 100), (1, 200), (2, 200), (3, 200), (4, 200), (5, 200), (6, 200), (7, 200), (8, 200), (9, 200), (10, 200), (12, 200), (14, 200), (16, 200), (17, 200)]:
     b = rand_batch(256, N, 1.2 / keep * 0.999, keep)
     b.keep = keep
     b = synth.replicate(b, 4096)
