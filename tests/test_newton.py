@@ -325,7 +325,7 @@ def test_device_status_refine_says_what_was_certified(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["c3", "c3_ragged", "keep2", "keep6", "keep7", "c5", "k", "tiny"])
+@pytest.mark.parametrize("case", ["c3", "c3_ragged", "keep2", "keep6", "keep7", "keep12", "keep15", "c5", "k", "tiny"])
 def test_sliced_newton_launches_change_nothing_but_the_schedule(case):
     """The engine issues the Newton refinement as TWO launches (every path for 8 steps; the unfinished ones parked, sorted by expected remaining work, resumed longest
     first — po_debug_set "newton_slice").  Parking and resuming keep every number the phase carries: statuses and certificates are those of the single launch, the solutions
