@@ -289,4 +289,10 @@ def kkt_certificate(P, A, l, u, x, act_tol=1e-6):
     cn[cn == 0] = 1.0
     res = lsq_linear(At @ sp.diags(1.0 / cn), -g, bounds=(lb, ub), method="trf", tol=1e-13, lsmr_tol="auto", max_iter=400)
     r = float(np.abs(At @ (res.x / cn) + g).max())
+    if r > 1e-9 * max(1.0, float(np.abs(g).max())) and At.shape[0] * At.shape[1] <= 4_000_000:
+        # the iterative (LSMR) inner solver may stop short on ill-conditioned row sets (one control held over a whole short path: found by tools/fuzz_wide.py, 1.8e-3 where the exact
+        # solve gives 4e-14): settle it with the dense exact solver
+        Ad = (At @ sp.diags(1.0 / cn)).toarray()
+        res = lsq_linear(Ad, -g, bounds=(lb, ub), method="bvls", tol=1e-15, max_iter=5000)
+        r = min(r, float(np.abs(At @ (res.x / cn) + g).max()))
     return dict(primal_violation=viol, stationarity=r, stationarity_rel=r / max(1.0, float(np.abs(g).max())), n_active=int(rows.size))
