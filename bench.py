@@ -5,8 +5,13 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (equilibration + assembly + factorisation + ADMM to eps 1e-4 + output map) over one batch of
-synthetic planning instances already resident in HBM:
+`--gpus N` MEANS N GPUs: started without torchrun and N > 1, the script re-runs itself under `torch.distributed.run --nproc-per-node N`; started
+under torchrun with WORLD_SIZE != N it exits non-zero; the printed line is refused unless N ranks answered.
+
+A "step" is one pass of the hot path over one batch of synthetic planning instances already resident in HBM, at the HEADLINE setting:
+equilibration + assembly + 25 ADMM iterations (the warm start) + the semismooth-Newton refinement of every path (factorisation, solve, line
+search per step; 13.9 steps on average on config 3), certified at OSQP's termination test with eps 1e-8 — hence also at the metric's 1e-4 —
++ output map.  The OSQP-faithful solve ("ADMM to eps 1e-4", what the metric's words describe) is timed beside it: `value_osqp_faithful`.
   N=1   BASELINE config 3: B=4096 paths, N=200 points, KP, per-path random obstacle clearances
   N>1   BASELINE config 4: the same generator, 4096 paths per GPU (contiguous shard of path ids), no data-path collective
         (paths are independent); RCCL carries the barrier, the reduction of a few statistics and (--gather) the result gather.
@@ -699,6 +704,25 @@ def main():
                     "assembly of the N>1 branch (tests/test_multi_process.py)")
     args = ap.parse_args()
 
+    # --gpus N means N GPUs.  Started WITHOUT torchrun (no WORLD_SIZE in the environment) and N > 1: re-run this very command under
+    # `python -m torch.distributed.run --nproc-per-node N` (one process per GPU, rendezvous on 127.0.0.1) and hand its exit code back.  Started
+    # under torchrun with a world that is not N: refuse — a line labelled n_gpus = world for a command that asked for N would be a wrong record.
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1 and not args.traffic_child:
+            import socket
+            import subprocess
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: launch with --nproc-per-node {args.gpus}")
+
     import torch
 
     if args.traffic_child:  # profiled by live_traffic(): three solves of the batch at the headline setting, nothing else
@@ -817,6 +841,8 @@ def main():
         me = {"rank": rank, "local_rank": local_rank, "device": "dry-run (cpu)" if dry else torch.cuda.get_device_name(local_rank), "paths": [lo, hi], "elapsed_s": elapsed}
         dist.all_gather_object(names, me)
         ranks_seen = {"backend": dist.get_backend(), "world": world, "rccl_ranks_seen": len([n for n in names if n is not None]), "ranks": names}
+        if ranks_seen["rccl_ranks_seen"] != args.gpus or sorted(n["rank"] for n in names if n is not None) != list(range(args.gpus)):
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the ranks that answered are {ranks_seen}")
 
     out, details = None, {}
     if rank == 0:

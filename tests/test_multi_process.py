@@ -93,3 +93,32 @@ def test_bench_n_gt_1_branch_dry_run():
     assert [r["rank"] for r in rk["ranks"]] == [0, 1] and [r["paths"] for r in rk["ranks"]] == [[0, 96], [96, 192]]
     g = d["gather"]
     assert g["paths_on_root"] == 192 and g["iters_sum_on_root"] == float(it.sum()) and g["path_ids_in_order"] is True
+
+
+def test_bench_gpus_flag_means_n_gpus_without_torchrun():
+    """`python bench.py --gpus 2 --dry-run` started WITHOUT torchrun (the shape of the driver's N = 1 command): the script re-runs itself under
+    torch.distributed.run with two ranks — n_gpus 2, two ranks seen, contiguous path ranges [0, B), [B, 2B) (the flag used to be ignored)."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    rk = d["config"]["ranks"]
+    assert d["n_gpus"] == 2 and rk["world"] == 2 and rk["rccl_ranks_seen"] == 2
+    assert [q["paths"] for q in rk["ranks"]] == [[0, 64], [64, 128]]
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """Under torchrun with WORLD_SIZE != --gpus the bench exits non-zero instead of printing a line labelled with the wrong GPU count."""
+    import subprocess
+
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "8", "--dry-run"],
+                       capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
