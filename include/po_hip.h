@@ -105,7 +105,8 @@ typedef struct po_params {
     int    enable_exact_position;       /* FLAGS_enable_exact_position (false): goal-trim search step 0.1 m instead of 0.5 m (path_optimizer.cpp:151) */
     int    polish;                      /* OSQP `polish` (0 = off: OSQP's default, which the reference never changes).  1: after a path is solved, the reduced
                                            KKT system on the active set is solved with the regularisation `polish_delta` and `polish_refine_iter` steps of
-                                           iterative refinement (OSQP polish.c); the result replaces the ADMM solution when OSQP's acceptance rule holds */
+                                           iterative refinement (OSQP polish.c); the result replaces the ADMM solution when OSQP's acceptance rule holds.  Shapes
+                                           without a polish kernel (KP keep 6 .. 16, and the single-level mapping): po_info.status_polish = PO_NOT_AVAILABLE */
     double polish_delta;                /* OSQP `delta` (1e-6) */
     int    polish_refine_iter;          /* OSQP `polish_refine_iter` (3) */
     /* Refinement (extension, off by default; runs after a path is solved and before the polish).  refine = 2: semismooth Newton on the augmented Lagrangian
@@ -174,11 +175,14 @@ typedef struct po_params {
                                            0: the equality penalty never grows; < 0: the default; at most 1e8, which also bounds what refine_newton_escalate raises it to */
 } po_params;
 
+#define PO_NOT_AVAILABLE (-2) /* po_info.status_refine / status_polish: asked for, but the batch's shape has no kernel for it (see the fields) */
 typedef struct po_info {
     int    status;      /* PO_STATUS_*                                  */
     int    iters;       /* ADMM iterations run (with po_params.refine: the solve's and the refinement's together) */
     int    n_refactor;  /* numeric refactorisations after the first (the refinement's included) */
-    int    status_polish; /* OSQP info.status_polish: 0 not attempted, 1 polished solution adopted, -1 polish unsuccessful (ADMM solution kept) */
+    int    status_polish; /* OSQP info.status_polish: 0 not attempted (polish off, or the path was not solved), 1 polished solution adopted, -1 polish unsuccessful
+                             (ADMM solution kept); PO_NOT_AVAILABLE (-2): po_params.polish was set but the SHAPE of this batch has no polish kernel — the role-split
+                             mapping (KP, keep_control_steps_ 6 .. 16) and the single-level mapping (see status_refine) — the solve itself is unaffected */
     double r_prim;      /* ||Ax - z||_inf   at exit (unscaled)          */
     double r_dual;      /* ||Px + q + A'y||_inf at exit                 */
     double rho;         /* final rho                                    */
@@ -188,7 +192,13 @@ typedef struct po_info {
                              ABI 5), i.e. the point is the QP's optimum to that tolerance; -1 the
                              refinement ran out of its budget before that: the returned point satisfies OSQP's test at eps_abs / eps_rel only (it is the refined
                              point when its residuals are no worse than the solved point's, else the solved point) — a caller that needs the <= 1e-4 m accuracy
-                             clause per path treats -1 as "not certified" */
+                             clause per path treats -1 as "not certified";
+                             PO_NOT_AVAILABLE (-2, ABI 6): po_params.refine = 2 was set but the SHAPE of this batch has no Newton kernel, so the call ran the plain solve at
+                             eps_abs / eps_rel on every path (status is what that solve reports).  The shapes WITH one — every case the reference's own pipeline produces
+                             (keep_control_steps_ 1 .. 8 from 0.15 .. 1.0 m spacing, path_optimizer.cpp:171-172; the reference itself accepts any horizon_,
+                             solver_kp_as_input.cpp:13-24): KP keep 1 .. 4 up to N = 512, keep 5 up to N = 320, keep 6 .. 8 up to N = 64 keep, keep 9 .. 16 up to
+                             N = 32 keep; KPC (keep 4) and K up to N = 512; in every case only while the two-level tables fit 160 KB of LDS.  Without one (the single-level
+                             chain): keep > 16, and longer paths than those limits. */
     int    reserved;
 } po_info;
 
@@ -466,8 +476,10 @@ int po_last_phase_ms(po_handle h, float *ms8);
 
 const char *po_strerror(int code);
 const char *po_last_hip_error(void);
-/* "po_hip <abi> (gfx950)"; PO_ABI_VERSION is bumped whenever a struct layout or an entry point changes (5: round 5, see po_params.refine) */
-#define PO_ABI_VERSION 5
+/* "po_hip <abi> (gfx950)"; PO_ABI_VERSION is bumped whenever a struct layout, an entry point or the meaning of a field changes (5: round 5, see po_params.refine;
+ * 6: round 6, po_info.status_refine / status_polish may be PO_NOT_AVAILABLE; po_create refuses refine_rounds + refine_extra_rounds >= 32).  A binding should compare
+ * the number in po_version() with the PO_ABI_VERSION it was written against before it passes a struct (path_optimizer_amd/binding.py does). */
+#define PO_ABI_VERSION 6
 const char *po_version(void);
 
 #ifdef __cplusplus

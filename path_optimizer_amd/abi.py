@@ -1,5 +1,6 @@
 """ctypes mirror of include/po_hip.h (struct layouts and enums only; no behaviour)."""
-PO_ABI_VERSION = 5  # include/po_hip.h
+PO_ABI_VERSION = 6  # include/po_hip.h
+PO_NOT_AVAILABLE = -2  # po_info.status_refine / status_polish: asked for, no kernel for this shape
 import ctypes as C
 
 PO_KP, PO_KPC, PO_K = 0, 1, 2

@@ -12,7 +12,7 @@ import sys
 
 import numpy as np
 
-from .abi import (INFO_BYTES, INFO_DTYPE, PO_ERR_HIP, PO_ERR_UNSUPPORTED, PO_OK, PoBatchIn, PoBatchOut, PoParams)
+from .abi import (INFO_BYTES, INFO_DTYPE, PO_ABI_VERSION, PO_ERR_HIP, PO_ERR_UNSUPPORTED, PO_OK, PoBatchIn, PoBatchOut, PoParams)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PO_LIB") or os.path.join(_HERE, "libpo_hip.so")  # PO_LIB: dev builds (make dev), A/B experiments
@@ -49,6 +49,11 @@ def lib():
         L.po_strerror.restype = C.c_char_p
         L.po_last_hip_error.restype = C.c_char_p
         L.po_version.restype = C.c_char_p
+        # the structs of abi.py are laid out for ONE ABI: a stale libpo_hip.so (or an older dev build picked through PO_LIB) would be driven with shifted fields
+        ver = L.po_version().decode()
+        parts = ver.split()
+        if len(parts) < 2 or not parts[1].isdigit() or int(parts[1]) != PO_ABI_VERSION:
+            raise PoError(f"{LIB_PATH} reports '{ver}' but this binding is written against PO_ABI_VERSION {PO_ABI_VERSION} (include/po_hip.h): rebuild the library")
         L.po_create.argtypes = [C.c_int, C.POINTER(PoParams), C.POINTER(C.c_void_p)]
         L.po_destroy.argtypes = [C.c_void_p]
         L.po_set_stream.argtypes = [C.c_void_p, C.c_void_p]

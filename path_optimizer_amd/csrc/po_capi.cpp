@@ -22,6 +22,7 @@
 
 extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out);
 extern "C" hipError_t po_launch_finalize_status(po_info *info, int B, hipStream_t st);
+extern "C" hipError_t po_launch_mark_unavailable(po_info *info, int B, int refine, int polish, hipStream_t st);
 extern "C" hipError_t po_launch_polish(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
 extern "C" hipError_t po_launch_newton(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
 extern "C" hipError_t po_launch_newton_fallback(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st);
@@ -223,6 +224,9 @@ int po_create(int device, const po_params *params, po_handle *out) {
     if (!params || !out) return PO_ERR_INVALID;
     if (params->scaling < 0 || params->scaling > 100) return PO_ERR_INVALID;
     if (params->refine != 0 && params->refine != 2) return PO_ERR_INVALID;  // (refine = 1 was removed with ABI 5, include/po_hip.h)
+    // the rounds of the refinement (refine_rounds regular ones + refine_extra_rounds below eps) are counted in 5 bits of the hand-back status: 32 or more used to switch the
+    // refinement off silently — refused here instead
+    if (params->refine == 2 && (params->refine_rounds > 1 ? params->refine_rounds : 1) + (params->refine_extra_rounds > 0 ? params->refine_extra_rounds : 0) >= 32) return PO_ERR_INVALID;
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return PO_ERR_INVALID;
@@ -403,11 +407,11 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     bool polish = false;
     if (h->params.polish || h->params.refine) {  // OSQP's polish (opt-in) and the Newton refinement pick the ADMM state up from pol_buf, where the solve kernels leave it
         const int sd = po_polish_state_doubles(in->formulation, in->N, C, in->keep);
-        if (sd > 0) {  // (shapes on the single-level mapping have neither kernel: status_polish / status_refine stay 0 = not attempted)
+        if (sd > 0) {  // (shapes on the single-level mapping have neither kernel: status_polish / status_refine = PO_NOT_AVAILABLE, see below)
             if ((rc = h->pol_buf.ensure(sizeof(double) * (size_t)sd * (size_t)in->B))) return rc;
             D.pol_state = static_cast<double *>(h->pol_buf.p);
             D.pol_stride = sd;
-            polish = h->params.polish && po_has_polish_kernel(in->formulation, in->N, C, in->keep);  // (role-split shapes, keep 5 .. 8: no polish kernel)
+            polish = h->params.polish && po_has_polish_kernel(in->formulation, in->N, C, in->keep);  // (role-split shapes, keep 6 .. 16: no polish kernel -> status_polish = PO_NOT_AVAILABLE)
         }
     }
     const int rounds_total = (h->params.refine_rounds > 1 ? h->params.refine_rounds : 1) + P.ref_extra;
@@ -488,6 +492,10 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     }
     if (split) HIP_TRY(po_launch_finalize_status(D.out_info, in->B, h->stream));
     if (polish) HIP_TRY(po_launch_polish(in->formulation, &D, &P, h->stream));
+    {   // asked for, but this shape has no kernel for it: say so per path (PO_NOT_AVAILABLE) instead of leaving the "off" value 0
+        const int no_refine = h->params.refine == 2 && !split, no_polish = h->params.polish && !polish;
+        if (no_refine || no_polish) HIP_TRY(po_launch_mark_unavailable(D.out_info, in->B, no_refine, no_polish, h->stream));
+    }
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     if (dbg) {
@@ -1175,6 +1183,8 @@ const char *po_strerror(int code) {
     }
 }
 const char *po_last_hip_error(void) { return g_hip_err.c_str(); }
-const char *po_version(void) { return "po_hip 5 (gfx950)"; }
+#define PO_STR2(x) #x
+#define PO_STR(x) PO_STR2(x)
+const char *po_version(void) { return "po_hip " PO_STR(PO_ABI_VERSION) " (gfx950)"; }
 
 }  // extern "C"

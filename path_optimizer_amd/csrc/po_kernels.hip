@@ -66,7 +66,20 @@ __global__ void finalize_status_kernel(po_info *info, int B) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B && info[b].status <= kStatusDeferred) { info[b].status = PO_STATUS_UNSOLVED; info[b].status_polish = 0; }
 }
+// A caller that asked for the Newton refinement (po_params.refine = 2) or the polish on a shape that has no kernel for it (the single-level mapping; polish: also the role-split
+// shapes) can SEE that: status_refine / status_polish = -2 (PO_NOT_AVAILABLE) on every path instead of 0, which also means "off" (include/po_hip.h, ABI 6).
+__global__ void mark_unavailable_kernel(po_info *info, int B, int refine, int polish) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        if (refine) info[b].status_refine = PO_NOT_AVAILABLE;
+        if (polish) info[b].status_polish = PO_NOT_AVAILABLE;
+    }
+}
 }  // namespace po
+extern "C" hipError_t po_launch_mark_unavailable(po_info *info, int B, int refine, int polish, hipStream_t st) {
+    hipLaunchKernelGGL(po::mark_unavailable_kernel, dim3((B + 255) / 256), dim3(256), 0, st, info, B, refine, polish);
+    return hipGetLastError();
+}
 // Two launches on the same stream for the two-level mapping: the uniform-row-class variant first (solves what it can, defers the rest),
 // then the general variant (po_fast.inc, solve_kernel_fast).
 extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out) {
@@ -74,7 +87,7 @@ extern "C" hipError_t po_launch_solve(int form, const po::DevBatch *in, const po
     hipError_t e;
     if (form == F_KP) {
         e = po_launch_solve_kp_uni(in, P, st, lds_out);
-        if (e == hipErrorInvalidValue) {  // not a shape of keep 1 .. 8: the wide objects
+        if (e == kNotMyShape) {  // not a shape of keep 1 .. 8: the wide objects
             e = po_launch_solve_kp_w_uni(in, P, st, lds_out);
             return e != hipSuccess ? e : po_launch_solve_kp_w(in, P, st, lds_out);
         }
@@ -103,13 +116,13 @@ PO_DECLP(po_launch_newton_kp_w1); PO_DECLP(po_launch_newton_kp_w1_fb); PO_DECLP(
 // the Newton refinement of round 0 as its own launch (po_params.refine = 2), and the fallback launch for what it hands back
 extern "C" hipError_t po_launch_newton(int form, const po::DevBatch *in, const po::DevParams *P, hipStream_t st) {
     using namespace po;
-    if (form == F_KP) {  // (an object answers hipErrorInvalidValue for a shape it does not hold)
+    if (form == F_KP) {  // (an object answers kNotMyShape for a shape it does not hold; any other code is that launch's own failure and is returned as it is)
         hipError_t e = po_launch_newton_kp(in, P, st);
-        if (e == hipErrorInvalidValue) e = po_launch_newton_kp_b(in, P, st);
-        if (e == hipErrorInvalidValue) e = po_launch_newton_kp_c(in, P, st);
-        if (e == hipErrorInvalidValue) e = po_launch_newton_kp_w1(in, P, st);
-        if (e == hipErrorInvalidValue) e = po_launch_newton_kp_w2(in, P, st);
-        return e == hipErrorInvalidValue ? po_launch_newton_kp_w3(in, P, st) : e;
+        if (e == kNotMyShape) e = po_launch_newton_kp_b(in, P, st);
+        if (e == kNotMyShape) e = po_launch_newton_kp_c(in, P, st);
+        if (e == kNotMyShape) e = po_launch_newton_kp_w1(in, P, st);
+        if (e == kNotMyShape) e = po_launch_newton_kp_w2(in, P, st);
+        return e == kNotMyShape ? po_launch_newton_kp_w3(in, P, st) : e;
     }
     return form == F_KPC ? po_launch_newton_kpc(in, P, st) : po_launch_newton_k(in, P, st);
 }
@@ -117,11 +130,11 @@ extern "C" hipError_t po_launch_newton_fallback(int form, const po::DevBatch *in
     using namespace po;
     if (form == F_KP) {
         hipError_t e = po_launch_newton_kp_fb(in, P, st);
-        if (e == hipErrorInvalidValue) e = po_launch_newton_kp_b_fb(in, P, st);
-        if (e == hipErrorInvalidValue) e = po_launch_newton_kp_c_fb(in, P, st);
-        if (e == hipErrorInvalidValue) e = po_launch_newton_kp_w1_fb(in, P, st);
-        if (e == hipErrorInvalidValue) e = po_launch_newton_kp_w2_fb(in, P, st);
-        return e == hipErrorInvalidValue ? po_launch_newton_kp_w3_fb(in, P, st) : e;
+        if (e == kNotMyShape) e = po_launch_newton_kp_b_fb(in, P, st);
+        if (e == kNotMyShape) e = po_launch_newton_kp_c_fb(in, P, st);
+        if (e == kNotMyShape) e = po_launch_newton_kp_w1_fb(in, P, st);
+        if (e == kNotMyShape) e = po_launch_newton_kp_w2_fb(in, P, st);
+        return e == kNotMyShape ? po_launch_newton_kp_w3_fb(in, P, st) : e;
     }
     return form == F_KPC ? po_launch_newton_kpc_fb(in, P, st) : po_launch_newton_k_fb(in, P, st);
 }
@@ -146,7 +159,7 @@ extern "C" int po_newton_park_doubles(int form, int N, int C, int keep) {
 namespace po {
 // the parked paths (keys[b] >= 0) in descending key order, ties in path order (a stable counting sort: deterministic): list[0] = count, list[1 ..] = path ids.
 // One workgroup of kNwSortThreads threads, thread t owns the contiguous range of paths [t * per, (t + 1) * per).
-constexpr int kNwKeys = 16, kNwSortThreads = 512;
+constexpr int kNwKeys = 32, kNwSortThreads = 256;  // (32 keys x 257 counters = 33 KB of LDS)
 __global__ __launch_bounds__(kNwSortThreads) void nw_sort_kernel(const int *keys, int B, int *list) {
     __shared__ int cnt[kNwKeys][kNwSortThreads + 1];
     const int t = threadIdx.x, per = (B + kNwSortThreads - 1) / kNwSortThreads, lo = t * per, hi = min(B, lo + per);
@@ -208,7 +221,7 @@ extern "C" int po_shape_threads(int form, int N, int C, int keep) {
 extern "C" int po_has_polish_kernel_kp(int N, int C, int keep);
 extern "C" int po_has_polish_kernel_kpc(int N, int C, int keep);
 extern "C" int po_has_polish_kernel_k(int N, int C, int keep);
-// does the shape of this batch have a polish kernel?  (the role-split shapes of keep 5 .. 8 and the single-level mapping do not)
+// does the shape of this batch have a polish kernel?  (the role-split shapes of keep 6 .. 16 and the single-level mapping do not)
 extern "C" int po_has_polish_kernel(int form, int N, int C, int keep) {
     using namespace po;
     return form == F_KP ? po_has_polish_kernel_kp(N, C, keep) : (form == F_KPC ? po_has_polish_kernel_kpc(N, C, keep) : po_has_polish_kernel_k(N, form == F_K ? 0 : C, keep));

@@ -106,6 +106,10 @@ template <class K> hipError_t launch1(K kern, const DevBatch *in, const DevParam
 // thread-block shape: NT threads x SPL stages per thread must cover N, and NT >= C (one control per thread).
 // Two-level mode needs chunk == control group, or no held controls at all (K): one lane per chunk (SPL == keep, keep <= 5), or — round 5, keep 6 .. 8 — the
 // ROLE-SPLIT mapping: two lanes per chunk, SPL = ceil(keep / 2) stages each (nwx = 2; 3 when keep is odd), NT = 64 for up to 32 chunks, 128 for up to 64.
+// What an object answers for a shape it does not hold (the dispatcher in po_kernels.hip then asks the next object).  NOT hipErrorInvalidValue: that is a code a
+// genuine hipFuncSetAttribute / launch failure produces (e.g. an LDS size over the limit), and a real failure must reach the caller from the launch that failed
+// instead of being retried through the other objects.  launch1 / launch_grid never produce hipErrorNotSupported.
+constexpr hipError_t kNotMyShape = hipErrorNotSupported;
 struct Shape { int nt, spl; bool two; int nwx; };
 inline bool pick_shape(int form, int N, int C, int keep, Shape *s) {
     const bool no_u = (form == F_K);
@@ -168,7 +172,7 @@ template <int F> inline bool has_uni_variant(const Shape &s) { return s.two && (
 #define PO_TWO_SHAPES(X) if (s.spl == PO_DEV_SPL && s.nt == PO_DEV_NT && s.nwx == PO_DEV_NWX) X(PO_DEV_SPL, PO_DEV_NT, PO_DEV_NWX);
 #else
 // (KP: keep 1 / 2 multi-group (4, ., 4 / 5), keep 3 / 4 / 5 one lane per chunk, keep 6 / 7 / 8 role-split; KPC: keep 4; K: 2 or 4 stages per lane)
-// -DPO_SHAPE_GROUP: which of KP's shapes an object holds (the dispatcher in po_kernels.hip asks the objects in turn; an object answers hipErrorInvalidValue / 0 for a shape it does not hold).
+// -DPO_SHAPE_GROUP: which of KP's shapes an object holds (the dispatcher in po_kernels.hip asks the objects in turn; an object answers kNotMyShape / 0 for a shape it does not hold).
 //   0  the shapes of keep 1 .. 8 (the solve objects);  1 / 2 / 3  of those only one lane per chunk / role-split / multi-group (the Newton objects: as ONE object their 15 shapes x 3
 //   kernels were the 5-minute pole of the build);  7  the WIDE role-split shapes of keep 9 .. 16 (5 .. 8 stages per lane; solve objects `_w`);  4 / 5 / 6  of those only SPL 5, 6 / 7 / 8.
 #if PO_SHAPE_GROUP == 0 || PO_SHAPE_GROUP == 1
@@ -240,7 +244,7 @@ template <int F, bool UNI, int G = PO_SHAPE_GROUP> hipError_t launch_form(const 
 #define PO_L(SPL_, NT_, NWX_) return launch1(&solve_kernel_fast<F, SPL_, NT_, true, UNI, NWX_>, in, P, NT_, lds, st)
         PO_TWO_SHAPES(PO_L)
 #undef PO_L
-        return hipErrorInvalidValue;
+        return kNotMyShape;
     }
 #if !defined(PO_DEV_HEADLINE) && PO_SHAPE_GROUP == 0  // (the single-level mapping lives in the objects of the keep 1 .. 8 shapes)
     if constexpr (!UNI) {
@@ -253,7 +257,7 @@ template <int F, bool UNI, int G = PO_SHAPE_GROUP> hipError_t launch_form(const 
 #undef PO_L1
     }
 #endif
-    return hipErrorInvalidValue;
+    return kNotMyShape;
 }
 // ---- state block / polish (po_params.polish): same shape as the solve launch; two-level shapes only (every case the reference produces) ----
 template <int F, int SPL_, int NT_, int NWX_> inline int state_doubles_of() { return Fast<F, SPL_, NT_, true, NWX_>::kStateDoubles * NT_; }
@@ -286,7 +290,7 @@ template <int F, bool FB, int G = PO_SHAPE_GROUP> hipError_t launch_newton(const
 #define PO_X(SPL_, NT_, NWX_) { if constexpr (FB) return launch_grid(&newton_fallback_kernel<F, SPL_, NT_, NWX_>, in, P, kFallbackGrid, NT_, lds, st); else if (in->nw_phase == 2) return launch1(&newton_kernel<F, SPL_, NT_, NWX_, 2>, in, P, NT_, lds, st); else return launch1(&newton_kernel<F, SPL_, NT_, NWX_, 1>, in, P, NT_, lds, st); }
     PO_TWO_SHAPES(PO_X)
 #undef PO_X
-    return hipErrorInvalidValue;
+    return kNotMyShape;
 }
 // OSQP's polish: one-lane-per-chunk shapes (the role-split shapes of keep 6 .. 8 have no polish kernel: status_polish stays 0 = not attempted, like the single-level mapping)
 template <int F> inline bool has_polish_kernel(int N, int C, int keep) {
@@ -302,6 +306,6 @@ template <int F, int G = PO_SHAPE_GROUP> hipError_t launch_polish(const DevBatch
 #define PO_X(SPL_, NT_, NWX_) { if constexpr (NWX_ != 2 && NWX_ != 3) return launch1(&polish_kernel<F, SPL_, NT_, NWX_>, in, P, NT_, lds, st); }
     PO_TWO_SHAPES(PO_X)
 #undef PO_X
-    return hipErrorInvalidValue;
+    return kNotMyShape;
 }
 }  // namespace po

@@ -52,7 +52,7 @@
 extern "C" hipError_t PO_G(PO_NEWTON_ENTRY)(const po::DevBatch *in, const po::DevParams *P, hipStream_t st) { return po::launch_newton<PO_FORM, false>(in, P, st); }
 extern "C" hipError_t PO_CAT(PO_G(PO_NEWTON_ENTRY), _fb)(const po::DevBatch *in, const po::DevParams *P, hipStream_t st) { return po::launch_newton<PO_FORM, true>(in, P, st); }
 #if defined(PO_DEV_HEADLINE) && PO_FORM == 0  // dev builds hold one shape in one object of each kind: the entries of the other groups answer "not mine"
-#define PO_STUB(name) extern "C" hipError_t name(const po::DevBatch *, const po::DevParams *, hipStream_t) { return hipErrorInvalidValue; }
+#define PO_STUB(name) extern "C" hipError_t name(const po::DevBatch *, const po::DevParams *, hipStream_t) { return po::kNotMyShape; }
 PO_STUB(po_launch_newton_kp_b) PO_STUB(po_launch_newton_kp_b_fb) PO_STUB(po_launch_newton_kp_c) PO_STUB(po_launch_newton_kp_c_fb)
 PO_STUB(po_launch_newton_kp_w1) PO_STUB(po_launch_newton_kp_w1_fb) PO_STUB(po_launch_newton_kp_w2) PO_STUB(po_launch_newton_kp_w2_fb) PO_STUB(po_launch_newton_kp_w3) PO_STUB(po_launch_newton_kp_w3_fb)
 #undef PO_STUB
@@ -62,7 +62,7 @@ extern "C" hipError_t PO_CAT(PO_G(PO_ENTRY_BASE), _uni)(const po::DevBatch *in, 
     return po::launch_form<PO_FORM, true>(in, P, st, lds_out);
 }
 #if defined(PO_DEV_HEADLINE) && PO_FORM == 0
-extern "C" hipError_t po_launch_solve_kp_w_uni(const po::DevBatch *, const po::DevParams *, hipStream_t, size_t *) { return hipErrorInvalidValue; }
+extern "C" hipError_t po_launch_solve_kp_w_uni(const po::DevBatch *, const po::DevParams *, hipStream_t, size_t *) { return po::kNotMyShape; }
 #endif
 #else
 extern "C" hipError_t PO_G(PO_ENTRY_BASE)(const po::DevBatch *in, const po::DevParams *P, hipStream_t st, size_t *lds_out) {
@@ -76,7 +76,7 @@ extern "C" hipError_t PO_POLISH_ENTRY(const po::DevBatch *in, const po::DevParam
 extern "C" int PO_POLISH_HAS(int N, int C, int keep) { return po::has_polish_kernel<PO_FORM>(N, C, keep) ? 1 : 0; }
 #endif
 #if defined(PO_DEV_HEADLINE) && PO_FORM == 0
-extern "C" hipError_t po_launch_solve_kp_w(const po::DevBatch *, const po::DevParams *, hipStream_t, size_t *) { return hipErrorInvalidValue; }
+extern "C" hipError_t po_launch_solve_kp_w(const po::DevBatch *, const po::DevParams *, hipStream_t, size_t *) { return po::kNotMyShape; }
 extern "C" int po_polish_state_doubles_kp_w(int, int, int) { return 0; }
 extern "C" int po_polish_state_doubles_kp_w_park(int, int, int) { return 0; }
 #endif

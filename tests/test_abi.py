@@ -84,3 +84,32 @@ def test_inline_dpp_fmacs_of_the_tension_solve_have_their_wait_states():
     total, findings = check()
     assert total >= 100 and not findings, (total, findings[:3])
     assert check.led * 9 == total, (check.led, total)  # one wait-state-carrying FMAC per product of nine (bandwidth W = 9)
+
+
+def test_library_version_is_the_headers_abi_and_the_binding_checks_it():
+    """po_version() is built from PO_ABI_VERSION (not a literal), the header, abi.py and the loaded library agree, and binding.lib() refuses a library of another ABI
+    (ABI 5 removed fields from the middle of po_params; a stale libpo_hip.so would have been driven with a shifted struct)."""
+    hdr = open(os.path.join(ROOT, "include", "po_hip.h")).read()
+    m = re.search(r"#define\s+PO_ABI_VERSION\s+(\d+)", hdr)
+    assert m and int(m.group(1)) == abi.PO_ABI_VERSION
+    ver = binding.lib().po_version().decode()
+    assert ver == f"po_hip {abi.PO_ABI_VERSION} (gfx950)", ver
+    assert re.search(r"#define\s+PO_NOT_AVAILABLE\s+\(-2\)", hdr) and abi.PO_NOT_AVAILABLE == -2
+    # a binding written against another ABI refuses this library at load time
+    code = ("import sys; sys.path.insert(0, %r); from path_optimizer_amd import abi; abi.PO_ABI_VERSION = 5; from path_optimizer_amd import binding; binding.lib()" % ROOT)
+    r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "PO_ABI_VERSION 5" in r.stderr, r.stderr[-600:]
+
+
+def test_po_create_refuses_round_counts_that_would_switch_the_refinement_off():
+    """refine_rounds + refine_extra_rounds >= 32 does not fit the hand-back status: it used to run the plain solve silently; now PO_ERR_INVALID — before any
+    device is touched, so the check runs on the CPU box too."""
+    p = binding.default_params()
+    p.refine = 2; p.refine_rounds = 30; p.refine_extra_rounds = 2
+    h = ctypes.c_void_p()
+    assert binding.lib().po_create(0, ctypes.byref(p), ctypes.byref(h)) == abi.PO_ERR_INVALID
+    p.refine_rounds = 5  # (the headline setting: 5 + 2 rounds) passes the parameter check — what follows is the device check
+    rc = binding.lib().po_create(0, ctypes.byref(p), ctypes.byref(h))
+    assert rc in (abi.PO_OK, abi.PO_ERR_HIP)
+    if rc == abi.PO_OK:
+        binding.lib().po_destroy(h)

@@ -1,4 +1,6 @@
-"""Dev tool (CPU): registers / spills / scratch of every kernel in the built objects (path_optimizer_amd/csrc/.build/*.o), read from the gfx950 code object's metadata notes.
+"""Dev tool (CPU): registers / spills / scratch of every kernel in the objects libpo_hip.so is LINKED from, read from the gfx950 code object's metadata notes.
+The object list is the Makefile's own (`make -pn` -> the prerequisites of ../libpo_hip.so), not a glob of .build/ — a box with left-over objects of earlier rounds used to
+put 131 rows of kernels that no longer ship into profiles/r5c/kernel_resources.txt.
     python tools/kernel_resources.py [substring of the object name ...]          (needs /opt/rocm/lib/llvm/bin/{llvm-objcopy,llvm-readelf})"""
 import glob, os, re, struct, subprocess, sys, tempfile
 
@@ -40,6 +42,16 @@ def kernels_of(obj):
         return out
 
 
+def linked_objects():
+    """The objects of the library's link line, as make itself resolves them (basenames, in link order)."""
+    csrc = os.path.join(ROOT, "path_optimizer_amd", "csrc")
+    db = subprocess.run(["make", "-pn", "-C", csrc], capture_output=True, text=True).stdout
+    m = re.search(r"^\.\./libpo_hip\.so:(.*)$", db, flags=re.M)
+    if not m:
+        raise SystemExit("kernel_resources: no rule for ../libpo_hip.so in the Makefile's database")
+    return [os.path.basename(o) for o in m.group(1).split() if o.endswith(".o")]
+
+
 def demangle(n):
     r = subprocess.run(["c++filt", n], capture_output=True, text=True).stdout.strip()
     return re.sub(r"\(po::Dev\w+(, po::Dev\w+)*\)", "", r) or n
@@ -48,8 +60,10 @@ def demangle(n):
 if __name__ == "__main__":
     pats = sys.argv[1:]
     print(f"{'object':28s} {'kernel':62s} {'vgpr':>5s} {'agpr':>5s} {'spillV':>6s} {'spillS':>6s} {'scratch B/lane':>14s}")
-    for obj in sorted(glob.glob(os.path.join(ROOT, "path_optimizer_amd", "csrc", ".build", "*.o"))):
-        base = os.path.basename(obj)
+    for base in sorted(linked_objects()):
+        obj = os.path.join(ROOT, "path_optimizer_amd", "csrc", ".build", base)
+        if not os.path.exists(obj):
+            raise SystemExit(f"kernel_resources: {obj} is on the link line but not built")
         if pats and not any(p in base for p in pats):
             continue
         for k in kernels_of(obj):

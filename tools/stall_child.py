@@ -14,8 +14,9 @@ def main():
 
     from path_optimizer_amd import binding, synth
 
-    cfg = int(sys.argv[1]); B = int(sys.argv[2]); reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-    batch = synth.make_batch(cfg, B=B)  # (path ids seed the generator: the first B paths of the config)
+    cfg_s = sys.argv[1]; B = int(sys.argv[2]); reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    cfg = int(cfg_s.rstrip("k"))  # "3k": config 3's generator with the K formulation (what bench.py's `k_formulation` leg runs)
+    batch = synth.make_batch(cfg, B=B, **({"formulation": 2} if cfg_s.endswith("k") else {}))  # (path ids seed the generator: the first B paths of the config)
     db = binding.DeviceBatch(batch)
     p = binding.default_params()
     p.refine = 2; p.refine_rounds = 5; p.refine_extra_rounds = 2; p.refine_eps = 1e-8; p.refine_chain = 2
@@ -25,7 +26,7 @@ def main():
     for _ in range(1 + reps):
         eng.solve_batch_device(db); torch.cuda.synchronize()
     info = db.info_numpy()
-    print(f"STALL cfg {cfg} B {B} reps {reps} ms {eng.last_kernel_ms():.4f} phases {eng.last_phase_ms()} iters mean {info['iters'].mean():.2f} max {int(info['iters'].max())} "
+    print(f"STALL cfg {cfg_s} B {B} reps {reps} ms {eng.last_kernel_ms():.4f} phases {eng.last_phase_ms()} iters mean {info['iters'].mean():.2f} max {int(info['iters'].max())} "
           f"certified {int((info['status_refine'] == 1).sum())}", flush=True)
 
 
