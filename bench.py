@@ -133,6 +133,18 @@ def config_legs(torch, binding, synth, dev, stream, steps=3):
         if ref:
             out[name]["with_refinement"] = ref
             hs = ref["headline_setting"]
+            # fp64-VALU roofline of this config at the headline setting (VERDICT r5 missing 4): the flop of one solve from the newest committed rocprofv3 PMC summary of THIS
+            # config (tools/profile_cfg.sh -> profiles/r6*/<config>/pmc_summary.json: the work of a solve does not depend on the run), the time measured here
+            prof = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r6*", name, "pmc_summary.json")))
+            pj = _load_json(prof[-1]) if prof else None
+            if pj and pj.get("fp64_flop_per_solve_all_kernels"):
+                rn = pj.get("roofline_newton_kernels") or {}
+                tf = pj["fp64_flop_per_solve_all_kernels"] / (hs["ms"] * 1e-3) / 1e12
+                out[name]["roofline"] = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
+                                         "fp64_flop_per_solve": pj["fp64_flop_per_solve_all_kernels"], "flop_source": os.path.relpath(prof[-1], ROOT) + " (rocprofv3 --pmc SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64, all kernels of a solve)",
+                                         "newton_kernels": {"names": rn.get("kernels"), "fp64_flop_per_solve": rn.get("fp64_flop_per_solve"), "ms_in_the_profiled_run": rn.get("ms_per_solve"), "frac_in_the_profiled_run": rn.get("frac"),
+                                                            "hbm_bytes_per_solve": rn.get("hbm_bytes_per_solve"), "resident_time_split": pj.get("resident_time_split")}}
+                out[name]["compliant_fp64_roofline_frac"] = tf / FP64_VALU_PEAK_TFLOPS
             # the compliant figures of this config for the compact line: time, certified count, paths beyond the bar — beside the plain ones
             out[name].update({"compliant_ms": hs["ms"], "compliant_paths_per_s": hs["paths_per_s"], "compliant_certified": hs["certified"], "compliant_iters_max": hs["iters_max"],
                               "compliant_n_gt_1e-4_m": hs.get("n_gt_1e-4_m"), "compliant_max_m": hs.get("max_m")})
@@ -287,9 +299,30 @@ def scaling_preview(torch, binding, synth, dev, stream, B):
         per_e[str(E)] = {"per_call_ms_median_over_engines": float(np.median(res)), "per_call_ms_max": float(np.max(res))}
         [e_.close() for e_ in engs]
     out["engines_on_pinned_threads"] = {"batch_per_engine": 64, "calls": 40, "per_call_ms": per_e,
-                                        "note": "one handle + stream + host thread per engine, threads pinned to distinct cores, all on device 0; flat in E = the launch paths of "
-                                                "concurrent engines do not serialise on the host"}
+                                        "note": "one handle + stream + host thread per engine, threads pinned to distinct cores, all on device 0, in THIS process (the HIP runtime "
+                                                "was started by torch with its default pool of 4 hardware queues); flat in E = the launch paths of concurrent engines do not serialise"}
     eng.close()
+    # (round 6) WHERE the growth with E comes from: the same leg (a) with E PROCESSES — a runtime and a hardware-queue pool each — and (b) with E threads in a
+    # fresh process whose runtime starts with GPU_MAX_HW_QUEUES = 16 (what libpo_hip.so sets before its first HIP call when the caller has not set the variable; a process
+    # that imported torch first keeps the default 4).  Flat with processes and with the larger pool = the streams of one process share hardware queues, not the device.
+    try:
+        import subprocess
+
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import engines_procs as EP
+
+        rows = {}
+        for E in (1, 4, 8):
+            r = EP.procs(E, "chain2")
+            rows[str(E)] = float(np.median(r)) if r else None
+        out["engines_in_processes"] = {"batch_per_engine": 64, "calls": EP.CALLS, "per_call_ms": rows, "note": "one PROCESS per engine (own HIP runtime and hardware queues), all on device 0"}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "engines_procs.py"), "--threads", "chain2"], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, GPU_MAX_HW_QUEUES="16"))
+        line = [l for l in r.stdout.splitlines() if l.startswith("THREADS ")]
+        out["engines_on_threads_hw_queues_16"] = {"batch_per_engine": 64, "calls": EP.CALLS, "per_call_ms": json.loads(line[0][8:]) if line else None,
+                                                  "note": "E threads in ONE fresh process started with GPU_MAX_HW_QUEUES=16"}
+    except Exception as exc:  # a secondary leg: never costs the bench its line
+        out["engines_in_processes"] = {"error": repr(exc)[:200]}
     return out
 
 
@@ -988,7 +1021,7 @@ def main():
         if not args.no_configs:
             details["configs"] = config_legs(torch, binding, synth, dev, streams[0])
             keep_ = ("ms", "paths_per_s", "iters_mean", "iters_max", "unsolved", "compliant_ms", "compliant_paths_per_s", "compliant_certified", "compliant_iters_max",
-                     "compliant_n_gt_1e-4_m", "compliant_max_m", "qp_iters", "max_abs_diff_vs_reference")
+                     "compliant_n_gt_1e-4_m", "compliant_max_m", "compliant_fp64_roofline_frac", "qp_iters", "max_abs_diff_vs_reference")
             out["configs"] = {k: {kk: v[kk] for kk in keep_ if kk in v} for k, v in details["configs"].items()}
             out["configs"]["note"] = "ms / paths_per_s: OSQP-faithful default at eps 1e-4; compliant_*: the headline setting (same as `value`) on the whole batch, against the exact optima"
         if not args.no_scaling_preview:
@@ -997,6 +1030,8 @@ def main():
                 sp = details["scaling_preview"]
                 out["scaling_preview"] = {"shard_4096_paths_per_s": out["single_batch"]["paths_per_s"], "shard_32768_paths_per_s": sp["b32768_single_launch"]["paths_per_s"],
                                           "engine_call_ms_by_E": {k: v["per_call_ms_median_over_engines"] for k, v in sp["engines_on_pinned_threads"]["per_call_ms"].items()},
+                                          "engine_call_ms_by_E_processes": (sp.get("engines_in_processes") or {}).get("per_call_ms"),
+                                          "engine_call_ms_by_E_threads_hw_queues_16": (sp.get("engines_on_threads_hw_queues_16") or {}).get("per_call_ms"),
                                           "note": "no multi-GPU node was available: one device at both shard sizes of a 1 -> 8 GPU split of config 4, and the host launch path of E concurrent engines (details file)"}
             except Exception as e_:
                 out["scaling_preview"] = {"error": repr(e_)}

@@ -215,7 +215,19 @@ int po_keep_control_steps(int form, const double *ref_s, int N) {
     return k > 1 ? k : 1;
 }
 
+// Several engines in ONE process (OsqpSolver::solveBatch(..., engines), one host thread + handle + stream each): the HIP runtime maps a process's streams onto a pool of
+// GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a hardware queue run their kernels one after the other — measured on one MI355X with E engines
+// solving 64-path batches side by side (tools/engines_procs.py, round 6): per call 1.21 / 1.22 / 1.82 / 4.24 ms for E = 1 / 2 / 4 / 8 with the default pool, 1.23 / 2.39 /
+// 4.77 / 7.16 with a pool of 2, 1.22 / 1.23 / 1.36 / 1.53 with a pool of 16; E PROCESSES (a pool each): 1.22 / 1.46 / 1.66 / 1.88.  The pool size is read once, when the
+// runtime starts; so, BEFORE this library's first HIP call, the variable is set to 16 unless the caller has set it (overwrite = 0; a process whose runtime is already up —
+// e.g. one that imported torch first — keeps what it started with: export GPU_MAX_HW_QUEUES there).
+static void runtime_prepare() {
+    static std::once_flag once;
+    std::call_once(once, [] { setenv("GPU_MAX_HW_QUEUES", "16", 0); });
+}
+
 int po_device_count(void) {
+    runtime_prepare();
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
@@ -227,6 +239,7 @@ int po_create(int device, const po_params *params, po_handle *out) {
     // the rounds of the refinement (refine_rounds regular ones + refine_extra_rounds below eps) are counted in 5 bits of the hand-back status: 32 or more used to switch the
     // refinement off silently — refused here instead
     if (params->refine == 2 && (params->refine_rounds > 1 ? params->refine_rounds : 1) + (params->refine_extra_rounds > 0 ? params->refine_extra_rounds : 0) >= 32) return PO_ERR_INVALID;
+    runtime_prepare();
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return PO_ERR_INVALID;

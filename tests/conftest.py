@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: the wider fuzz slices (GPU, about two minutes together; part of -m gpu, deselect with -m 'gpu and not slow')")
 
 
 @pytest.fixture(scope="session")

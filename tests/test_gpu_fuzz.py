@@ -50,9 +50,13 @@ def _params(rng, make):
 
 @pytest.mark.parametrize("seed", range(48))
 def test_random_case_matches_oracle(oracle, seed):
+    _plain_case(oracle, seed)
+
+
+def _plain_case(oracle, seed, case=None, loose=False):
     from path_optimizer_amd import binding
 
-    rng, form, b = _case(seed)
+    rng, form, b = (case or _case)(seed)
     if form == T.PO_KP:
         b.keep = binding.keep_control_steps(form, b.ref_s[0])
         assert b.keep == oracle.keep_steps(form, b.ref_s[0])
@@ -73,6 +77,12 @@ def test_random_case_matches_oracle(oracle, seed):
     st, info, xs = binding.Engine(0, p).solve_batch(b, want_x=True)
     ost, oinfo, oxs = oracle.solve_batch(b, po)
     assert np.array_equal(info["n_refactor"][info["iters"] == oinfo["iters"]], oinfo["n_refactor"][info["iters"] == oinfo["iters"]])
+    if loose:
+        # the three known cases of the wider sweep: equal iteration and refactorisation counts, one path 2.2e-6 .. 3.8e-6 from the oracle's after
+        # 500 - 1 200 iterations and up to three rho updates down to rho = 4.8e-6 (round-off amplified by the adaptive-rho estimate) — compared at 1e-5 instead of 1e-6
+        assert np.array_equal(info["status"], oinfo["status"]) and np.array_equal(info["iters"], oinfo["iters"]) and np.array_equal(info["n_refactor"], oinfo["n_refactor"])
+        assert np.abs(xs - oxs)[info["status"] == 1].max() < 1e-5
+        return
     _compare_every_path(info, oinfo, xs, oxs, st, ost, 0.6, eps=1e-4, check_every=ce)
 
 
@@ -85,9 +95,15 @@ def test_random_case_newton_matches_oracle(oracle, seed):
     refine = 0 sweep, a third of them with the corridors shrunk to 0.5 - 0.7 (soft margins bind, degenerate optima): statuses and certificates equal to the
     oracle's, solved points within 1e-5, every solved path certified — and, independent of the oracle's own Newton code, a KKT certificate of the DEVICE
     point computed from the assembled QP alone (np_twin.kkt_certificate: scipy's bounded least squares finds the multipliers)."""
+    _newton_case(oracle, seed)
+
+
+def _newton_case(oracle, seed, case=None, flagged=None):
+    """flagged: None = every solved path must be certified; else the expected status_refine of the five paths (a known case of the wider sweep in which the refinement
+    ends on a rounding floor / the edge of infeasibility on BOTH sides: solved, flagged -1)."""
     from path_optimizer_amd import binding
 
-    rng, form, b = _case(seed)
+    rng, form, b = (case or _case)(seed)
     if form == T.PO_KP:
         b.keep = binding.keep_control_steps(form, b.ref_s[0])
     st0 = rng.bit_generator.state
@@ -108,7 +124,11 @@ def test_random_case_newton_matches_oracle(oracle, seed):
     assert np.array_equal(fail_d, fail_o), (seed, info["status"], oinfo["status"])
     ok = ~fail_d
     assert np.array_equal(info["status_refine"][ok], oinfo["status_refine"][ok]), (seed, info["status_refine"], oinfo["status_refine"])
-    assert (info["status_refine"][ok] == 1).all(), (seed, form, b.N, b.keep, info["status_refine"], info["iters"])  # every solved path is certified
+    if flagged is None:
+        assert (info["status_refine"][ok] == 1).all(), (seed, form, b.N, b.keep, info["status_refine"], info["iters"])  # every solved path is certified
+    else:
+        assert list(info["status_refine"]) == list(flagged), (seed, info["status_refine"])
+        ok = ok & (info["status_refine"] == 1)  # (a path on a floor is compared in status and flag only: where on the floor it stops is decided by noise)
     if ok.any():
         assert np.abs(xs - oxs)[ok].max() < 1e-5, (seed, form, b.N, b.keep, np.abs(xs - oxs)[ok].max())
         assert np.abs(st - ost)[ok].max() < 1e-5
@@ -126,3 +146,60 @@ def test_random_case_newton_matches_oracle(oracle, seed):
         assert k["primal_violation"] < 1e-6 and k["stationarity_rel"] < 1e-5, (seed, form, n_i, b.keep, int(i), k)
         checked += 1
     assert checked > 0 or not ok.any()
+
+
+# ---- the wider sweeps as driver-run tests (their results used to live in DESIGN.md prose only) ----
+# Headline setting, seeds 48 .. 175 of the same generator plus the known exceptions (tools/fuzz_more.py ran 48 .. 1099): three cases end with paths solved-but-uncertified on device and oracle alike.
+_KNOWN_FLAGGED = {214: [-1, -1, 1, -1, 1], 250: [1, 1, -1, 1, 1], 251: None}
+# OSQP-faithful setting: cases whose one path agrees to 2.2e-6 .. 3.8e-6 only (equal counts)
+_KNOWN_LOOSE = {178, 201}
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("seed", list(range(48, 176)) + [214, 250, 251])
+def test_wider_sweep_headline(oracle, seed):
+    if seed in _KNOWN_FLAGGED and _KNOWN_FLAGGED[seed] is None:
+        # seed 251: which of its paths certifies is decided inside rounding noise (a corridor on the edge of infeasibility); asserted: device == oracle, nothing beyond -1 / 1
+        from path_optimizer_amd import binding
+        import test_newton as N
+
+        b, p = N._fuzz_case_at_headline(binding.default_params, seed)
+        bo, po = N._fuzz_case_at_headline(oracle.default_params, seed)
+        _, info, _ = binding.Engine(0, p).solve_batch(b, want_x=True)
+        _, oinfo, _ = oracle.solve_batch(bo, oracle.device_equivalent_params(po), want_x=True)
+        assert np.array_equal(info["status"], oinfo["status"]) and np.array_equal(info["status_refine"], oinfo["status_refine"]) and (info["status_refine"] == -1).any()
+        return
+    _newton_case(oracle, seed, flagged=_KNOWN_FLAGGED.get(seed))
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("seed", list(range(48, 112)) + [178, 201])
+def test_wider_sweep_osqp_faithful(oracle, seed):
+    _plain_case(oracle, seed, loose=seed in _KNOWN_LOOSE)
+
+
+def _wide_case(seed):
+    """KP, keep_control_steps_ 9 .. 16 (spacing 1.2 / keep), lengths up to the one-wave limit 32 keep of the wide role-split shapes, ragged (tools/fuzz_wide.py)."""
+    rng = np.random.default_rng(5000 + seed)
+    form = T.PO_KP
+    keep = int(rng.integers(9, 17))
+    ds = 1.2 / keep * 0.999
+    N = int(rng.integers(6, min(512, 32 * keep) + 1))
+    B = 5
+    narrow = bool(rng.integers(0, 2))
+    insts = [T.random_instance(rng, N, ds=ds, narrow=narrow) for _ in range(B)]
+    stk = lambda k: np.ascontiguousarray(np.stack([i[k] for i in insts]))
+    b = synth.Batch(form, B, N, 4, stk("ref_x"), stk("ref_y"), stk("ref_z"), stk("ref_k"), stk("ref_s"), stk("bounds"), stk("x0"), np.array([i["goal_z"] for i in insts]), None, None)
+    if rng.integers(0, 2):
+        npts = rng.integers(max(3, N // 3), N + 1, size=B).astype(np.int32)
+        npts[0] = N
+        b.n_points = npts
+    return rng, form, b
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("seed", range(24))
+def test_wide_shapes_sweep(oracle, seed):
+    """keep 9 .. 16 under both sweeps (the shapes the reference's own pipeline cannot produce but OsqpSolver::create accepts)."""
+    _plain_case(oracle, seed, case=_wide_case)
+    _newton_case(oracle, seed, case=_wide_case)

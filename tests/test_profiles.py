@@ -61,3 +61,25 @@ def test_pmc_summary_attributes_launches_to_their_solve(tmp_path):
     assert n["headline"]["pmc_f64"] == 3 and n["other"]["pmc_f64"] == 2
     assert S.flop_of(lambda c: S.per_solve(out, n, "headline", c, "pmc_f64")) == 64.0 * 2 * 40
     assert S.flop_of(lambda c: S.per_solve(out, n, "other", c, "pmc_f64")) == 64.0 * 2 * 100
+
+
+def test_committed_kernel_resources_describe_the_objects_that_ship():
+    """profiles/r5c/kernel_resources.txt listed 131 kernels of twelve objects the Makefile had stopped building (a glob over a box with leftovers).
+    tools/kernel_resources.py now takes the object list from the Makefile's link line; the newest committed listing names exactly objects on that line, and every
+    solve / Newton object of the line appears in it."""
+    import re
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as K
+
+    linked = set(K.linked_objects())
+    assert {"po_kernels.o", "po_newton_kp.o", "po_solve_kp_uni.o", "po_capi.o"} <= linked
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r6*", "kernel_resources.txt")))
+    assert files, "no round-6 kernel_resources.txt committed"
+    rows = [l.split()[0] for l in open(files[-1]).read().splitlines()[1:] if l.strip()]
+    named = set(rows)
+    assert named <= linked, sorted(named - linked)
+    mk = open(os.path.join(ROOT, "path_optimizer_amd", "csrc", "Makefile")).read()
+    solve_objs = set(re.findall(r"\$\(BUILD\)/(po_(?:solve|newton)_\w+\.o)", re.search(r"^SOLVE_OBJS :=(.*?)\n\n", mk, flags=re.S | re.M).group(1)))
+    assert solve_objs and solve_objs <= named, sorted(solve_objs - named)
