@@ -149,14 +149,14 @@ def _newton_case(oracle, seed, case=None, flagged=None):
 
 
 # ---- the wider sweeps as driver-run tests (their results used to live in DESIGN.md prose only) ----
-# Headline setting, seeds 48 .. 175 of the same generator plus the known exceptions (tools/fuzz_more.py ran 48 .. 1099): three cases end with paths solved-but-uncertified on device and oracle alike.
+# Headline setting, seeds 48 .. 127 of the same generator plus the known exceptions (tools/fuzz_more.py ran 48 .. 1099): three cases end with paths solved-but-uncertified on device and oracle alike.
 _KNOWN_FLAGGED = {214: [-1, -1, 1, -1, 1], 250: [1, 1, -1, 1, 1], 251: None}
 # OSQP-faithful setting: cases whose one path agrees to 2.2e-6 .. 3.8e-6 only (equal counts)
 _KNOWN_LOOSE = {178, 201}
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("seed", list(range(48, 176)) + [214, 250, 251])
+@pytest.mark.parametrize("seed", list(range(48, 128)) + [214, 250, 251])
 def test_wider_sweep_headline(oracle, seed):
     if seed in _KNOWN_FLAGGED and _KNOWN_FLAGGED[seed] is None:
         # seed 251: which of its paths certifies is decided inside rounding noise (a corridor on the edge of infeasibility); asserted: device == oracle, nothing beyond -1 / 1
@@ -173,7 +173,7 @@ def test_wider_sweep_headline(oracle, seed):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("seed", list(range(48, 112)) + [178, 201])
+@pytest.mark.parametrize("seed", list(range(48, 96)) + [178, 201])
 def test_wider_sweep_osqp_faithful(oracle, seed):
     _plain_case(oracle, seed, loose=seed in _KNOWN_LOOSE)
 
@@ -198,7 +198,7 @@ def _wide_case(seed):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(16))
 def test_wide_shapes_sweep(oracle, seed):
     """keep 9 .. 16 under both sweeps (the shapes the reference's own pipeline cannot produce but OsqpSolver::create accepts)."""
     _plain_case(oracle, seed, case=_wide_case)

@@ -136,7 +136,8 @@ def test_device_newton_matches_oracle_and_optimum(oracle, name, B, kw):
         assert (info["status_refine"] == 1).all() and (oinfo["status_refine"] == 1).all()
     di = np.abs(info["iters"].astype(int) - oinfo["iters"].astype(int))
     if "refine_newton_max" not in kw:
-        assert (di <= 1).mean() >= (0.65 if name == "c5" else 0.88) and (di <= 2).mean() >= (0.85 if name == "c5" else 0.95), ((di <= 1).mean(), (di <= 2).mean(), info["iters"][di > 1], oinfo["iters"][di > 1])
+        # (KPC: measured on the round-6 tree 0.78 within one step, 0.97 within two, all within three, on 32 and on 96 paths — the forks are decisions inside rounding noise)
+        assert (di <= 1).mean() >= (0.72 if name == "c5" else 0.88) and (di <= 2).mean() >= (0.93 if name == "c5" else 0.95), ((di <= 1).mean(), (di <= 2).mean(), info["iters"][di > 1], oinfo["iters"][di > 1])
     assert (di <= 3).mean() >= 0.9 and abs(info["iters"].mean() - oinfo["iters"].mean()) <= 0.05 * oinfo["iters"].mean()
     dx = np.abs(xs - oxs).max(axis=1)
     assert dx.max() < 1e-4 and np.median(dx) < 1e-8, (dx.max(), np.median(dx))
