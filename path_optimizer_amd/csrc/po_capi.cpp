@@ -320,6 +320,30 @@ int po_debug_get(po_handle h, const char *key, long long *value) {
         *value = c;
         return PO_OK;
     }
+    if (k == "newton_list_ok") {  // sliced Newton launches: is the second launch's list what nw_sort_kernel promises — every parked path exactly once, keys non-increasing, ties in path
+        // order?  1 yes, 0 no, -1 the last solve was not sliced.  (The results of a solve do not depend on the list's ORDER, so only this check sees an ordering bug.)
+        *value = -1;
+        if (!h->nw_idx_buf.p || h->nw_last_B <= 0) return PO_OK;
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        const int B = h->nw_last_B;
+        std::vector<int> kl(2 * (size_t)B + 1);
+        HIP_TRY(hipMemcpy(kl.data(), h->nw_idx_buf.p, sizeof(int) * kl.size(), hipMemcpyDeviceToHost));
+        const int *keys = kl.data(), *list = kl.data() + B;
+        const int n = list[0];
+        int parked = 0;
+        for (int b = 0; b < B; ++b) parked += keys[b] >= 0;
+        bool ok = n == parked;
+        std::vector<char> seen((size_t)B, 0);
+        for (int i = 0; ok && i < n; ++i) {
+            const int b = list[1 + i];
+            ok = b >= 0 && b < B && keys[b] >= 0 && !seen[(size_t)b];
+            if (ok) seen[(size_t)b] = 1;
+            if (ok && i > 0) { const int a = list[i]; ok = keys[a] > keys[b] || (keys[a] == keys[b] && a < b); }
+        }
+        *value = ok ? 1 : 0;
+        return PO_OK;
+    }
     return PO_ERR_INVALID;
 }
 

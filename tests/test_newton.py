@@ -361,8 +361,9 @@ def test_sliced_newton_launches_change_nothing_but_the_schedule(case):
         e = binding.Engine(0, p)
         e.debug_set("newton_slice", sl)
         st, info, xs = e.solve_batch(b, want_x=True)
-        out[sl] = (st.copy(), info.copy(), xs.copy(), e.debug_get("newton_parked"))
+        out[sl] = (st.copy(), info.copy(), xs.copy(), e.debug_get("newton_parked"), e.debug_get("newton_list_ok"))
     assert out[0][3] == -1 and out[8][3] >= 0 and out[3][3] >= out[8][3]
+    assert out[0][4] == -1 and out[8][4] == 1 and out[3][4] == 1  # the second launch's list: every parked path once, keys non-increasing, ties in path order (nw_sort_kernel)
     if case in ("c3", "c5", "k"):
         assert out[8][3] > 0.5 * b.B  # nearly every path needs more than 8 steps
     for sl in (8, 3):
