@@ -1070,10 +1070,25 @@ def main():
                 rf["frac_of_measured_issue_ceiling"] = {k: rf["achieved"] / v for k, v in FP64_VALU_MEASURED_CEILING.items()} if rf.get("achieved") else None
                 nk_ms = (out["single_batch"].get("phases_ms_last_step") or {}).get("newton")
                 if lt.get("newton_kernel_fp64_flop_per_launch") and nk_ms:
-                    rf["dominant_kernel"] = {"kernel": "po::newton_kernel<KP,4,64>: the sliced pair of launches (8 steps of every path; the parked rest, longest expected first) with the 13 us sort between them (+ the fallback launch behind, empty here)", "launch_ms": nk_ms,
+                    rf["dominant_kernel"] = {"kernel": "po::newton_kernel<KP,4,64>: the sliced pair of launches (8 steps of every path; the parked rest, longest expected first) with the 22 us sort between them (+ the fallback launch behind, empty here)", "launch_ms": nk_ms,
                                              "fp64_flop_per_launch": lt["newton_kernel_fp64_flop_per_launch"], "achieved": lt["newton_kernel_fp64_flop_per_launch"] / (nk_ms * 1e-3) / 1e12,
                                              "frac": lt["newton_kernel_fp64_flop_per_launch"] / (nk_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                                              "launch_ms_source": "hipEvents on the engine's stream around the launch (po_last_phase_ms), last timed step"}
+                    # what bounds it (round 6): the issue cadence of a lone wave per SIMD — from the newest committed counter attribution (tools/stall_pmc.sh; the split of a
+                    # wave's resident time does not depend on the run), beside the same counters of a cache-resident loop of independent v_fma_f64 (tools/ubench/issue_mix.hip)
+                    sa = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r6*", "stall_attribution.json")))
+                    sj = _load_json(sa[-1]) if sa else None
+                    try:
+                        dk = sj["by_batch_size"]["4096"]["derived"]["po::newton_kernel<0, 4, 64, 1, 1>"]
+                        rf["dominant_kernel"]["issue_attribution"] = {
+                            "frac_issuing": dk["frac_issuing"], "frac_wait_any": dk["frac_wait_any"], "frac_wait_inst_any": dk["frac_wait_inst_any"], "cycles_per_instruction": dk["cycles_per_inst"],
+                            "instruction_cache_miss_rate": dk["icache_miss_rate"], "lds_bank_conflict_of_lds_active": dk["lds_bank_conflict_of_active"],
+                            "lone_wave_loop_of_independent_v_fma_f64": {"frac_issuing": 0.653, "frac_wait_any": 0.347, "frac_wait_inst_any": 0.0, "cycles_per_instruction": 6.13},
+                            "reading": "a wave alone on its SIMD issues ANY independent VALU stream at 6 - 7 cycles per instruction (two waves: 3.4 - 3.8 per SIMD); the kernel sits at that "
+                                       "cadence — no memory, LDS, scratch or instruction-fetch stall to remove; 38 % of its instructions are fp64, hence frac 0.13 of the fp64 lane peak",
+                            "source": os.path.relpath(sa[-1], ROOT) + ", profiles/r6a/ubench/issue_mix_pmc.json"}
+                    except (KeyError, TypeError):
+                        pass
         torch.cuda.synchronize()
         out["gpu_done_s"] = time.time()  # everything after this timestamp is host-only (CPU baseline / checker legs)
         if args.cpu_sample > 0:
