@@ -1070,7 +1070,7 @@ def main():
                 rf["frac_of_measured_issue_ceiling"] = {k: rf["achieved"] / v for k, v in FP64_VALU_MEASURED_CEILING.items()} if rf.get("achieved") else None
                 nk_ms = (out["single_batch"].get("phases_ms_last_step") or {}).get("newton")
                 if lt.get("newton_kernel_fp64_flop_per_launch") and nk_ms:
-                    rf["dominant_kernel"] = {"kernel": "po::newton_kernel<KP,4,64>: the sliced pair of launches (8 steps of every path; the parked rest, longest expected first) with the 22 us sort between them (+ the fallback launch behind, empty here)", "launch_ms": nk_ms,
+                    rf["dominant_kernel"] = {"kernel": "po::newton_kernel<KP,4,64>: the sliced pair of launches (8 steps of every path; the parked rest, longest expected first) with the 10 us sort between them (+ the fallback launch behind, empty here)", "launch_ms": nk_ms,
                                              "fp64_flop_per_launch": lt["newton_kernel_fp64_flop_per_launch"], "achieved": lt["newton_kernel_fp64_flop_per_launch"] / (nk_ms * 1e-3) / 1e12,
                                              "frac": lt["newton_kernel_fp64_flop_per_launch"] / (nk_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                                              "launch_ms_source": "hipEvents on the engine's stream around the launch (po_last_phase_ms), last timed step"}
