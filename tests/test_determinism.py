@@ -1,0 +1,28 @@
+"""The solve does not depend on what the machine held before it (GPU).  VGPRs, AccVGPRs and LDS are not cleared between waves / workgroups: a kernel that reads a register or an
+LDS word it never wrote normally sees leftovers of its own earlier waves and passes every parity test — until a change of the register allocation turns the read into garbage
+(round 6: a scalar condition that is never true, added to newton_kernel, produced non-deterministic statuses on the infeasible paths of the ragged batch and a wild store in the
+SPL = 6 role-split shape).  tools/poison_check.py solves 24 cases — every mapping, sliced and unsliced Newton launches, the fall-back rounds, polish, the
+single-level chain — three times each, after every VGPR / AccVGPR of every lane and all LDS of every CU have been filled with NaN payloads, with zeros, and with NaNs again
+(tools/ubench/poison.hip): the three results must be bitwise equal."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_results_do_not_depend_on_register_or_lds_leftovers():
+    so = os.path.join(ROOT, "tools", "ubench", ".bin", "libpoison.so")
+    if not os.path.exists(so):
+        hipcc = "/opt/rocm/bin/hipcc"
+        if not os.path.exists(hipcc):
+            pytest.skip("no libpoison.so and no hipcc to build it")
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-Wno-unused-value", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tools", "ubench", "poison.hip")])
+    # own process: the poison library and libpo_hip.so share one HIP runtime there, and a fault (what such a bug can also look like) does not take the test session down
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "poison_check.py")], capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith(("SAME", "DIFFER"))]
+    assert r.returncode == 0 and len(lines) >= 20 and all(l.startswith("SAME") for l in lines), (r.stdout[-3000:], r.stderr[-1500:])

@@ -1,0 +1,86 @@
+"""Dev tool (GPU box): do the solve kernels read a REGISTER (or an LDS word) they never wrote?
+VGPRs, AccVGPRs and LDS are not cleared between waves / workgroups, so such a read normally sees harmless leftovers of the same kernel and survives every parity test — until a
+one-line change moves the register allocation (round 6: a condition that is never true put NaNs into the fall-back rounds of the ragged test batch).
+tools/ubench/poison.hip fills every VGPR / AccVGPR of every lane and all 160 KB of LDS on every CU with a pattern; this tool solves each case after a NaN-payload poison and after
+a zero poison (and once more after the NaN poison): results must be BITWISE equal.  Cases: the headline shape (sliced, unsliced), the ragged batch whose infeasible paths go
+through the fall-back rounds, KPC, K, role-split and multi-group shapes, the OSQP-faithful solve, the polish.
+    hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tools/ubench/.bin/libpoison.so tools/ubench/poison.hip ; python tools/poison_check.py"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+NAN_PATTERN = 0x7FF8DEAD7FF8BEEF  # both halves of every 64-bit pair are quiet-NaN bit patterns as doubles AND as floats
+HEAD = dict(refine=2, refine_rounds=5, refine_extra_rounds=2, refine_eps=1e-8, refine_chain=2)
+
+
+def cases():
+    import np_twin as T
+    from path_optimizer_amd import synth
+
+    def rand(keep, N, B, seed):
+        rng = np.random.default_rng(seed)
+        insts = [T.random_instance(rng, N, ds=1.2 / keep * 0.999) for _ in range(B)]
+        st = lambda k: np.ascontiguousarray(np.stack([i[k] for i in insts]))
+        return synth.Batch(0, B, N, keep, st("ref_x"), st("ref_y"), st("ref_z"), st("ref_k"), st("ref_s"), st("bounds"), st("x0"), np.array([i["goal_z"] for i in insts]))
+
+    rag = synth.make_batch(3, B=333)
+    rag.n_points = np.random.default_rng(5).integers(60, 201, size=333).astype(np.int32)
+    yield "c3 headline, engine's slicing (B 2048)", synth.make_batch(3, B=2048), HEAD, None
+    yield "c3 headline, unsliced", synth.make_batch(3, B=700), HEAD, 0
+    yield "c3 headline, sliced 8", synth.make_batch(3, B=700), HEAD, 8
+    yield "c3 ragged (14 infeasible paths -> fall-back rounds), unsliced", rag, HEAD, 0
+    yield "c3 ragged, sliced 3", rag, HEAD, 3
+    yield "c3 OSQP-faithful", synth.make_batch(3, B=512), {}, None
+    yield "c3 OSQP-faithful + polish", synth.make_batch(3, B=256), dict(polish=1), None
+    yield "c5 KPC headline", synth.make_batch(5, B=192), HEAD, None
+    yield "c5 KPC sliced 8", synth.make_batch(5, B=96), HEAD, 8
+    yield "K headline sliced 8", synth.make_batch(3, B=300, formulation=2), HEAD, 8
+    yield "K OSQP-faithful", synth.make_batch(3, B=200, formulation=2), {}, None
+    yield "c2 headline", synth.make_batch(2, B=512), HEAD, None
+    for keep in (1, 2, 3, 5, 6, 7, 8, 10, 12, 15):
+        yield f"keep {keep} headline sliced 8", rand(keep, 150, 64, 7 + keep), HEAD, 8
+    yield "keep 12 headline unsliced", rand(12, 150, 64, 19), HEAD, 0
+    yield "keep 17 (single-level chain) OSQP-faithful", rand(17, 120, 16, 40), {}, None
+
+
+def main():
+    import torch  # noqa: F401  (one HIP runtime for both libraries)
+
+    from path_optimizer_amd import binding
+
+    P = ctypes.CDLL(os.path.join(ROOT, "tools", "ubench", ".bin", "libpoison.so"))
+    P.po_poison_what.argtypes = [ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_int]
+    what = int(os.environ.get("POISON_WHAT", "3"))  # 1 registers only, 2 LDS only, 3 both
+    bad = 0
+    for name, b, kw, sl in cases():
+        res = []
+        for pattern in (NAN_PATTERN, 0, NAN_PATTERN):
+            p = binding.default_params()
+            for k, v in kw.items():
+                setattr(p, k, v)
+            e = binding.Engine(0, p)
+            if sl is not None:
+                e.debug_set("newton_slice", sl)
+            assert P.po_poison_what(pattern, None, what) == 0
+            st, info, xs = e.solve_batch(b, want_x=True)
+            res.append((st.copy(), info.copy(), xs.copy()))
+            e.close()
+        same = all(np.array_equal(res[0][j].view(np.uint8), res[i][j].view(np.uint8)) for i in (1, 2) for j in (0, 2)) and all(
+            res[0][1].tobytes() == res[i][1].tobytes() for i in (1, 2))
+        diffs = ""
+        if not same:
+            bad += 1
+            d = np.flatnonzero([(not np.array_equal(res[0][2][q].view(np.uint64), res[1][2][q].view(np.uint64))) or res[0][1][q].tobytes() != res[1][1][q].tobytes() for q in range(b.B)])
+            diffs = f" paths that differ (NaN poison vs zero poison): {d.tolist()[:12]} statuses {res[0][1]['status'][d][:8].tolist()} vs {res[1][1]['status'][d][:8].tolist()}"
+        print(("SAME   " if same else "DIFFER ") + name + diffs, flush=True)
+    print("cases that differ:", bad)
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main() else 0)
