@@ -33,6 +33,8 @@ def run(shares, chain=3, reps=9):
     engs = []
     for _ in dbs:
         e = binding.Engine(0, params(chain)); s = torch.cuda.Stream(); e.set_stream(s.cuda_stream); engs.append((e, s))
+        if os.environ.get("SPLIT_FORCE_SLICE"):
+            e.debug_set("newton_slice", int(os.environ["SPLIT_FORCE_SLICE"]))
     ts = []
     for r in range(3 + reps):
         torch.cuda.synchronize()
@@ -47,5 +49,5 @@ def run(shares, chain=3, reps=9):
 
 
 if __name__ == "__main__":
-    for sh, ch in (((1,), 2), ((1,), 3), ((1, 1), 3), ((1, 2), 3), ((2, 1), 3), ((1, 1, 1), 3), ((1, 2, 3), 3), ((1, 1, 1, 1), 3), ((3, 1), 3)):
+    for sh, ch in (((1,), 2), ((1,), 3), ((1, 1), 3), ((1, 2), 3), ((2, 1), 3), ((1, 1, 1), 3), ((1, 2, 3), 3), ((1, 1, 1, 1), 3), ((3, 1), 3), ((1, 3), 3), ((7, 1), 3), ((1, 7), 3), ((4, 2, 1, 1), 3), ((1, 1, 2, 4), 3)):
         print(json.dumps(run(sh, ch)), flush=True)
