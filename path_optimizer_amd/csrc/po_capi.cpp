@@ -417,6 +417,7 @@ static void fill_dev_batch(const po_handle_s *h, po::DevBatch *D, const po_batch
     D->round = 0;
     D->fb_list = nullptr;
     D->nw_phase = 0; D->nw_state = nullptr; D->nw_stride = 0; D->nw_keys = nullptr; D->nw_list = nullptr;
+    D->nw_follows = 0;
     D->n = n; D->m = m;
 }
 
@@ -462,7 +463,9 @@ int po_solve_batch_device(po_handle h, const po_batch_in *in, const po_batch_out
     if (split) {
         po::DevParams P1 = P;  // the warm start: the plain solve kernels, stopped where round 0 of the rounds stops (10^(R-1) x eps)
         for (int r = 1; r < (h->params.refine_rounds > 1 ? h->params.refine_rounds : 1); ++r) { P1.eps_abs *= 10.0; P1.eps_rel *= 10.0; }
+        D.nw_follows = 1;  // (newton_kernel writes the outputs of the paths this launch reports SOLVED)
         HIP_TRY(po_launch_solve(in->formulation, &D, &P1, h->stream, nullptr));
+        D.nw_follows = 0;
         HIP_TRY(hipEventRecord(h->evp[0], h->stream));
         D.fb_list = static_cast<int *>(h->fb_buf.p);
         HIP_TRY(hipMemsetAsync(D.fb_list, 0, sizeof(int), h->stream));

@@ -66,6 +66,9 @@ struct DevBatch {
     int nw_stride;
     int *nw_keys;           // [B]: -1 finished in the first launch, else the priority key (larger = longer expected)
     int *nw_list;           // count, then the parked path ids in launch order (nw_sort_kernel)
+    // set by the engine on the warm-start launch of a split solve (po_params.refine = 2): newton_kernel follows on the same stream and writes the outputs of every path
+    // the warm start reports SOLVED (from its own result, or — attempt not taken — from the state block), so the solve kernel skips its output pass for those
+    int nw_follows;
 };
 
 template <int F> struct FormTraits;
@@ -326,6 +329,15 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 #endif
+// A WAVE-UNIFORM double into scalar registers.  Why it matters (round 6): a uniform value that VALU arithmetic produced lives in a VGPR, one copy per
+// lane, and the register allocator may park such a copy (scratch / AccVGPR) INSIDE a region that only part of the wave executes — e.g. the `stage(q) < N` body of a slot the
+// path's last lane does not own — and read it back under the full mask: the lanes that sat the region out get whatever their slot held.  Found on newton_kernel<KP,4,64,1,1>:
+// rho of the warm start (loaded at kernel entry, used by the phase's last pass) came back 0 on the last lane of every path whose length is not a multiple of four, and the
+// state handed to the fall-back rounds was Inf / NaN there.  SGPRs are spilled with v_writelane / v_readlane, which ignore the execution mask.
+__device__ __forceinline__ double uni(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // exponent all ones: Inf or NaN.  An integer test on purpose: the build uses -fno-honor-nans, under which `v != v` folds to false, and the
 // residual norms are fmax-accumulated (fmax drops a NaN operand), so a non-finite iterate would otherwise read as "converged".
 // The high word goes through an empty asm: otherwise the optimiser recognises the mask-and-compare as is.fpclass(v, inf | nan) and, the producing

@@ -326,6 +326,31 @@ def test_device_status_refine_says_what_was_certified(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("slice_", [0, 3, 8])
+def test_failed_attempts_on_ragged_lengths_hand_back_finite_states(oracle, slice_):
+    """Round 6: the single (unsliced) Newton launch handed the fall-back rounds a state block with Inf / NaN on the LAST lane of every path whose length is not a multiple of
+    four whenever the attempt was not certified: a wave-uniform scalar kept one copy per lane (rho of the warm start, read at kernel entry, used by the phase's last pass) came
+    back 0 on that lane, the re-expression of v divided by it, and the type-based iteration that followed went non-finite (status -8 where the oracle detects the infeasible
+    corridor, -3) — on 9 of the 14 infeasible paths of this batch, the other 5 being the ones with 4 | n_points.  Which builds showed it depended on the register allocation
+    (DESIGN.md section 12); the scalars the phase carries now live in scalar registers (uni(), csrc/po_device.hpp).  Device = oracle on every status, no path non-finite."""
+    from path_optimizer_amd import binding, synth
+
+    b = synth.make_batch(3, B=333)
+    b.n_points = np.random.default_rng(5).integers(60, 201, size=333).astype(np.int32)
+    p = _set(binding.default_params(), **NEWTON)
+    e = binding.Engine(0, p)
+    e.debug_set("newton_slice", slice_)
+    st, info, xs = e.solve_batch(b, want_x=True)
+    ost, oinfo, oxs = oracle.solve_batch(b, oracle.device_equivalent_params(p))
+    bad = np.flatnonzero(oinfo["status"] != 1)
+    assert len(bad) == 14 and (b.n_points[bad] % 4 != 0).sum() == 9  # the batch the bug was found on
+    assert np.array_equal(info["status"], oinfo["status"]), (info["status"][bad].tolist(), oinfo["status"][bad].tolist())
+    assert (info["status"] != -8).all() and np.isfinite(st).all() and np.isfinite(xs).all()
+    # (an infeasible path: several Newton attempts and rounds of type-based iterations before the certificate fires; device and oracle fork on rounding in the attempts)
+    assert (np.abs(info["iters"][bad] - oinfo["iters"][bad]) <= 0.35 * oinfo["iters"][bad] + 50).all(), (info["iters"][bad].tolist(), oinfo["iters"][bad].tolist())  # measured: 1 .. 55, one path 271 of 950
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["c3", "c3_ragged", "keep2", "keep6", "keep7", "keep12", "keep15", "c5", "k", "tiny"])
 def test_sliced_newton_launches_change_nothing_but_the_schedule(case):
     """The engine issues the Newton refinement as TWO launches (every path for 8 steps; the unfinished ones parked, sorted by expected remaining work, resumed longest

@@ -57,7 +57,10 @@ def main():
     P.po_poison_what.argtypes = [ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_int]
     what = int(os.environ.get("POISON_WHAT", "3"))  # 1 registers only, 2 LDS only, 3 both
     bad = 0
+    only = os.environ.get("POISON_ONLY", "")
     for name, b, kw, sl in cases():
+        if only and only not in name:
+            continue
         res = []
         for pattern in (NAN_PATTERN, 0, NAN_PATTERN):
             p = binding.default_params()
@@ -77,6 +80,15 @@ def main():
             bad += 1
             d = np.flatnonzero([(not np.array_equal(res[0][2][q].view(np.uint64), res[1][2][q].view(np.uint64))) or res[0][1][q].tobytes() != res[1][1][q].tobytes() for q in range(b.B)])
             diffs = f" paths that differ (NaN poison vs zero poison): {d.tolist()[:12]} statuses {res[0][1]['status'][d][:8].tolist()} vs {res[1][1]['status'][d][:8].tolist()}"
+            for i in (1, 2):  # which output differs between which runs, and where
+                for j, nm in ((0, "states"), (2, "x")):
+                    a, c = res[0][j].view(np.uint64).reshape(b.B, -1), res[i][j].view(np.uint64).reshape(b.B, -1)
+                    rows = np.flatnonzero((a != c).any(axis=1))
+                    if len(rows):
+                        q = int(rows[0]); cols = np.flatnonzero(a[q] != c[q])
+                        diffs += f" | run 0 vs {i}: {nm} differ on {len(rows)} paths, first {rows[:8].tolist()}; path {q} (n_points {int(b.n_points[q]) if getattr(b, 'n_points', None) is not None else b.N}, status {int(res[0][1]['status'][q])}, refine {int(res[0][1]['status_refine'][q])}): words {cols[:10].tolist()} of {a.shape[1]}, e.g. {res[0][j].reshape(b.B, -1)[q][cols[:3]].tolist()} vs {res[i][j].reshape(b.B, -1)[q][cols[:3]].tolist()}"
+                if res[0][1].tobytes() != res[i][1].tobytes():
+                    diffs += f" | run 0 vs {i}: info differs"
         print(("SAME   " if same else "DIFFER ") + name + diffs, flush=True)
     print("cases that differ:", bad)
     return bad
