@@ -4,6 +4,10 @@ one-line change moves the register allocation (round 6: a condition that is neve
 tools/ubench/poison.hip fills every VGPR / AccVGPR of every lane and all 160 KB of LDS on every CU with a pattern; this tool solves each case after a NaN-payload poison and after
 a zero poison (and once more after the NaN poison): results must be BITWISE equal.  Cases: the headline shape (sliced, unsliced), the ragged batch whose infeasible paths go
 through the fall-back rounds, KPC, K, role-split and multi-group shapes, the OSQP-faithful solve, the polish.
+What it can and cannot see (round 6, second session): the poison reaches the FIRST kernel of a solve only — every later kernel sees the leftovers of the kernels
+before it — so for the Newton / fall-back kernels the three runs differ by which hardware wave slot a path lands on (the poison launch shifts the dispatcher), not by the pattern.
+That was enough to expose the bug of section 13 (a wave-uniform scalar lost on the last lane of paths with n_points % 4 != 0: run 2 differed from runs 0 and 1), but a "SAME" is a
+sample, not a proof.  POISON_ONLY=<substring> runs the matching cases only; a DIFFER line says which output differs between which runs, and where.
     hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tools/ubench/.bin/libpoison.so tools/ubench/poison.hip ; python tools/poison_check.py"""
 import ctypes
 import os
