@@ -334,10 +334,15 @@ __device__ __forceinline__ double wave_sum(double v) {
 // path's last lane does not own — and read it back under the full mask: the lanes that sat the region out get whatever their slot held.  Found on newton_kernel<KP,4,64,1,1>:
 // rho of the warm start (loaded at kernel entry, used by the phase's last pass) came back 0 on the last lane of every path whose length is not a multiple of four, and the
 // state handed to the fall-back rounds was Inf / NaN there.  SGPRs are spilled with v_writelane / v_readlane, which ignore the execution mask.
+#ifndef PO_NO_UNI  // (-DPO_NO_UNI: the values stay where the compiler puts them — the build tools/poison_check.py's placement check is validated against)
 __device__ __forceinline__ double uni(double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#else
+__device__ __forceinline__ double uni(double v) { return v; }
+__device__ __forceinline__ int uni(int v) { return v; }
+#endif
 // exponent all ones: Inf or NaN.  An integer test on purpose: the build uses -fno-honor-nans, under which `v != v` folds to false, and the
 // residual norms are fmax-accumulated (fmax drops a NaN operand), so a non-finite iterate would otherwise read as "converged".
 // The high word goes through an empty asm: otherwise the optimiser recognises the mask-and-compare as is.fpclass(v, inf | nan) and, the producing

@@ -98,5 +98,68 @@ def main():
     return bad
 
 
+def placement():
+    """The same solve on different PARTS of the chip (HIP streams with a CU mask: all CUs, two complementary halves, every fourth CU) and after an unrelated batch has run: a
+    path then lands on other wave slots, behind other leftovers in registers, LDS and scratch.  Results must be bitwise equal.  (The bug of DESIGN.md section 13 was of this kind:
+    what a scratch slot of the path's last lane held decided the status.)"""
+    import torch  # noqa: F401
+
+    from path_optimizer_amd import binding, synth
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipExtStreamCreateWithCUMask.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+    hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    words = (ncu + 31) // 32
+
+    def masked_stream(bits):
+        m = (ctypes.c_uint32 * words)(*[sum(1 << k for k in range(32) if 32 * w + k < ncu and bits(32 * w + k)) for w in range(words)])
+        st = ctypes.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), words, m)
+        assert rc == 0 and st.value, rc
+        return st
+
+    masks = [("all CUs", None), ("first half", lambda c: c < ncu // 2), ("second half", lambda c: c >= ncu // 2), ("every fourth CU", lambda c: c % 4 == 1), ("all CUs, after another batch", None)]
+    other = synth.make_batch(3, B=1500)
+    bad = 0
+    wanted = ("c3 ragged", "c3 headline, unsliced", "c5 KPC headline", "K headline", "keep 3 ", "keep 6 ", "keep 12 headline sliced", "c3 OSQP-faithful")
+    only = os.environ.get("POISON_ONLY", "")
+    for name, b, kw, sl in cases():
+        if not name.startswith(wanted) or (only and only not in name):
+            continue
+        res = []
+        for label, bits in masks:
+            p = binding.default_params()
+            for k, v in kw.items():
+                setattr(p, k, v)
+            e = binding.Engine(0, p)
+            if sl is not None:
+                e.debug_set("newton_slice", sl)
+            st_ = None
+            if bits is not None:
+                st_ = masked_stream(bits)
+                e.set_stream(st_.value)
+            if label.endswith("another batch"):
+                e.solve_batch(other)
+            st, info, xs = e.solve_batch(b, want_x=True)
+            res.append((label, st.copy(), info.copy(), xs.copy()))
+            e.close()
+            if st_ is not None:
+                hip.hipStreamDestroy(st_)
+        diff = [r[0] for r in res[1:] if not (np.array_equal(r[1].view(np.uint64), res[0][1].view(np.uint64)) and np.array_equal(r[3].view(np.uint64), res[0][3].view(np.uint64)) and r[2].tobytes() == res[0][2].tobytes())]
+        bad += bool(diff)
+        extra = ""
+        if diff:
+            r = next(r for r in res[1:] if r[0] == diff[0])
+            rows = np.flatnonzero((r[3].view(np.uint64) != res[0][3].view(np.uint64)).any(axis=1) | (r[2]["status"] != res[0][2]["status"]))
+            extra = f" differs on: {diff}; first paths {rows[:8].tolist()} statuses {res[0][2]['status'][rows[:8]].tolist()} vs {r[2]['status'][rows[:8]].tolist()}"
+        print(("SAME   " if not diff else "DIFFER ") + "placement: " + name + extra, flush=True)
+    print("placement cases that differ:", bad)
+    return bad
+
+
 if __name__ == "__main__":
-    sys.exit(1 if main() else 0)
+    rc = main()
+    if os.environ.get("POISON_PLACEMENT", "1") != "0":
+        rc += placement()
+    sys.exit(1 if rc else 0)
