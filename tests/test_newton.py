@@ -351,7 +351,10 @@ def test_failed_attempts_on_ragged_lengths_hand_back_finite_states(oracle, slice
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["c3", "c3_ragged", "keep2", "keep6", "keep7", "keep12", "keep15", "c5", "k", "tiny"])
+@pytest.mark.parametrize("case", ["c3", "c3_ragged", "keep2", "keep6", "keep7", "keep12", "keep15", "c5", "k", "tiny",
+                                  # (round 6, second session: every other mapping too, and ragged KPC / K batches — the long loops of the UNSLICED launch are the library's
+                                  #  least-exercised code)
+                                  "keep1", "keep3", "keep5", "keep8", "keep9", "keep10", "keep16", "c5_ragged", "k_ragged"])
 def test_sliced_newton_launches_change_nothing_but_the_schedule(case):
     """The engine issues the Newton refinement as TWO launches (every path for 8 steps; the unfinished ones parked, sorted by expected remaining work, resumed longest
     first — po_debug_set "newton_slice").  Parking and resuming keep every number the phase carries: statuses and certificates are those of the single launch, the solutions
@@ -372,8 +375,14 @@ def test_sliced_newton_launches_change_nothing_but_the_schedule(case):
         b.n_points = np.random.default_rng(5).integers(60, 201, size=333).astype(np.int32)
     elif case == "c5":
         b = synth.make_batch(5, B=96)
+    elif case == "c5_ragged":
+        b = synth.make_batch(5, B=80)
+        b.n_points = np.random.default_rng(6).integers(150, 401, size=80).astype(np.int32)
     elif case == "k":
         b = synth.make_batch(3, B=130, formulation=2)
+    elif case == "k_ragged":
+        b = synth.make_batch(3, B=150, formulation=2)
+        b.n_points = np.random.default_rng(7).integers(60, 201, size=150).astype(np.int32)
     elif case == "tiny":
         b = synth.make_batch(3, B=1)
     else:
@@ -394,11 +403,13 @@ def test_sliced_newton_launches_change_nothing_but_the_schedule(case):
     for sl in (8, 3):
         # the same operations in the same order; the kernels of the two launches are compiled separately and may contract multiply-adds differently, so the iterates
         # agree to round-off, not bit for bit (measured: identical on the KP keep 3 / 4 and K shapes, <= 7e-11 elsewhere)
-        assert np.abs(out[sl][0] - out[0][0]).max() < 1e-8 and np.abs(out[sl][2] - out[0][2]).max() < 1e-8
+        cert = (out[0][1]["status"] == 1) & (out[0][1]["status_refine"] == 1)  # (an uncertified path went through the rounds: hundreds of type-based iterations amplify the round-off)
+        assert np.abs(out[sl][0] - out[0][0])[cert].max() < 1e-8 and np.abs(out[sl][2] - out[0][2])[cert].max() < 1e-8
+        assert np.abs(out[sl][0] - out[0][0]).max() < 1e-6 and np.abs(out[sl][2] - out[0][2]).max() < 1e-6
         for f in ("status", "status_refine", "status_polish"):
             assert np.array_equal(out[sl][1][f], out[0][1][f]), f
         assert np.abs(out[sl][1]["iters"] - out[0][1]["iters"]).max() <= 3 and (out[sl][1]["iters"] != out[0][1]["iters"]).mean() <= 0.05
-    if case != "c3_ragged":  # (config-3 paths cut short at a random point: 14 of 333 go through the fallback rounds — the parked / resumed state feeds those as well)
+    if not case.endswith("_ragged"):  # (paths cut short at a random point: some are infeasible (14 of 333 of config 3) and go through the fallback rounds — the parked / resumed state feeds those as well)
         assert (out[0][1]["status_refine"] == 1).all()
 
 
